@@ -20,6 +20,8 @@ What is a stand-in (the reference's native core cannot be built without CUDA):
     core/parallel/expert_module.cpp, and returns results in enqueue order.
   * ``MixtralBlockSparseTop2MLP`` (removed from transformers 5.x) is re-declared with
     the 4.37 definition so models/mixtral.py imports.
+  * the HF 5.15 NLLB router no longer flattens [B,S,H] to [B*S,H] itself (4.37 did); the
+    generator flattens before calling it and keeps the 4.37 return arity.
   * the HF 5.15 Switch router returns (probs, index, logits); it is adapted back to the
     4.37 order (index, probs, logits) the reference unpacks, and its keepdim quirk is
     bypassed by calling the 4.37 formula on its own classifier weights.
@@ -273,10 +275,19 @@ def gen_nllb(mods, name, b, s, h, f, e, seed, dtype=torch.bfloat16, norm_before=
             ex.fc2.weight.copy_(w2)
             ex.fc2.bias.copy_(b2)
     blk.layer_id = 0
-    blk.expert_executor = make_executor(mods, FakeDispatcher(lambda i: blk.experts[f"expert_{i}"]))
+
+    def nllb_expert(i):
+        # core/parallel/expert_module.cpp:88-93 op sequence (matmul, THEN bias add: two roundings in
+        # bf16) on the HF module's parameters; HF's fused F.linear(bias) rounds once and differs by 1 ulp.
+        ex = blk.experts[f"expert_{i}"]
+        return lambda xx: torch.matmul(torch.relu(torch.matmul(xx, ex.fc1.weight.t()) + ex.fc1.bias),
+                                       ex.fc2.weight.t()) + ex.fc2.bias
+
+    blk.expert_executor = make_executor(mods, FakeDispatcher(nllb_expert))
     x = acts(b * s, h, dtype, 2024 + seed).reshape(b, s, h)
     orig_router_fwd = blk.router.forward
-    blk.router.forward = lambda hs, pm=None: orig_router_fwd(hs, pm)[:2]  # 4.37 returned (top_1_mask, probs)
+    # 4.37 semantics: the router flattened [B,S,H] -> [B*S,H] itself and returned (top_1_mask, probs)
+    blk.router.forward = lambda hs, pm=None: orig_router_fwd(hs.reshape(-1, hs.shape[-1]), pm)[:2]
     with _NoCuda(), torch.no_grad():
         out, (router_probs, top1) = blk.forward(x)
     np.savez_compressed(os.path.join(OUT, name), x=npf(x), out=npf(out), router_probs=npf(router_probs), top1=npf(top1),
