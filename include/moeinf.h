@@ -1,0 +1,261 @@
+/* moeinf.h — C ABI of libmoeinf_hip.so, the MI355X-native expert-offload engine.
+ *
+ * This is the drop-in boundary for MoE-Infinity's native core.  In the reference the boundary is
+ * the pybind11 module `prefetch_op` (core/python/py_archer_prefetch.cpp:10-93) exposing two
+ * classes, `prefetch_handle` (ArcherPrefetchHandle) and `expert_dispatcher` (ExpertDispatcher).
+ * Every entry point below names the reference interface it replaces.  No torch types cross
+ * this boundary: plain pointers, sizes and a HIP stream handle (as void*).
+ *
+ * Conventions
+ *   - every function returns an int status (MOEINF_OK == 0); on failure
+ *     moeinf_last_error() returns a thread-local message.  Nothing aborts the process
+ *     (the reference DLOG_FATAL -> abort(), core/base/logging.cc:168-176).
+ *   - one engine per (process, GPU).  Calls on one engine must come from one thread at a time.
+ *   - "dev" pointers are HIP device pointers on cfg.device_id; "host" pointers are ordinary
+ *     host memory unless stated pinned.
+ *   - row-major tensors; nn.Linear layout [out, in] for every weight matrix.
+ */
+#ifndef MOEINF_H_
+#define MOEINF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOEINF_ABI_VERSION 1
+
+/* status codes */
+enum {
+  MOEINF_OK = 0,
+  MOEINF_ERR_INVALID = 1,     /* bad argument / unsupported shape */
+  MOEINF_ERR_HIP = 2,         /* a HIP runtime call failed (message has hipGetErrorString) */
+  MOEINF_ERR_OOM = 3,         /* host arena or device slab exhausted */
+  MOEINF_ERR_STATE = 4,       /* call order violated (e.g. forward before experts registered) */
+  MOEINF_ERR_UNSUPPORTED = 5  /* feature of the reference not (yet) built */
+};
+
+/* dtype ids: core/parallel/expert_module.h:20-23 (DTYPE_BFLOAT16 0, DTYPE_FLOAT32 1, DTYPE_FLOAT16 2) */
+enum { MOEINF_DTYPE_BF16 = 0, MOEINF_DTYPE_F32 = 1, MOEINF_DTYPE_F16 = 2 };
+
+/* expert_type ids: core/parallel/expert_module.h:13-18, moe_infinity/common/constants.py:29-37 */
+enum {
+  MOEINF_EXPERT_SWITCH = 0,       /* relu(x wi^T) wo^T                      expert_module.cpp:24-36   */
+  MOEINF_EXPERT_SWITCH_GATED = 1, /* gelu-gated, not in BASELINE configs -> MOEINF_ERR_UNSUPPORTED   */
+  MOEINF_EXPERT_NLLB = 2,         /* relu(x fc1^T + b1) fc2^T + b2          expert_module.cpp:79-93   */
+  MOEINF_EXPERT_FSGPT = 3,        /* same math as NLLB                      expert_module.cpp:113-129 */
+  MOEINF_EXPERT_MIXTRAL = 4,      /* (silu(x w1^T) * (x w3^T)) w2^T         expert_module.cpp:147-175 */
+  MOEINF_EXPERT_DEEPSEEK = 5      /* (silu(x g^T) * (x u^T)) d^T            expert_module.cpp:193-204 */
+};
+
+/* router kinds (the Python blocks of the reference) */
+enum {
+  MOEINF_ROUTER_MIXTRAL = 0,  /* moe_infinity/models/mixtral.py:46-54 */
+  MOEINF_ROUTER_DEEPSEEK = 1, /* models/modeling_deepseek/modeling_deepseek.py:463-512 (MoEGate) */
+  MOEINF_ROUTER_SWITCH = 2,   /* HF SwitchTransformersTop1Router @ models/switch_transformers.py:76 */
+  MOEINF_ROUTER_NLLB = 3      /* HF NllbMoeTop2Router @ models/nllb_moe.py:53 */
+};
+
+/* cache replacement policy. LFU-in-cache is what the reference actually runs
+ * (core/parallel/expert_dispatcher.cpp:227-258, core/prefetch/task_scheduler.cpp:276-310). */
+enum { MOEINF_POLICY_LFU_INCACHE = 0, MOEINF_POLICY_LRU = 1 };
+
+typedef struct moeinf_engine moeinf_engine;
+
+typedef struct moeinf_config {
+  int32_t abi_version; /* MOEINF_ABI_VERSION */
+  int32_t device_id;   /* HIP device ordinal of this process's GPU */
+  /* model: expert_dispatcher(num_experts, num_layers, dtype, expert_type, num_threads)
+   * (core/python/py_archer_prefetch.cpp:84-85); num_threads has no equivalent here. */
+  int32_t num_layers;  /* MoE layers (parse_moe_param, moe_infinity/utils/hf_config.py:22-55) */
+  int32_t num_experts; /* routed experts per layer */
+  int32_t expert_type; /* MOEINF_EXPERT_* */
+  int32_t dtype;       /* MOEINF_DTYPE_* of expert weights AND activations */
+  int32_t hidden;      /* H */
+  int32_t inter;       /* F (routed expert intermediate size) */
+  int32_t shared_inter;/* DeepSeek shared expert F (n_shared_experts * moe_intermediate_size), 0 = none
+                          (moe_infinity/models/deepseek.py:39-46,133-136) */
+  int32_t top_k;       /* K */
+  /* router */
+  int32_t router_kind;    /* MOEINF_ROUTER_* */
+  int32_t gate_dtype;     /* dtype of the gate/classifier weight handed to moe_forward */
+  int32_t norm_topk_prob; /* DeepSeek norm_topk_prob; NLLB normalize_router_prob_before_dropping */
+  float routed_scaling_factor; /* DeepSeek */
+  int32_t n_group;        /* DeepSeek group_limited_greedy: >1 enables it */
+  int32_t topk_group;
+  int32_t expert_capacity;/* Switch expert_capacity (tokens per expert per batch row) */
+  /* memory tiers: prefetch_handle(prefix, device_memory_ratio) (py_archer_prefetch.cpp:12) */
+  double device_memory_ratio;  /* fraction of TOTAL device memory (core/memory/memory_pool.cpp:150-158) */
+  int64_t device_memory_bytes; /* >0: explicit expert-cache byte budget overriding the ratio */
+  int64_t host_memory_bytes;   /* >0: cap of the pinned host arena; 0 = sized on demand */
+  int32_t policy;              /* MOEINF_POLICY_* */
+  /* expert parallelism: this engine owns experts with (e % ep_size) == ep_rank
+   * (core/model/model_topology.cpp:533-536, distributed/expert_executor.py:49-54) */
+  int32_t ep_rank;
+  int32_t ep_size;
+  int32_t max_tokens; /* largest T (tokens per forward call) the workspace is sized for */
+} moeinf_config;
+
+typedef struct moeinf_stats {
+  int64_t forwards;        /* moe_forward calls */
+  int64_t expert_hits;     /* dispatches that found the expert resident */
+  int64_t expert_misses;   /* dispatches that had to fetch on demand */
+  int64_t prefetch_issued; /* H2D copies started by moeinf_prefetch */
+  int64_t prefetch_useful; /* prefetched experts that were later dispatched before eviction */
+  int64_t evictions;
+  int64_t h2d_bytes;       /* bytes copied host->device (demand + prefetch) */
+  int64_t slots_total;     /* device cache capacity in experts */
+  int64_t slots_used;
+  int64_t slot_bytes;      /* bytes per slot (= expert blob size rounded to 4 KiB) */
+  int64_t host_arena_bytes;
+  double h2d_busy_ms;      /* copy-stream busy time measured with HIP events (demand + prefetch) */
+  double exposed_wait_ms;  /* time the compute stream spent waiting on copies (event-timed) */
+} moeinf_stats;
+
+/* ---- errors ------------------------------------------------------------------------------ */
+const char* moeinf_last_error(void);
+int moeinf_abi_version(void);
+
+/* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------
+ * (core/prefetch/archer_prefetch_handle.cpp:18-64,73-81) */
+int moeinf_create(const moeinf_config* cfg, moeinf_engine** out);
+int moeinf_destroy(moeinf_engine* eng);
+
+/* ---- expert blobs --------------------------------------------------------------------------
+ * The reference keeps one contiguous, 4 KiB-aligned blob per expert with the tensors in
+ * `tensor_ids` order (core/model/model_topology.cpp:429-431,677-700):
+ *   mixtral  w1[F,H] w2[H,F] w3[F,H]          deepseek gate[F,H] up[F,H] down[H,F]
+ *   nllb     fc1.w[F,H] fc1.b[F] fc2.w[H,F] fc2.b[H]      switch wi[F,H] wo[H,F]
+ * moeinf_expert_layout reports that layout (byte offsets/sizes per tensor, total bytes).
+ * which = 0 routed expert, 1 shared expert (DeepSeek). */
+int moeinf_expert_layout(const moeinf_engine* eng, int which, int64_t offsets[4], int64_t sizes[4],
+                         int32_t* n_tensors, int64_t* total_bytes);
+
+/* expert_dispatcher.register_expert(layer, expert, tensor_ids) + prefetch_handle.offload/register
+ * (core/parallel/expert_dispatcher.cpp:160-173, core/prefetch/archer_prefetch_handle.cpp:229-237):
+ * hands the engine the host copy of one expert.  blob != NULL: `nbytes` bytes are copied into the
+ * engine's pinned arena.  blob == NULL: an uninitialised arena block is reserved and the caller
+ * fills it through moeinf_expert_host_ptr (zero-copy registration). */
+int moeinf_register_expert(moeinf_engine* eng, int layer, int expert, const void* blob, int64_t nbytes);
+int moeinf_expert_host_ptr(moeinf_engine* eng, int layer, int expert, void** host_ptr);
+/* DeepSeek shared expert: always device-resident ("shared" params are exempt from offloading,
+ * moe_infinity/runtime/model_offload.py:758-759,824-826).  Host blob is copied to the device once. */
+int moeinf_register_shared(moeinf_engine* eng, int layer, const void* blob, int64_t nbytes);
+
+/* ---- the hot path --------------------------------------------------------------------------
+ * moeinf_moe_forward replaces, for one MoE layer and one step:
+ *   Sync*MoeBlock.forward router+mask   (moe_infinity/models/{mixtral,deepseek,switch_transformers,nllb_moe}.py)
+ *   DistributedExpertExecutor.dispatch_local (moe_infinity/distributed/expert_executor.py:32-58)
+ *   ExpertDispatcher set_inputs/enqueue_expert/wait_expert (core/parallel/expert_dispatcher.cpp:111-450)
+ *   Node::SetDevice on-demand fetch + LFU eviction (core/model/model_topology.cpp:53-136,
+ *                                                   expert_dispatcher.cpp:227-266)
+ *   the combine loop of the block (e.g. mixtral.py:96-101).
+ * x_dev:  [tokens, H] activations (cfg.dtype).  batch_rows: B (tokens = B*S; only Switch's
+ * per-row capacity uses it; pass 1 otherwise).  gate_w_dev: [E, H] (cfg.gate_dtype).
+ * out_dev: [tokens, H] (cfg.dtype).  stream: hipStream_t the caller's work is ordered on.
+ * The call enqueues work and returns; it blocks the host only to read the routing counts
+ * when a residency decision is needed. */
+#define MOEINF_FWD_DEFAULT 0u
+#define MOEINF_FWD_ROUTE_ONLY 1u  /* stop after router + dispatch-index (parity tests) */
+#define MOEINF_FWD_NO_COMBINE 2u  /* stop after the expert FFN (parity tests) */
+int moeinf_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tokens, int batch_rows,
+                       const void* gate_w_dev, void* out_dev, void* stream, uint32_t flags);
+
+/* Decomposed results of the LAST forward, copied to host (synchronises `stream`).
+ * Any output pointer may be NULL.  Replaces the values the reference's blocks hold in Python
+ * locals: selected_experts/routing_weights (mixtral.py:48-54), topk_idx/topk_weight
+ * (deepseek.py:55-60), and dispatch_local's expert_count (expert_executor.py:34-43).
+ *   topk_idx  [tokens*K] int32 expert ids, descending weight (Switch: -1 = dropped token)
+ *   topk_w    [tokens*K] float  (values already rounded to the dtype the reference holds them in)
+ *   counts    [E] int32 tokens per expert;  offsets [E+1] exclusive scan
+ *   slot_token[tokens*K] int32 token id of every expert-sorted row (first offsets[E] valid)
+ *   pair_slot [tokens*K] int32 expert-sorted row of every (token,k) pair, -1 if not dispatched */
+int moeinf_get_routing(moeinf_engine* eng, int32_t* topk_idx, float* topk_w, int32_t* counts,
+                       int32_t* offsets, int32_t* slot_token, int32_t* pair_slot);
+/* Per-expert FFN outputs of the last forward, expert-sorted rows [offsets[E], H] in cfg.dtype:
+ * what wait_expert() returns as a list of tensors (core/parallel/expert_dispatcher.cpp:436-450). */
+int moeinf_get_expert_outputs(moeinf_engine* eng, void* host_out, int64_t nbytes);
+/* router logits [tokens, E] fp32 of the last forward (Mixtral: bf16-rounded values) */
+int moeinf_get_logits(moeinf_engine* eng, float* host_out, int64_t n_floats);
+
+/* ---- prefetch / cache control --------------------------------------------------------------
+ * prefetch_handle.enqueue_prefetch(tensor_id, gpu) (archer_prefetch_handle.cpp:206-218) for n
+ * experts of one layer, in priority order (highest score first).  Copies run on the engine's
+ * prefetch stream and never block the caller. */
+int moeinf_prefetch(moeinf_engine* eng, int layer, const int32_t* experts, const float* scores, int n);
+/* prefetch_handle.replace_cache_candidates(ids) (archer_prefetch_handle.cpp:195-204,
+ * core/prefetch/task_scheduler.h:66-79): the new protected set replaces the old one;
+ * protected experts are skipped by eviction. */
+int moeinf_protect(moeinf_engine* eng, const int32_t* layers, const int32_t* experts, int n);
+/* expert_dispatcher.clear_expert_cache_counts() (expert_dispatcher.cpp:175-184) */
+int moeinf_clear_cache_counts(moeinf_engine* eng);
+/* 1 if resident on device, 0 otherwise: prefetch_handle.is_tensor_on_device (py_archer_prefetch.cpp:64-69) */
+int moeinf_is_resident(moeinf_engine* eng, int layer, int expert, int32_t* resident);
+/* blocks until every issued H2D copy has landed (tests/bench warm-up) */
+int moeinf_sync_copies(moeinf_engine* eng);
+
+/* prefetch_handle.get_hit_rate() (archer_prefetch_handle.cpp:281-297): per-expert counters,
+ * out[L*E][6] = {visit_cnt, hit_cnt, miss_cnt, prefetch_cnt, incache_visit_count, resident} */
+int moeinf_get_expert_counters(moeinf_engine* eng, int64_t* out, int64_t n_int64);
+int moeinf_get_stats(moeinf_engine* eng, moeinf_stats* out);
+int moeinf_reset_stats(moeinf_engine* eng);
+
+/* ---- activation-aware tracer / predictor ---------------------------------------------------
+ * Host-side restatement of moe_infinity/memory/expert_tracer.py, expert_predictor.py,
+ * expert_prefetcher.py (EAM = expert activation matrix [L,E]). */
+typedef struct moeinf_tracer moeinf_tracer;
+int moeinf_tracer_create(int num_layers, int num_experts, int capacity, moeinf_tracer** out);
+int moeinf_tracer_destroy(moeinf_tracer* tr);
+/* load historical EAMs: n x [L,E] float (expert_tracer.py:40-52 load_trace) */
+int moeinf_tracer_load(moeinf_tracer* tr, const float* eams, int n);
+/* ExpertTracer.create_entry (expert_tracer.py:54-59): returns a sequence handle */
+int moeinf_tracer_create_entry(moeinf_tracer* tr, int64_t* seq_id);
+/* ExpertTracer.finish_entry (expert_tracer.py:61-76): fold the sequence's EAM into the collection */
+int moeinf_tracer_finish_entry(moeinf_tracer* tr, int64_t seq_id);
+/* ExpertPredictor.predict (expert_predictor.py:17-35) = update_entry + find_most_similar + decay.
+ * experts: the n expert ids activated at `layer` in this step.  matrix_out: [L,E] float scores.
+ * nearest_out (optional): index of the most similar historical EAM. */
+int moeinf_tracer_predict(moeinf_tracer* tr, int64_t seq_id, int layer, const int32_t* experts, int n,
+                          float* matrix_out, int32_t* nearest_out);
+/* ExpertPrefetcher.prefetch_experts ordering (expert_prefetcher.py:42-59): from a predicted
+ * matrix, the (layer, expert) list for layers >= `layer` with score > 0, descending score,
+ * ties in (layer, expert) order.  Returns count in *n_out (<= L*E). */
+int moeinf_tracer_prefetch_order(const moeinf_tracer* tr, int layer, const float* matrix, int32_t* layers_out,
+                                 int32_t* experts_out, float* scores_out, int32_t* n_out);
+int moeinf_tracer_get_eam(moeinf_tracer* tr, int64_t seq_id, double* eam_out);
+
+/* ---- cache-policy simulator (host only, no GPU) --------------------------------------------
+ * The engine's replacement policy as a standalone object, so the policy can be checked against
+ * the oracle without a device (tests -m "not gpu"). ids are arbitrary non-negative ints. */
+typedef struct moeinf_cache_sim moeinf_cache_sim;
+int moeinf_cache_sim_create(int num_slots, int policy, moeinf_cache_sim** out);
+int moeinf_cache_sim_destroy(moeinf_cache_sim* sim);
+/* access one id: *hit = 1/0, *evicted = evicted id or -1 */
+int moeinf_cache_sim_access(moeinf_cache_sim* sim, int64_t id, int32_t* hit, int64_t* evicted);
+int moeinf_cache_sim_protect(moeinf_cache_sim* sim, const int64_t* ids, int n);
+int moeinf_cache_sim_clear_counts(moeinf_cache_sim* sim);
+
+/* ---- expert-parallel exchange helpers (multi-GPU) ---------------------
+ * Pack routed rows for an all-to-all and unpack the replies.  The collective itself (RCCL
+ * all_to_all over xGMI) is issued by the host layer (torch.distributed) between these calls. */
+/* After a MOEINF_FWD_ROUTE_ONLY forward: write, for each destination rank r, the rows of x whose
+ * expert lives on r ((e % ep_size) == r) into send_dev[r*cap_rows ...] (cfg.dtype, [ep_size*cap_rows, H]),
+ * and per-row metadata meta_dev[ep_size*cap_rows] (int32: expert id, -1 = padding).
+ * send_counts_dev[ep_size] int32 receives the row counts. */
+int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* meta_dev,
+                   int32_t* send_counts_dev, int cap_rows, void* stream);
+/* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, H] with
+ * meta_dev (expert ids, -1 padding); writes y_dev in the same row order. */
+int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, const int32_t* meta_dev,
+                         void* y_dev, int cap_rows, void* stream);
+/* Combine replies: ret_dev [ep_size*cap_rows, H] holds, in the order moeinf_ep_pack produced,
+ * the expert outputs for this rank's routed rows; writes out_dev [tokens, H]. */
+int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOEINF_H_ */

@@ -1,0 +1,117 @@
+"""ctypes binding of libmoeinf_hip.so (include/moeinf.h).  Loading never falls back to
+anything else: a missing library is an ImportError-class failure at first use."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MoeInfError(RuntimeError):
+    """Raised for every non-zero status of the C ABI; message = moeinf_last_error()."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"moeinf error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "libmoeinf_hip.so")
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device_id", C.c_int32), ("num_layers", C.c_int32), ("num_experts", C.c_int32),
+        ("expert_type", C.c_int32), ("dtype", C.c_int32), ("hidden", C.c_int32), ("inter", C.c_int32),
+        ("shared_inter", C.c_int32), ("top_k", C.c_int32), ("router_kind", C.c_int32), ("gate_dtype", C.c_int32),
+        ("norm_topk_prob", C.c_int32), ("routed_scaling_factor", C.c_float), ("n_group", C.c_int32),
+        ("topk_group", C.c_int32), ("expert_capacity", C.c_int32), ("device_memory_ratio", C.c_double),
+        ("device_memory_bytes", C.c_int64), ("host_memory_bytes", C.c_int64), ("policy", C.c_int32),
+        ("ep_rank", C.c_int32), ("ep_size", C.c_int32), ("max_tokens", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("forwards", C.c_int64), ("expert_hits", C.c_int64), ("expert_misses", C.c_int64),
+        ("prefetch_issued", C.c_int64), ("prefetch_useful", C.c_int64), ("evictions", C.c_int64),
+        ("h2d_bytes", C.c_int64), ("slots_total", C.c_int64), ("slots_used", C.c_int64), ("slot_bytes", C.c_int64),
+        ("host_arena_bytes", C.c_int64), ("h2d_busy_ms", C.c_double), ("exposed_wait_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+_I64P = C.POINTER(C.c_int64)
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/moeinf.h declares
+PROTOTYPES = {
+    "moeinf_last_error": (C.c_char_p, []),
+    "moeinf_abi_version": (C.c_int, []),
+    "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "moeinf_destroy": (C.c_int, [_P]),
+    "moeinf_expert_layout": (C.c_int, [_P, C.c_int, _I64P, _I64P, _I32P, _I64P]),
+    "moeinf_register_expert": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
+    "moeinf_expert_host_ptr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "moeinf_register_shared": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "moeinf_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_uint32]),
+    "moeinf_get_routing": (C.c_int, [_P, _I32P, _F32P, _I32P, _I32P, _I32P, _I32P]),
+    "moeinf_get_expert_outputs": (C.c_int, [_P, _P, C.c_int64]),
+    "moeinf_get_logits": (C.c_int, [_P, _F32P, C.c_int64]),
+    "moeinf_prefetch": (C.c_int, [_P, C.c_int, _I32P, _F32P, C.c_int]),
+    "moeinf_protect": (C.c_int, [_P, _I32P, _I32P, C.c_int]),
+    "moeinf_clear_cache_counts": (C.c_int, [_P]),
+    "moeinf_is_resident": (C.c_int, [_P, C.c_int, C.c_int, _I32P]),
+    "moeinf_sync_copies": (C.c_int, [_P]),
+    "moeinf_get_expert_counters": (C.c_int, [_P, _I64P, C.c_int64]),
+    "moeinf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "moeinf_reset_stats": (C.c_int, [_P]),
+    "moeinf_tracer_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "moeinf_tracer_destroy": (C.c_int, [_P]),
+    "moeinf_tracer_load": (C.c_int, [_P, _F32P, C.c_int]),
+    "moeinf_tracer_create_entry": (C.c_int, [_P, _I64P]),
+    "moeinf_tracer_finish_entry": (C.c_int, [_P, C.c_int64]),
+    "moeinf_tracer_predict": (C.c_int, [_P, C.c_int64, C.c_int, _I32P, C.c_int, _F32P, _I32P]),
+    "moeinf_tracer_prefetch_order": (C.c_int, [_P, C.c_int, _F32P, _I32P, _I32P, _F32P, _I32P]),
+    "moeinf_tracer_get_eam": (C.c_int, [_P, C.c_int64, _F64P]),
+    "moeinf_cache_sim_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "moeinf_cache_sim_destroy": (C.c_int, [_P]),
+    "moeinf_cache_sim_access": (C.c_int, [_P, C.c_int64, _I32P, _I64P]),
+    "moeinf_cache_sim_protect": (C.c_int, [_P, _I64P, C.c_int]),
+    "moeinf_cache_sim_clear_counts": (C.c_int, [_P]),
+    "moeinf_ep_pack": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "moeinf_ep_expert_ffn": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+}
+
+
+def load_library():
+    """dlopen libmoeinf_hip.so (built by ``python moe-infinity_amd/build.py`` /
+    ``__graft_entry__.build()``).  Raises if it is missing — there is no other backend."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python moe-infinity_amd/build.py` "
+                          "(hipcc --offload-arch=gfx950). moe-infinity_amd has no CPU/PyTorch fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.moeinf_abi_version() != 1:
+        raise ImportError("libmoeinf_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load_library().moeinf_last_error()
+        raise MoeInfError(rc, msg.decode() if msg else "")

@@ -1,0 +1,941 @@
+// engine.cpp — host side of libmoeinf_hip.so: memory tiers, residency, the per-layer hot path
+// orchestration, and the C ABI (include/moeinf.h).
+//
+// Replaces (reference, /root/reference): core/parallel/expert_dispatcher.cpp (ExpertDispatcher),
+// core/model/model_topology.cpp Node::SetDevice (tier mover), core/memory/* (pools, allocators,
+// streams), core/prefetch/task_scheduler.cpp (prefetch queue + eviction) — with a different
+// architecture: no worker threads, no per-expert stream syncs.  Every H2D copy is a
+// hipMemcpyAsync from the pinned arena into a fixed-size HBM slot on a dedicated copy stream and
+// is ordered against the compute stream with events (hipStreamWaitEvent), so the host never blocks
+// on a copy and a slot is never recycled while a kernel may still read it.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/moeinf.h"
+#include "cache_policy.h"
+#include "kernels.h"
+#include "tracer.h"
+
+using namespace moeinf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail(MOEINF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(call)              \
+  do {                         \
+    int r_ = (call);           \
+    if (r_ != MOEINF_OK) return r_; \
+  } while (0)
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static constexpr int64_t kAioAlignment = 4096;  // core/aio/archer_aio_utils.h kAioAlignment (model_topology.cpp:429-431)
+
+// ------------------------------------------------------------------------------------------------
+// blob layout
+// ------------------------------------------------------------------------------------------------
+struct BlobLayout {
+  int n = 0;
+  int64_t off[4] = {0, 0, 0, 0}, size[4] = {0, 0, 0, 0};
+  int64_t total = 0;
+};
+static BlobLayout make_layout(int expert_type, int64_t H, int64_t F, int64_t es) {
+  BlobLayout b;
+  auto add = [&](int64_t bytes) {
+    b.off[b.n] = b.total;
+    b.size[b.n] = bytes;
+    b.total += align_up(bytes, kAioAlignment);
+    ++b.n;
+  };
+  switch (expert_type) {
+    case MOEINF_EXPERT_MIXTRAL:   // w1[F,H] w2[H,F] w3[F,H]
+    case MOEINF_EXPERT_DEEPSEEK:  // gate[F,H] up[F,H] down[H,F]
+      add(F * H * es); add(F * H * es); add(F * H * es);
+      break;
+    case MOEINF_EXPERT_NLLB:
+    case MOEINF_EXPERT_FSGPT:  // fc1.w fc1.b fc2.w fc2.b
+      add(F * H * es); add(F * es); add(H * F * es); add(H * es);
+      break;
+    case MOEINF_EXPERT_SWITCH:  // wi wo
+      add(F * H * es); add(H * F * es);
+      break;
+    default: break;
+  }
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct Node {
+  void* host = nullptr;
+  int slot = -1;
+  hipEvent_t ready = nullptr;  // recorded after the H2D copy of this expert
+  bool ready_waited = true;    // compute stream already ordered after `ready`
+  bool prefetched = false;     // resident because of a prefetch, not yet dispatched
+  int64_t visit = 0, hit = 0, miss = 0, prefetch_cnt = 0;
+};
+struct Slot {
+  void* dev = nullptr;
+  int node = -1;
+  uint64_t last_use_seq = 0;  // sequence number of the last forward whose kernels read this slot
+};
+
+static constexpr int kFenceRing = 64;
+
+struct moeinf_engine {
+  moeinf_config cfg;
+  int64_t es = 2;  // element size
+  int dt = DT_BF16;
+  BlobLayout lay, lay_sh;
+  int64_t slot_bytes = 0;
+  int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
+  bool has_shared = false;
+
+  // host tier: pinned arena in chunks
+  std::vector<void*> arena_chunks;
+  int64_t arena_chunk_bytes = 0, arena_used_in_chunk = 0, arena_total = 0;
+
+  // device tier
+  std::vector<Slot> slots;
+  std::vector<int> free_slots;
+  int64_t max_slots = 0;
+  bool slab_exhausted = false;
+  std::vector<Node> nodes;           // [e*L + l]  (expert-major: the reference's eviction scan order)
+  std::vector<PolicyEntry> pol;      // same indexing
+  std::vector<void*> shared_dev;     // [L]
+  uint64_t clock = 0;
+  std::vector<int> resident_per_layer;  // #experts of layer l resident AND ordered (ready_waited)
+
+  // streams / events
+  hipStream_t demand_stream = nullptr, prefetch_stream = nullptr;
+  hipEvent_t route_ev = nullptr;
+  hipEvent_t fence_ev[kFenceRing];
+  uint64_t seq = 0;  // forwards issued
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> copy_timers;  // (start, end) pairs not yet accumulated
+  std::vector<hipEvent_t> event_pool;
+
+  // device workspace
+  uint64_t* d_wptr = nullptr;  // [L][E+1]
+  float* d_logits = nullptr;
+  int32_t *d_topk_idx = nullptr, *d_pair_valid = nullptr, *d_pair_order = nullptr, *d_pair_slot = nullptr;
+  float *d_topk_w = nullptr, *d_router_prob = nullptr;
+  int32_t *d_counts = nullptr, *d_offsets = nullptr, *d_active = nullptr, *d_n_active = nullptr;
+  int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_mirror = nullptr, *d_miss = nullptr;
+  void *d_h = nullptr, *d_y = nullptr;
+  int64_t ldh = 0;
+  int32_t* h_mirror = nullptr;  // pinned: {n_active, counts[E+1], active[E+1]}
+  int32_t* h_miss = nullptr;
+  std::vector<PokeArgs> pending_pokes;
+
+  // EP workspace (lazily allocated)
+  int32_t *d_ep_key = nullptr, *d_ep_counts = nullptr, *d_ep_offsets = nullptr, *d_ep_active = nullptr,
+          *d_ep_nactive = nullptr, *d_ep_pair_slot = nullptr, *d_ep_slot_token = nullptr, *d_ep_slot_pair = nullptr,
+          *d_ep_pair_pos = nullptr;
+  int ep_cap_rows = 0;
+
+  // last forward
+  int last_T = 0, last_layer = -1;
+  hipStream_t last_stream = nullptr;
+  int last_rows = 0;
+
+  moeinf_stats st;
+};
+
+static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }
+static bool owns(const moeinf_engine* g, int expert) { return g->cfg.ep_size <= 1 || (expert % g->cfg.ep_size) == g->cfg.ep_rank; }
+
+// ---- host arena ----------------------------------------------------------------------------
+static int arena_alloc(moeinf_engine* g, int64_t bytes, void** out) {
+  bytes = align_up(bytes, kAioAlignment);
+  if (g->cfg.host_memory_bytes > 0 && g->arena_total + bytes > g->cfg.host_memory_bytes)
+    return fail(MOEINF_ERR_OOM, "pinned host arena cap (%lld bytes) exceeded", (long long)g->cfg.host_memory_bytes);
+  if (g->arena_chunks.empty() || g->arena_used_in_chunk + bytes > g->arena_chunk_bytes) {
+    // chunk = at least 64 experts' worth or 1 GiB, so pinning cost is amortised
+    int64_t want = std::max<int64_t>(bytes, std::min<int64_t>(std::max<int64_t>(bytes * 64, 1ll << 30), 8ll << 30));
+    want = align_up(want, bytes);  // whole blobs per chunk
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipHostMalloc(&p, (size_t)want, hipHostMallocDefault);
+      if (e != hipSuccess) return fail(MOEINF_ERR_OOM, "hipHostMalloc(%lld) failed: %s", (long long)want, hipGetErrorString(e));
+    }
+    g->arena_chunks.push_back(p);
+    g->arena_chunk_bytes = want;
+    g->arena_used_in_chunk = 0;
+  }
+  *out = (char*)g->arena_chunks.back() + g->arena_used_in_chunk;
+  g->arena_used_in_chunk += bytes;
+  g->arena_total += bytes;
+  g->st.host_arena_bytes = g->arena_total;
+  return MOEINF_OK;
+}
+
+static hipEvent_t get_event(moeinf_engine* g) {
+  if (!g->event_pool.empty()) {
+    hipEvent_t e = g->event_pool.back();
+    g->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+// ---- lifecycle -----------------------------------------------------------------------------
+extern "C" const char* moeinf_last_error(void) { return g_err.c_str(); }
+extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
+
+static int validate(const moeinf_config* c) {
+  if (!c) return fail(MOEINF_ERR_INVALID, "cfg is NULL");
+  if (c->abi_version != MOEINF_ABI_VERSION) return fail(MOEINF_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOEINF_ABI_VERSION);
+  if (c->num_layers <= 0 || c->num_experts <= 0 || c->num_experts > 256) return fail(MOEINF_ERR_INVALID, "num_layers/num_experts out of range (experts <= 256)");
+  if (c->dtype != MOEINF_DTYPE_BF16 && c->dtype != MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "dtype %d: only bf16 (0) and fp32 (1) are built", c->dtype);
+  if (c->gate_dtype != MOEINF_DTYPE_BF16 && c->gate_dtype != MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "gate_dtype %d", c->gate_dtype);
+  switch (c->expert_type) {
+    case MOEINF_EXPERT_SWITCH: case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: case MOEINF_EXPERT_MIXTRAL: case MOEINF_EXPERT_DEEPSEEK: break;
+    default: return fail(MOEINF_ERR_UNSUPPORTED, "expert_type %d is not built (switch-gated/gelu is outside BASELINE's configs)", c->expert_type);
+  }
+  const int ev = c->dtype == MOEINF_DTYPE_BF16 ? 8 : 4;
+  if (c->hidden <= 0 || c->inter <= 0 || c->hidden % ev || c->inter % ev) return fail(MOEINF_ERR_INVALID, "hidden/inter must be positive multiples of %d", ev);
+  if (c->shared_inter < 0 || c->shared_inter % ev) return fail(MOEINF_ERR_INVALID, "shared_inter must be a multiple of %d", ev);
+  if (c->top_k <= 0 || c->top_k > 8 || c->top_k > c->num_experts) return fail(MOEINF_ERR_INVALID, "top_k must be in 1..min(8,E)");
+  if (c->router_kind < 0 || c->router_kind > 3) return fail(MOEINF_ERR_INVALID, "router_kind");
+  if (c->router_kind == MOEINF_ROUTER_SWITCH && c->top_k != 1) return fail(MOEINF_ERR_INVALID, "switch router is top-1");
+  if (c->router_kind == MOEINF_ROUTER_NLLB && c->top_k != 2) return fail(MOEINF_ERR_INVALID, "nllb router is top-2");
+  if (c->router_kind == MOEINF_ROUTER_DEEPSEEK && c->n_group > 1) {
+    if (c->num_experts % c->n_group || c->n_group > 64 || c->topk_group <= 0 || c->topk_group > c->n_group)
+      return fail(MOEINF_ERR_INVALID, "group_limited_greedy: bad n_group/topk_group");
+  }
+  if (c->shared_inter > 0 && c->expert_type != MOEINF_EXPERT_DEEPSEEK) return fail(MOEINF_ERR_INVALID, "shared expert only with deepseek experts");
+  if (c->ep_size < 1 || c->ep_rank < 0 || c->ep_rank >= c->ep_size) return fail(MOEINF_ERR_INVALID, "ep_rank/ep_size");
+  if (c->max_tokens <= 0) return fail(MOEINF_ERR_INVALID, "max_tokens must be > 0");
+  if (c->policy != MOEINF_POLICY_LFU_INCACHE && c->policy != MOEINF_POLICY_LRU) return fail(MOEINF_ERR_INVALID, "policy");
+  if (c->device_memory_bytes <= 0 && !(c->device_memory_ratio > 0.0 && c->device_memory_ratio <= 1.0)) return fail(MOEINF_ERR_INVALID, "device_memory_ratio must be in (0,1] when no byte budget is given");
+  return MOEINF_OK;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_destroy(moeinf_engine* g) {
+  if (!g) return MOEINF_OK;
+  hipSetDevice(g->cfg.device_id);
+  hipDeviceSynchronize();
+  for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
+  for (auto p : g->shared_dev) if (p) hipFree(p);
+  for (auto p : g->arena_chunks) hipHostFree(p);
+  for (auto& n : g->nodes) if (n.ready) hipEventDestroy(n.ready);
+  for (auto e : g->event_pool) hipEventDestroy(e);
+  for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  void* bufs[] = {g->d_wptr, g->d_logits, g->d_topk_idx, g->d_pair_valid, g->d_pair_order, g->d_pair_slot, g->d_topk_w,
+                  g->d_router_prob, g->d_counts, g->d_offsets, g->d_active, g->d_n_active, g->d_slot_token, g->d_slot_pair,
+                  g->d_mirror, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
+  for (void* b : bufs) if (b) hipFree(b);
+  if (g->h_mirror) hipHostFree(g->h_mirror);
+  if (g->h_miss) hipHostFree(g->h_miss);
+  if (g->route_ev) hipEventDestroy(g->route_ev);
+  for (int i = 0; i < kFenceRing; ++i) if (g->fence_ev[i]) hipEventDestroy(g->fence_ev[i]);
+  if (g->demand_stream) hipStreamDestroy(g->demand_stream);
+  if (g->prefetch_stream) hipStreamDestroy(g->prefetch_stream);
+  delete g;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
+  if (!out) return fail(MOEINF_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  CHK(validate(cfg));
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(MOEINF_ERR_INVALID, "device_id %d but %d HIP devices visible", cfg->device_id, ndev);
+  HIPCHK(hipSetDevice(cfg->device_id));
+  moeinf_engine* g = new moeinf_engine();
+  g->cfg = *cfg;
+  memset(&g->st, 0, sizeof g->st);
+  for (int i = 0; i < kFenceRing; ++i) g->fence_ev[i] = nullptr;
+  g->L = cfg->num_layers; g->E = cfg->num_experts; g->K = cfg->top_k; g->H = cfg->hidden; g->F = cfg->inter; g->Fs = cfg->shared_inter;
+  g->has_shared = cfg->shared_inter > 0;
+  g->dt = cfg->dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
+  g->es = g->dt == DT_BF16 ? 2 : 4;
+  g->lay = make_layout(cfg->expert_type, g->H, g->F, g->es);
+  if (g->has_shared) g->lay_sh = make_layout(cfg->expert_type, g->H, g->Fs, g->es);
+  g->slot_bytes = g->lay.total;
+  g->nodes.resize((size_t)g->L * g->E);
+  g->pol.resize((size_t)g->L * g->E);
+  g->shared_dev.assign(g->L, nullptr);
+  g->resident_per_layer.assign(g->L, 0);
+
+  auto bail = [&](int rc) { std::string keep = g_err; moeinf_destroy(g); g_err = keep; return rc; };
+#define TRY(x) do { int r__ = (x); if (r__ != MOEINF_OK) return bail(r__); } while (0)
+#define TRYHIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { fail(MOEINF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); return bail(MOEINF_ERR_HIP); } } while (0)
+
+  // budget: fraction of TOTAL device memory (reference semantics) unless an explicit byte budget is given
+  size_t free_b = 0, total_b = 0;
+  TRYHIP(hipMemGetInfo(&free_b, &total_b));
+  const int64_t budget = cfg->device_memory_bytes > 0 ? cfg->device_memory_bytes : (int64_t)((double)total_b * cfg->device_memory_ratio);
+  int64_t owned = 0;
+  for (int e = 0; e < g->E; ++e) if (owns(g, e)) ++owned;
+  g->max_slots = std::min<int64_t>(budget / g->slot_bytes, owned * g->L);
+  if (g->max_slots < std::min<int64_t>(g->K, owned)) { fail(MOEINF_ERR_OOM, "device budget %lld bytes holds %lld experts of %lld bytes; need at least %d", (long long)budget, (long long)g->max_slots, (long long)g->slot_bytes, g->K); return bail(MOEINF_ERR_OOM); }
+  g->st.slots_total = g->max_slots;
+  g->st.slot_bytes = g->slot_bytes;
+
+  int lo = 0, hi = 0;
+  TRYHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  TRYHIP(hipStreamCreateWithPriority(&g->demand_stream, hipStreamNonBlocking, hi));  // on-demand misses outrank prefetch
+  TRYHIP(hipStreamCreateWithPriority(&g->prefetch_stream, hipStreamNonBlocking, lo));
+  TRYHIP(hipEventCreateWithFlags(&g->route_ev, hipEventDisableTiming));
+  for (int i = 0; i < kFenceRing; ++i) TRYHIP(hipEventCreateWithFlags(&g->fence_ev[i], hipEventDisableTiming));
+
+  const size_t T = (size_t)cfg->max_tokens, K = (size_t)g->K, E1 = (size_t)g->E + 1;
+  const size_t rows = T * K + (g->has_shared ? T : 0);
+  g->ldh = std::max(g->F, g->Fs);
+  TRY(dmalloc(&g->d_wptr, (size_t)g->L * E1));
+  TRYHIP(hipMemset(g->d_wptr, 0, (size_t)g->L * E1 * sizeof(uint64_t)));
+  TRY(dmalloc(&g->d_logits, T * g->E));
+  TRY(dmalloc(&g->d_topk_idx, T * K)); TRY(dmalloc(&g->d_pair_valid, T * K)); TRY(dmalloc(&g->d_pair_order, T * K));
+  TRY(dmalloc(&g->d_pair_slot, T * K)); TRY(dmalloc(&g->d_topk_w, T * K)); TRY(dmalloc(&g->d_router_prob, T));
+  TRY(dmalloc(&g->d_counts, E1)); TRY(dmalloc(&g->d_offsets, E1 + 1)); TRY(dmalloc(&g->d_active, E1)); TRY(dmalloc(&g->d_n_active, 1));
+  TRY(dmalloc(&g->d_slot_token, rows)); TRY(dmalloc(&g->d_slot_pair, rows));
+  TRY(dmalloc(&g->d_mirror, 1 + 2 * E1)); TRY(dmalloc(&g->d_miss, 1));
+  TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
+  TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
+  TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
+  TRYHIP(hipHostMalloc((void**)&g->h_mirror, (1 + 2 * E1) * sizeof(int32_t), hipHostMallocDefault));
+  TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
+  *out = g;
+  return MOEINF_OK;
+#undef TRY
+#undef TRYHIP
+}
+
+// ---- registration --------------------------------------------------------------------------
+extern "C" int moeinf_expert_layout(const moeinf_engine* g, int which, int64_t offsets[4], int64_t sizes[4], int32_t* n_tensors, int64_t* total_bytes) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  const BlobLayout& b = which ? g->lay_sh : g->lay;
+  if (which && !g->has_shared) return fail(MOEINF_ERR_INVALID, "engine has no shared expert");
+  for (int i = 0; i < 4; ++i) { if (offsets) offsets[i] = b.off[i]; if (sizes) sizes[i] = b.size[i]; }
+  if (n_tensors) *n_tensors = b.n;
+  if (total_bytes) *total_bytes = b.total;
+  return MOEINF_OK;
+}
+
+static int check_le(const moeinf_engine* g, int layer, int expert) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range [0,%d)", layer, g->L);
+  if (expert < 0 || expert >= g->E) return fail(MOEINF_ERR_INVALID, "expert %d out of range [0,%d)", expert, g->E);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_register_expert(moeinf_engine* g, int layer, int expert, const void* blob, int64_t nbytes) {
+  CHK(check_le(g, layer, expert));
+  if (!owns(g, expert)) return fail(MOEINF_ERR_INVALID, "expert %d is not owned by ep_rank %d of %d", expert, g->cfg.ep_rank, g->cfg.ep_size);
+  if (blob && nbytes != g->lay.total) return fail(MOEINF_ERR_INVALID, "expert blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay.total);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  Node& n = g->nodes[node_index(g, layer, expert)];
+  if (!n.host) CHK(arena_alloc(g, g->lay.total, &n.host));
+  if (blob) memcpy(n.host, blob, (size_t)nbytes);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_expert_host_ptr(moeinf_engine* g, int layer, int expert, void** host_ptr) {
+  CHK(check_le(g, layer, expert));
+  Node& n = g->nodes[node_index(g, layer, expert)];
+  if (!n.host) return fail(MOEINF_ERR_STATE, "expert (%d,%d) is not registered", layer, expert);
+  *host_ptr = n.host;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_register_shared(moeinf_engine* g, int layer, const void* blob, int64_t nbytes) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (!g->has_shared) return fail(MOEINF_ERR_INVALID, "engine was created without a shared expert");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  if (!blob || nbytes != g->lay_sh.total) return fail(MOEINF_ERR_INVALID, "shared blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay_sh.total);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  if (!g->shared_dev[layer]) HIPCHK(hipMalloc(&g->shared_dev[layer], (size_t)nbytes));
+  HIPCHK(hipMemcpy(g->shared_dev[layer], blob, (size_t)nbytes, hipMemcpyHostToDevice));
+  uint64_t p = (uint64_t)g->shared_dev[layer];
+  HIPCHK(hipMemcpy(g->d_wptr + (size_t)layer * (g->E + 1) + g->E, &p, sizeof p, hipMemcpyHostToDevice));
+  return MOEINF_OK;
+}
+
+// ---- device tier ---------------------------------------------------------------------------
+static void queue_poke(moeinf_engine* g, int layer, int expert, uint64_t val) {
+  if (g->pending_pokes.empty() || g->pending_pokes.back().n == 16) {
+    PokeArgs p;
+    p.table = g->d_wptr;
+    p.n = 0;
+    g->pending_pokes.push_back(p);
+  }
+  PokeArgs& p = g->pending_pokes.back();
+  p.idx[p.n] = layer * (g->E + 1) + expert;
+  p.val[p.n] = val;
+  ++p.n;
+}
+static int flush_pokes(moeinf_engine* g, hipStream_t st) {
+  for (auto& p : g->pending_pokes) HIPCHK(launch_poke(p, st));
+  g->pending_pokes.clear();
+  return MOEINF_OK;
+}
+
+static void drop_ready_count(moeinf_engine* g, int idx) {
+  Node& n = g->nodes[idx];
+  if (n.slot >= 0 && n.ready_waited) g->resident_per_layer[idx % g->L] -= 1;
+}
+
+// obtain a device slot for node `idx`; may evict.  Pinned entries (pol[].pinned) are never evicted.
+static int acquire_slot(moeinf_engine* g, int idx, int* slot_out) {
+  if (!g->free_slots.empty()) {
+    *slot_out = g->free_slots.back();
+    g->free_slots.pop_back();
+    return MOEINF_OK;
+  }
+  if ((int64_t)g->slots.size() < g->max_slots && !g->slab_exhausted) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)g->slot_bytes);
+    if (e == hipSuccess) {
+      Slot s;
+      s.dev = p;
+      g->slots.push_back(s);
+      *slot_out = (int)g->slots.size() - 1;
+      return MOEINF_OK;
+    }
+    (void)hipGetLastError();
+    g->slab_exhausted = true;  // physical memory ran out before the budget did: cache stops growing
+    g->st.slots_total = (int64_t)g->slots.size();
+  }
+  const int64_t v = pick_victim(g->pol.data(), (int64_t)g->pol.size(), g->cfg.policy);
+  if (v < 0) return fail(MOEINF_ERR_OOM, "no evictable expert: %zu slots all pinned by the current layer", g->slots.size());
+  Node& vn = g->nodes[v];
+  drop_ready_count(g, (int)v);
+  const int slot = vn.slot;
+  vn.slot = -1;
+  vn.prefetched = false;
+  g->pol[v].resident = false;
+  g->slots[slot].node = -1;
+  g->st.evictions += 1;
+  g->st.slots_used -= 1;
+  queue_poke(g, (int)(v % g->L), (int)(v / g->L), 0);
+  *slot_out = slot;
+  return MOEINF_OK;
+}
+
+// start the H2D copy of node idx into a slot on `cs`
+static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs) {
+  Node& n = g->nodes[idx];
+  if (!n.host) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) was dispatched but never registered", idx % g->L, idx / g->L);
+  int slot = -1;
+  CHK(acquire_slot(g, idx, &slot));
+  Slot& s = g->slots[slot];
+  // the slot's previous tenant may still be read by kernels of forward #last_use_seq
+  // (fence ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence)
+  if (s.last_use_seq > 0) {
+    const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
+    hipEvent_t fe = g->fence_ev[fs % kFenceRing];
+    if (hipEventQuery(fe) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipStreamWaitEvent(cs, fe, 0));
+    }
+  }
+  hipEvent_t start = get_event(g), stop = get_event(g);
+  if (!n.ready) HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
+  if (start && stop) HIPCHK(hipEventRecord(start, cs));
+  HIPCHK(hipMemcpyAsync(s.dev, n.host, (size_t)g->lay.total, hipMemcpyHostToDevice, cs));
+  if (start && stop) {
+    HIPCHK(hipEventRecord(stop, cs));
+    g->copy_timers.push_back({start, stop});
+  }
+  HIPCHK(hipEventRecord(n.ready, cs));
+  n.slot = slot;
+  n.ready_waited = false;
+  s.node = idx;
+  g->pol[idx].resident = true;
+  g->st.slots_used += 1;
+  g->st.h2d_bytes += g->lay.total;
+  queue_poke(g, idx % g->L, idx / g->L, (uint64_t)s.dev);
+  return MOEINF_OK;
+}
+
+static void settle_copy_timers(moeinf_engine* g, bool wait) {
+  size_t keep = 0;
+  for (size_t i = 0; i < g->copy_timers.size(); ++i) {
+    auto pr = g->copy_timers[i];
+    if (wait) hipEventSynchronize(pr.second);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      g->st.h2d_busy_ms += ms;
+      g->event_pool.push_back(pr.first);
+      g->event_pool.push_back(pr.second);
+    } else {
+      (void)hipGetLastError();
+      g->copy_timers[keep++] = pr;
+    }
+  }
+  g->copy_timers.resize(keep);
+}
+
+// ---- the hot path --------------------------------------------------------------------------
+static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s) {
+  const BlobLayout& b = g->lay;
+  const BlobLayout& bs = g->lay_sh;
+  memset(&s, 0, sizeof s);
+  s.wptr = g->d_wptr + (size_t)layer * (g->E + 1);
+  s.active = g->d_active; s.n_active = g->d_n_active; s.counts = g->d_counts; s.offsets = g->d_offsets;
+  s.miss_flag = g->d_miss;
+  s.E = g->E;
+  s.dtype = g->dt;
+  const int et = g->cfg.expert_type;
+  if (stage == 1) {
+    s.K = g->H; s.R = g->F; s.K_sh = g->H; s.R_sh = g->Fs;
+    s.ld_in = g->H; s.row_map = g->d_slot_token; s.out = g->d_h; s.ld_out = g->ldh;
+    if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[0]; s.off_b = b.off[2]; s.epi = EPI_GATED_SILU; }
+    else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[0]; s.off_b = b.off[1]; s.off_a_sh = bs.off[0]; s.off_b_sh = bs.off[1]; s.epi = EPI_GATED_SILU; }
+    else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[0]; s.epi = EPI_RELU; }
+    else { s.off_a = b.off[0]; s.off_bias = b.off[1]; s.epi = EPI_BIAS_RELU; }
+  } else {
+    s.K = g->F; s.R = g->H; s.K_sh = g->Fs; s.R_sh = g->H;
+    s.in = g->d_h; s.ld_in = g->ldh; s.row_map = nullptr; s.out = g->d_y; s.ld_out = g->H;
+    if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
+    else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[2]; s.off_a_sh = bs.off[2]; s.epi = EPI_NONE; }
+    else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
+    else { s.off_a = b.off[2]; s.off_bias = b.off[3]; s.epi = EPI_BIAS; }
+  }
+}
+
+// make every active routed expert of `layer` resident and order the compute stream after its copy.
+// h_mirror = {n_active, counts[E+1], active[E+1]} (already on the host).
+static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st) {
+  const int E1 = g->E + 1;
+  const int na = g->h_mirror[0];
+  const int32_t* counts = g->h_mirror + 1;
+  const int32_t* active = g->h_mirror + 1 + E1;
+  // pin this layer's active experts so a miss cannot evict a sibling that the same launch reads
+  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
+  int rc = MOEINF_OK;
+  for (int i = 0; i < na && rc == MOEINF_OK; ++i) {
+    const int e = active[i];
+    if (e >= g->E) continue;  // shared pseudo-expert
+    (void)counts;
+    const int idx = node_index(g, layer, e);
+    Node& n = g->nodes[idx];
+    n.visit += 1;
+    if (n.slot >= 0) {
+      n.hit += 1;
+      g->st.expert_hits += 1;
+      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; }
+    } else {
+      n.miss += 1;
+      g->st.expert_misses += 1;
+      rc = issue_copy(g, idx, g->demand_stream);
+      if (rc != MOEINF_OK) break;
+    }
+    if (!n.ready_waited) {
+      hipError_t he = hipStreamWaitEvent(st, n.ready, 0);
+      if (he != hipSuccess) { rc = fail(MOEINF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(he)); break; }
+      n.ready_waited = true;
+      g->resident_per_layer[layer] += 1;
+    }
+    g->pol[idx].incache += 1;  // incache_visit_count += 1 on every dispatch (expert_dispatcher.cpp:263)
+    g->pol[idx].last_access = ++g->clock;
+    g->slots[n.slot].last_use_seq = g->seq + 1;
+  }
+  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
+  return rc;
+}
+
+extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                                  void* out_dev, void* stream, uint32_t flags) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
+  if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
+  if (!x_dev || !gate_w_dev) return fail(MOEINF_ERR_INVALID, "x_dev/gate_w_dev is NULL");
+  if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
+  if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
+  const bool route_only = flags & MOEINF_FWD_ROUTE_ONLY;
+  if (!route_only && !(flags & MOEINF_FWD_NO_COMBINE) && !out_dev) return fail(MOEINF_ERR_INVALID, "out_dev is NULL");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const int T = tokens, K = g->K, E = g->E, E1 = E + 1;
+
+  RouteArgs ra;
+  memset(&ra, 0, sizeof ra);
+  ra.x = x_dev; ra.gate_w = gate_w_dev; ra.logits = g->d_logits;
+  ra.T = T; ra.H = g->H; ra.E = E; ra.K = K;
+  ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
+  ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
+  ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
+  ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
+  ra.router_prob = g->d_router_prob;
+  HIPCHK(launch_gate_logits(ra, st));
+  HIPCHK(launch_route_topk(ra, st));
+
+  IndexArgs ia;
+  memset(&ia, 0, sizeof ia);
+  ia.topk_idx = g->d_topk_idx; ia.pair_valid = g->d_pair_valid; ia.T = T; ia.K = K; ia.E = E;
+  ia.rows = batch_rows;
+  ia.capacity = g->cfg.router_kind == MOEINF_ROUTER_SWITCH ? g->cfg.expert_capacity : 0;
+  ia.shared = g->has_shared ? 1 : 0;
+  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  HIPCHK(launch_dispatch_index(ia, st));
+  g->last_T = T; g->last_layer = layer; g->last_stream = st;
+  g->st.forwards += 1;
+  if (route_only) return MOEINF_OK;
+
+  // Residency.  The host needs the active-expert list to decide fetches/evictions (the reference does
+  // the same D2H every layer, expert_executor.py:34-43); one small pinned copy + event.
+  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(g->route_ev, st));
+  HIPCHK(hipEventSynchronize(g->route_ev));
+  CHK(ensure_resident(g, layer, st));
+  CHK(flush_pokes(g, st));
+
+  const int na = g->h_mirror[0];
+  FfnStage s1, s2;
+  fill_stage(g, layer, 1, s1);
+  s1.in = x_dev;
+  fill_stage(g, layer, 2, s2);
+  if (na > 0) {
+    HIPCHK(launch_ffn_stage(s1, na, st));
+    HIPCHK(launch_ffn_stage(s2, na, st));
+  }
+  if (!(flags & MOEINF_FWD_NO_COMBINE)) {
+    CombineArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
+    ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
+    ca.router_prob = g->d_router_prob;
+    ca.shared_row0 = -1;
+    ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
+    if (g->has_shared) {
+      // first row of the shared expert = offsets[E] = number of routed rows
+      int routed = 0;
+      for (int e = 0; e < E; ++e) routed += g->h_mirror[1 + e];
+      ca.shared_row0 = routed;
+    }
+    HIPCHK(launch_combine(ca, st));
+  }
+  // fence: slots used by this forward may be recycled only after this point of the stream
+  g->seq += 1;
+  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  return MOEINF_OK;
+}
+
+// ---- getters -------------------------------------------------------------------------------
+static int sync_last(moeinf_engine* g) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "no forward has run yet");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  HIPCHK(hipStreamSynchronize(g->last_stream));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_routing(moeinf_engine* g, int32_t* topk_idx, float* topk_w, int32_t* counts, int32_t* offsets, int32_t* slot_token, int32_t* pair_slot) {
+  CHK(sync_last(g));
+  const size_t n = (size_t)g->last_T * g->K;
+  std::vector<int32_t> valid(n), idx(n);
+  HIPCHK(hipMemcpy(idx.data(), g->d_topk_idx, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(valid.data(), g->d_pair_valid, n * 4, hipMemcpyDeviceToHost));
+  if (topk_idx) {
+    for (size_t i = 0; i < n; ++i) topk_idx[i] = valid[i] ? idx[i] : -1;
+  }
+  if (topk_w) HIPCHK(hipMemcpy(topk_w, g->d_topk_w, n * 4, hipMemcpyDeviceToHost));
+  if (counts) HIPCHK(hipMemcpy(counts, g->d_counts, (size_t)g->E * 4, hipMemcpyDeviceToHost));
+  if (offsets) HIPCHK(hipMemcpy(offsets, g->d_offsets, (size_t)(g->E + 1) * 4, hipMemcpyDeviceToHost));
+  if (slot_token) HIPCHK(hipMemcpy(slot_token, g->d_slot_token, n * 4, hipMemcpyDeviceToHost));
+  if (pair_slot) HIPCHK(hipMemcpy(pair_slot, g->d_pair_slot, n * 4, hipMemcpyDeviceToHost));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_expert_outputs(moeinf_engine* g, void* host_out, int64_t nbytes) {
+  CHK(sync_last(g));
+  const int64_t rows = (int64_t)g->last_T * g->K + (g->has_shared ? g->last_T : 0);
+  const int64_t need = rows * g->H * g->es;
+  if (!host_out || nbytes > need || nbytes <= 0) return fail(MOEINF_ERR_INVALID, "nbytes must be in 1..%lld", (long long)need);
+  HIPCHK(hipMemcpy(host_out, g->d_y, (size_t)nbytes, hipMemcpyDeviceToHost));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_logits(moeinf_engine* g, float* host_out, int64_t n_floats) {
+  CHK(sync_last(g));
+  if (!host_out || n_floats != (int64_t)g->last_T * g->E) return fail(MOEINF_ERR_INVALID, "n_floats must be tokens*E");
+  HIPCHK(hipMemcpy(host_out, g->d_logits, (size_t)n_floats * 4, hipMemcpyDeviceToHost));
+  return MOEINF_OK;
+}
+
+// ---- prefetch / cache control ----------------------------------------------------------------
+extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* experts, const float* scores, int n) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  if (n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "experts is NULL");
+  (void)scores;  // the caller passes experts in priority order; scores are kept for tracing only
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  for (int i = 0; i < n; ++i) {
+    const int e = experts[i];
+    if (e < 0 || e >= g->E) return fail(MOEINF_ERR_INVALID, "expert id %d out of range", e);
+    if (!owns(g, e)) continue;
+    const int idx = node_index(g, layer, e);
+    Node& nd = g->nodes[idx];
+    if (nd.slot >= 0) continue;  // resident or already in flight: dedup (task_scheduler.cpp:82-118)
+    if (!nd.host) return fail(MOEINF_ERR_STATE, "expert (%d,%d) not registered", layer, e);
+    // never evict a protected expert or one hotter than nothing: if no slot can be freed, stop quietly
+    g->pol[idx].pinned = true;
+    int rc = issue_copy(g, idx, g->prefetch_stream);
+    g->pol[idx].pinned = false;
+    if (rc == MOEINF_ERR_OOM) break;
+    if (rc != MOEINF_OK) return rc;
+    nd.prefetched = true;
+    nd.prefetch_cnt += 1;
+    g->st.prefetch_issued += 1;
+  }
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_protect(moeinf_engine* g, const int32_t* layers, const int32_t* experts, int n) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (n < 0 || (n > 0 && (!layers || !experts))) return fail(MOEINF_ERR_INVALID, "NULL id arrays");
+  for (int i = 0; i < n; ++i) CHK(check_le(g, layers[i], experts[i]));
+  for (auto& p : g->pol) p.is_protected = false;
+  for (int i = 0; i < n; ++i) g->pol[node_index(g, layers[i], experts[i])].is_protected = true;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_clear_cache_counts(moeinf_engine* g) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  for (auto& p : g->pol) p.incache = 0;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_is_resident(moeinf_engine* g, int layer, int expert, int32_t* resident) {
+  CHK(check_le(g, layer, expert));
+  if (!resident) return fail(MOEINF_ERR_INVALID, "resident is NULL");
+  *resident = g->nodes[node_index(g, layer, expert)].slot >= 0 ? 1 : 0;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_sync_copies(moeinf_engine* g) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  HIPCHK(hipStreamSynchronize(g->demand_stream));
+  HIPCHK(hipStreamSynchronize(g->prefetch_stream));
+  settle_copy_timers(g, true);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_expert_counters(moeinf_engine* g, int64_t* out, int64_t n_int64) {
+  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (n_int64 != (int64_t)g->L * g->E * 6) return fail(MOEINF_ERR_INVALID, "n_int64 must be L*E*6");
+  for (int l = 0; l < g->L; ++l)
+    for (int e = 0; e < g->E; ++e) {
+      const int idx = node_index(g, l, e);
+      int64_t* o = out + ((int64_t)l * g->E + e) * 6;
+      o[0] = g->nodes[idx].visit; o[1] = g->nodes[idx].hit; o[2] = g->nodes[idx].miss; o[3] = g->nodes[idx].prefetch_cnt;
+      o[4] = g->pol[idx].incache; o[5] = g->nodes[idx].slot >= 0 ? 1 : 0;
+    }
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_stats(moeinf_engine* g, moeinf_stats* out) {
+  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  settle_copy_timers(g, false);
+  *out = g->st;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_reset_stats(moeinf_engine* g) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  settle_copy_timers(g, false);
+  const int64_t st = g->st.slots_total, su = g->st.slots_used, sb = g->st.slot_bytes, ha = g->st.host_arena_bytes;
+  memset(&g->st, 0, sizeof g->st);
+  g->st.slots_total = st; g->st.slots_used = su; g->st.slot_bytes = sb; g->st.host_arena_bytes = ha;
+  return MOEINF_OK;
+}
+
+// ---- cache simulator -----------------------------------------------------------------------
+struct moeinf_cache_sim { CacheSim* sim; };
+extern "C" int moeinf_cache_sim_create(int num_slots, int policy, moeinf_cache_sim** out) {
+  if (!out || num_slots <= 0 || (policy != POLICY_LFU_INCACHE && policy != POLICY_LRU)) return fail(MOEINF_ERR_INVALID, "bad cache_sim arguments");
+  *out = new moeinf_cache_sim{new CacheSim(num_slots, policy)};
+  return MOEINF_OK;
+}
+extern "C" int moeinf_cache_sim_destroy(moeinf_cache_sim* s) { if (s) { delete s->sim; delete s; } return MOEINF_OK; }
+extern "C" int moeinf_cache_sim_access(moeinf_cache_sim* s, int64_t id, int32_t* hit, int64_t* evicted) {
+  if (!s || id < 0) return fail(MOEINF_ERR_INVALID, "bad cache_sim_access arguments");
+  int64_t ev = -1;
+  const bool h = s->sim->access(id, &ev);
+  if (hit) *hit = h ? 1 : 0;
+  if (evicted) *evicted = ev;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_cache_sim_protect(moeinf_cache_sim* s, const int64_t* ids, int n) {
+  if (!s || n < 0 || (n > 0 && !ids)) return fail(MOEINF_ERR_INVALID, "bad cache_sim_protect arguments");
+  s->sim->protect(ids, n);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_cache_sim_clear_counts(moeinf_cache_sim* s) {
+  if (!s) return fail(MOEINF_ERR_INVALID, "sim is NULL");
+  s->sim->clear_counts();
+  return MOEINF_OK;
+}
+
+// ---- tracer --------------------------------------------------------------------------------
+struct moeinf_tracer { Tracer* t; };
+extern "C" int moeinf_tracer_create(int L, int E, int capacity, moeinf_tracer** out) {
+  if (!out || L <= 0 || E <= 0 || capacity <= 0) return fail(MOEINF_ERR_INVALID, "bad tracer arguments");
+  *out = new moeinf_tracer{new Tracer(L, E, capacity)};
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_destroy(moeinf_tracer* t) { if (t) { delete t->t; delete t; } return MOEINF_OK; }
+extern "C" int moeinf_tracer_load(moeinf_tracer* t, const float* eams, int n) {
+  if (!t || !eams || n < 0 || n > t->t->capacity()) return fail(MOEINF_ERR_INVALID, "tracer_load: n must be in 0..capacity");
+  t->t->load(eams, n);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_create_entry(moeinf_tracer* t, int64_t* seq_id) {
+  if (!t || !seq_id) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  *seq_id = t->t->create_entry();
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_finish_entry(moeinf_tracer* t, int64_t seq_id) {
+  if (!t || !t->t->has(seq_id)) return fail(MOEINF_ERR_INVALID, "unknown seq_id");
+  t->t->finish_entry(seq_id);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_predict(moeinf_tracer* t, int64_t seq_id, int layer, const int32_t* experts, int n, float* matrix_out, int32_t* nearest_out) {
+  if (!t || !t->t->has(seq_id) || !matrix_out || n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "bad tracer_predict arguments");
+  if (layer < 0 || layer >= t->t->layers()) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  for (int i = 0; i < n; ++i) if (experts[i] < 0 || experts[i] >= t->t->experts()) return fail(MOEINF_ERR_INVALID, "expert id out of range");
+  int nearest = t->t->predict(seq_id, layer, experts, n, matrix_out);
+  if (nearest_out) *nearest_out = nearest;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_prefetch_order(const moeinf_tracer* t, int layer, const float* matrix, int32_t* layers_out, int32_t* experts_out, float* scores_out, int32_t* n_out) {
+  if (!t || !matrix || !layers_out || !experts_out || !n_out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (layer < 0 || layer >= t->t->layers()) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  *n_out = t->t->prefetch_order(layer, matrix, layers_out, experts_out, scores_out);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* eam_out) {
+  if (!t || !t->t->has(seq_id) || !eam_out) return fail(MOEINF_ERR_INVALID, "bad tracer_get_eam arguments");
+  t->t->get_eam(seq_id, eam_out);
+  return MOEINF_OK;
+}
+
+// ---- expert-parallel helpers ---------------------------------------------------------------
+static int ep_alloc(moeinf_engine* g, int cap_rows) {
+  if (g->d_ep_key && g->ep_cap_rows >= cap_rows) return MOEINF_OK;
+  void* olds[] = {g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active, g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
+  for (void* p : olds) if (p) hipFree(p);
+  const size_t np = (size_t)g->cfg.max_tokens * g->K;
+  const size_t nr = std::max<size_t>(np, (size_t)g->cfg.ep_size * cap_rows);
+  const size_t nk = std::max<size_t>((size_t)g->cfg.ep_size, (size_t)g->E) + 2;
+  CHK(dmalloc(&g->d_ep_key, nr)); CHK(dmalloc(&g->d_ep_counts, nk)); CHK(dmalloc(&g->d_ep_offsets, nk + 1)); CHK(dmalloc(&g->d_ep_active, nk));
+  CHK(dmalloc(&g->d_ep_nactive, 1)); CHK(dmalloc(&g->d_ep_pair_slot, nr)); CHK(dmalloc(&g->d_ep_slot_token, nr + 1)); CHK(dmalloc(&g->d_ep_slot_pair, nr + 1));
+  CHK(dmalloc(&g->d_ep_pair_pos, np));
+  g->ep_cap_rows = cap_rows;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* meta_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
+  if (!g || !x_dev || !send_dev || !meta_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack needs a preceding ROUTE_ONLY forward");
+  if (cap_rows < g->last_T * g->K) return fail(MOEINF_ERR_INVALID, "cap_rows %d < tokens*K %d (worst case: every pair goes to one rank)", cap_rows, g->last_T * g->K);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  CHK(ep_alloc(g, cap_rows));
+  const int np = g->last_T * g->K, ep = g->cfg.ep_size;
+  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, np, ep, st));
+  IndexArgs ia;
+  memset(&ia, 0, sizeof ia);
+  ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
+  ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
+  ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
+  HIPCHK(launch_dispatch_index(ia, st));
+  HIPCHK(hipMemsetAsync(g->d_ep_pair_pos, 0xFF, (size_t)np * 4, st));
+  EpPackArgs pa;
+  memset(&pa, 0, sizeof pa);
+  pa.x = x_dev; pa.send = send_dev; pa.meta = meta_dev; pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
+  pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
+  pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
+  HIPCHK(launch_ep_pack(pa, st));
+  if (send_counts_dev) HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, const int32_t* meta_dev, void* y_dev, int cap_rows, void* stream) {
+  if (!g || !recv_dev || !meta_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const int ep = g->cfg.ep_size, nrows = ep * cap_rows, E = g->E, E1 = E + 1;
+  if ((int64_t)nrows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "ep rows %d exceed workspace (max_tokens*K = %d): create the engine with max_tokens >= ep_size*cap_rows/K", nrows, g->cfg.max_tokens * g->K);
+  IndexArgs ia;
+  memset(&ia, 0, sizeof ia);
+  ia.topk_idx = meta_dev; ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
+  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  HIPCHK(launch_dispatch_index(ia, st));
+  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(g->route_ev, st));
+  HIPCHK(hipEventSynchronize(g->route_ev));
+  for (int i = 0; i < g->h_mirror[0]; ++i) {
+    const int e = g->h_mirror[1 + E1 + i];
+    if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d received rows for expert %d it does not own", g->cfg.ep_rank, e);
+  }
+  CHK(ensure_resident(g, layer, st));
+  CHK(flush_pokes(g, st));
+  FfnStage s1, s2;
+  fill_stage(g, layer, 1, s1);
+  s1.in = recv_dev;
+  fill_stage(g, layer, 2, s2);
+  const int na = g->h_mirror[0];
+  if (na > 0) {
+    HIPCHK(launch_ffn_stage(s1, na, st));
+    HIPCHK(launch_ffn_stage(s2, na, st));
+  }
+  HIPCHK(launch_ep_unsort(g->d_y, y_dev, g->d_pair_slot, nrows, g->H, g->dt, st));
+  g->seq += 1;
+  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream) {
+  if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows");
+  if (g->has_shared) return fail(MOEINF_ERR_UNSUPPORTED, "EP combine with a shared expert: run the shared expert locally and add it (not built yet)");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  CombineArgs ca;
+  memset(&ca, 0, sizeof ca);
+  ca.x = x_dev; ca.y = ret_dev; ca.out = out_dev;
+  ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
+  ca.router_prob = g->d_router_prob; ca.shared_row0 = -1;
+  ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
+  HIPCHK(launch_combine(ca, (hipStream_t)stream));
+  return MOEINF_OK;
+}

@@ -1,0 +1,126 @@
+// kernels.h — launch wrappers of the gfx950 kernels (implemented in kernels.hip).
+// Host code (engine.cpp) sees only these plain-C++ declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace moeinf {
+
+enum { DT_BF16 = 0, DT_F32 = 1 };
+
+// epilogues of the row-dot (weight-streaming) FFN kernel
+enum {
+  EPI_NONE = 0,       // out = Tr(acc)                      (down / w2 / wo projections)
+  EPI_BIAS = 1,       // out = Tr(Tr(acc) + bias)           (NLLB fc2)
+  EPI_RELU = 2,       // out = relu(Tr(acc))                (Switch wi)
+  EPI_BIAS_RELU = 3,  // out = relu(Tr(Tr(acc) + bias))     (NLLB fc1)
+  EPI_GATED_SILU = 4  // out = Tr(Tr(silu(Tr(acc0))) * Tr(acc1))   (Mixtral w1/w3, DeepSeek gate/up)
+};
+
+// One stage (x -> h, or h -> y) of the grouped expert FFN for every active expert of a layer.
+struct FfnStage {
+  const void* in;          // B-operand rows: x [tokens, ld_in] (stage 1) or h [rows, ld_in] (stage 2)
+  int64_t ld_in;           // elements
+  const int32_t* row_map;  // stage 1: expert-sorted row -> token id (fused gather); nullptr: identity
+  void* out;               // [rows, ld_out]
+  int64_t ld_out;
+  const uint64_t* wptr;    // [E+1] device base pointer of every expert blob of this layer (0 = absent);
+                           // entry E is the shared expert (DeepSeek) or 0
+  const int32_t* active;   // [<= E+1] ids of experts with tokens, ascending
+  const int32_t* n_active; // device scalar
+  const int32_t* counts;   // [E+1] rows per expert
+  const int32_t* offsets;  // [E+2] first expert-sorted row of each expert
+  int32_t* miss_flag;      // set to 1 if an active expert has wptr == 0
+  int E;                   // number of routed experts (index of the shared pseudo-expert)
+  int K, R;                // routed experts: reduction length, output rows
+  int K_sh, R_sh;          // shared expert
+  int64_t off_a, off_b, off_bias;           // byte offsets inside a routed expert blob
+  int64_t off_a_sh, off_b_sh;               // inside the shared blob
+  int epi;
+  int dtype;
+};
+hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st);
+
+struct RouteArgs {
+  const void* x;        // [T,H] dtype x_dtype
+  const void* gate_w;   // [E,H] dtype gate_dtype
+  float* logits;        // [T,E]
+  int T, H, E, K;
+  int x_dtype, gate_dtype;
+  int kind;             // MOEINF_ROUTER_*
+  int norm_topk_prob;
+  float scale;
+  int n_group, topk_group;
+  int32_t* topk_idx;    // [T,K]
+  float* topk_w;        // [T,K]
+  int32_t* pair_valid;  // [T,K]
+  int32_t* pair_order;  // [T,K] k-indices sorted by ascending expert id
+  float* router_prob;   // [T] (Switch: max prob)
+};
+hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st);
+hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st);
+
+struct IndexArgs {
+  const int32_t* topk_idx;  // [T,K]; entries < 0 are never dispatched
+  int32_t* pair_valid;      // [T,K] in/out (Switch capacity clears entries); nullptr: all valid
+  int T, K, E;
+  int rows;                 // batch rows B (T = B*S); capacity applies per row
+  int capacity;             // <=0: unlimited
+  int shared;               // 1: append the shared pseudo-expert E with all T tokens
+  int32_t* counts;          // [E+1]
+  int32_t* offsets;         // [E+2]
+  int32_t* active;          // [E+1]
+  int32_t* n_active;        // scalar
+  int32_t* pair_slot;       // [T,K]
+  int32_t* slot_token;      // [T*K + T] expert-sorted row -> token id
+  int32_t* slot_pair;       // [T*K + T] expert-sorted row -> pair id t*K+k (shared rows: -1)
+  int32_t* mirror;          // device staging of {n_active, counts[E+1], active[E+1]} for one D2H copy
+};
+hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
+
+struct CombineArgs {
+  const void* x;            // [T,H] (Switch/NLLB passthrough)
+  const void* y;            // [rows,H] expert outputs, expert-sorted
+  void* out;                // [T,H]
+  const int32_t* topk_idx;  // [T,K]
+  const float* topk_w;      // [T,K]
+  const int32_t* pair_slot; // [T,K]
+  const int32_t* pair_order;// [T,K]
+  const float* router_prob; // [T] Switch
+  int shared_row0;          // first row of the shared expert's outputs in y, -1: none
+  int T, H, K;
+  int kind;                 // MOEINF_ROUTER_* (selects the reference block's combine semantics)
+  int dtype;
+};
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+
+// residency-table update: table[idx[i]] = val[i], i < n (n <= 16), stream-ordered
+struct PokeArgs {
+  uint64_t* table;
+  int n;
+  int32_t idx[16];
+  uint64_t val[16];
+};
+hipError_t launch_poke(const PokeArgs& a, hipStream_t st);
+
+// expert-parallel helpers
+// key[p] = valid pair ? topk_idx[p] % ep_size : -1   (destination rank of every (token,k) pair)
+hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n_pairs,
+                              int ep_size, hipStream_t st);
+struct EpPackArgs {
+  const void* x;              // [T,H]
+  void* send;                 // [ep_size*cap_rows, H]
+  int32_t* meta;              // [ep_size*cap_rows] expert id, -1 = padding
+  int32_t* pair_pos;          // [T*K] row of every pair inside `send`, -1 if not dispatched
+  const int32_t* topk_idx;    // [T*K]
+  const int32_t* counts;      // [ep_size] rows per destination (from dispatch_index on the dest keys)
+  const int32_t* offsets;     // [ep_size+1]
+  const int32_t* slot_pair;   // [T*K] destination-sorted slot -> pair id
+  int K, H, ep_size, cap_rows, dtype;
+};
+hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
+// y_rows[r] = (row_slot[r] >= 0) ? y_sorted[row_slot[r]] : 0
+hipError_t launch_ep_unsort(const void* y_sorted, void* y_rows, const int32_t* row_slot, int n_rows, int H,
+                            int dtype, hipStream_t st);
+
+}  // namespace moeinf

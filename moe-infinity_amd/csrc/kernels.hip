@@ -1,0 +1,744 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the expert-offload hot path.
+//
+//   gate_logits      router GEMV/GEMM, fp64 accumulate (bit-stable routing)        HBM/latency bound
+//   route_topk       softmax + wave-level top-k + renorm, one wave per token       latency bound
+//   dispatch_index   per-expert counts (ballot/popc), prefix sums, stable permutation
+//   ffn_rows         grouped expert FFN as a weight-streaming row-dot kernel: MFMA 16x16 tiles with
+//                    the WEIGHT rows on the M side and <=16 routed tokens on the N side, so one
+//                    pass over an expert's weights serves every token routed to it; fused
+//                    gather (stage 1), fused SiLU*mul / ReLU / bias epilogues      HBM bound
+//   combine          deterministic weighted gather (ascending expert id), reference rounding points
+//
+// What these replace in the reference is a SEQUENCE OF ATen OPS, not kernels (the reference has no
+// device code): SURVEY.md section 2.3 K1..K10.  Rounding points of the reference's dtype-typed ATen ops
+// are reproduced (Tr() below) so results match its CPU path to accumulation-order noise.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace moeinf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+template <typename T>
+struct DT;
+template <>
+struct DT<uint16_t> {  // bf16 storage
+  static constexpr int EPV = 8;  // elements per 16-byte vector
+  __device__ static __forceinline__ float round(float f) { return bf2f(f2bf(f)); }
+  __device__ static __forceinline__ float load(const uint16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void store(uint16_t* p, float f) { *p = f2bf(f); }
+};
+template <>
+struct DT<float> {
+  static constexpr int EPV = 4;
+  __device__ static __forceinline__ float round(float f) { return f; }
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float f) { *p = f; }
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+// ------------------------------------------------------------------------------------------------
+// ffn_rows: grouped expert FFN, one stage.  grid = (ceil(Rmax/16), max_active), block = NW waves.
+//
+// Block (rg, u) owns 16 consecutive output rows [16*rg, 16*rg+16) of expert active[u] (for the
+// gated stage: the same 16 rows of BOTH the gate and the up matrix).  The reduction dimension is
+// split over the block's NW waves in interleaved 128-byte windows, so the 4/8 waves of a block
+// read 512/1024 contiguous bytes of every weight row per step: each weight byte is read exactly
+// once from HBM, straight into VGPRs (no LDS round trip: the stream is not shared between waves).
+// MFMA operands: A = weights (lane: row r = lane&15, quad q = lane>>4), B = activations of up to
+// 16 tokens (lane: token n = lane&15, quad q).  A lane's two 16-byte loads cover 32 contiguous
+// bytes of its row; any k <-> MFMA-slot assignment is legal as long as A and B agree.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <>
+__device__ __forceinline__ void mma16<uint16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+
+template <typename T, int NMAT, int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int WE = 128 / (int)sizeof(T);  // elements per 128-byte window
+  constexpr int U = 4;                      // windows in flight per wave
+  __shared__ float red[NW][NMAT][256];
+
+  const int u = blockIdx.y;
+  if (u >= *s.n_active) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int r0 = blockIdx.x * 16;
+  if (r0 >= R) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row = min(r0 + r, R - 1);
+  const T* a0 = reinterpret_cast<const T*>(W + (sh ? s.off_a_sh : s.off_a)) + (size_t)row * K;
+  const T* a1 = NMAT == 2 ? reinterpret_cast<const T*>(W + (sh ? s.off_b_sh : s.off_b)) + (size_t)row * K : nullptr;
+  const int nfull = K / WE;
+  const int kq = q * 2 * EPV;  // this lane's element offset inside a window
+
+  for (int tile = 0; tile * 16 < cnt; ++tile) {
+    const int srow = off + min(tile * 16 + r, cnt - 1);  // r doubles as the token column n
+    const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+    const T* xr = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    int w = wave;
+    for (; w + (U - 1) * NW < nfull; w += U * NW) {
+      u32x4 av[U][2], bv[U][2], xv[U][2];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const size_t k = (size_t)(w + i * NW) * WE + kq;
+        av[i][0] = ld16_nt(a0 + k);
+        av[i][1] = ld16_nt(a0 + k + EPV);
+        if (NMAT == 2) {
+          bv[i][0] = ld16_nt(a1 + k);
+          bv[i][1] = ld16_nt(a1 + k + EPV);
+        }
+        xv[i][0] = ld16(xr + k);
+        xv[i][1] = ld16(xr + k + EPV);
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        mma16<T>(acc0, av[i][0], xv[i][0]);
+        mma16<T>(acc0, av[i][1], xv[i][1]);
+        if (NMAT == 2) {
+          mma16<T>(acc1, bv[i][0], xv[i][0]);
+          mma16<T>(acc1, bv[i][1], xv[i][1]);
+        }
+      }
+    }
+    for (; w < nfull; w += NW) {
+      const size_t k = (size_t)w * WE + kq;
+      u32x4 x0 = ld16(xr + k), x1 = ld16(xr + k + EPV);
+      mma16<T>(acc0, ld16_nt(a0 + k), x0);
+      mma16<T>(acc0, ld16_nt(a0 + k + EPV), x1);
+      if (NMAT == 2) {
+        mma16<T>(acc1, ld16_nt(a1 + k), x0);
+        mma16<T>(acc1, ld16_nt(a1 + k + EPV), x1);
+      }
+    }
+    if ((K % WE) != 0 && wave == (nfull % NW)) {  // partial last window (K % EPV == 0 required)
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const size_t k = (size_t)nfull * WE + kq + hlf * EPV;
+        const bool ok = (int)k + EPV <= K;
+        u32x4 xx = ok ? ld16(xr + k) : z;
+        mma16<T>(acc0, ok ? ld16_nt(a0 + k) : z, xx);
+        if (NMAT == 2) mma16<T>(acc1, ok ? ld16_nt(a1 + k) : z, xx);
+      }
+    }
+    // cross-wave reduction of the K split
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][lane * 4 + j] = acc0[j];
+      if (NMAT == 2) red[wave][1][lane * 4 + j] = acc1[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 256; i += NW * 64) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) {
+        s0 += red[ww][0][i];
+        if (NMAT == 2) s1 += red[ww][1][i];
+      }
+      const int l = i >> 2, j = i & 3;
+      const int n = l & 15;                 // token column
+      const int orow = r0 + (l >> 4) * 4 + j;  // output row
+      if (tile * 16 + n < cnt && orow < R) {
+        float v = DT<T>::round(s0);
+        if (s.epi == EPI_GATED_SILU) {
+          const float b = DT<T>::round(s1);
+          const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+          v = DT<T>::round(sl * b);
+        } else {
+          if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
+            v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+          if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        }
+        DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + n) * s.ld_out + orow, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st) {
+  const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
+  dim3 grid((rmax + 15) / 16, max_active);
+  const bool gated = (s.epi == EPI_GATED_SILU);
+  // long reductions get 8 waves per block (more bytes in flight per CU), short ones 4
+  const int kmax = s.K > s.K_sh ? s.K : s.K_sh;
+  const size_t kbytes = (size_t)kmax * (s.dtype == DT_BF16 ? 2 : 4);
+  const bool wide = kbytes >= 16384;
+#define LAUNCH(TT, NM, NWV) hipLaunchKernelGGL((ffn_rows_kernel<TT, NM, NWV>), grid, dim3(NWV * 64), 0, st, s)
+  if (s.dtype == DT_BF16) {
+    if (gated) { if (wide) LAUNCH(uint16_t, 2, 8); else LAUNCH(uint16_t, 2, 4); }
+    else       { if (wide) LAUNCH(uint16_t, 1, 8); else LAUNCH(uint16_t, 1, 4); }
+  } else {
+    if (gated) { if (wide) LAUNCH(float, 2, 8); else LAUNCH(float, 2, 4); }
+    else       { if (wide) LAUNCH(float, 1, 8); else LAUNCH(float, 1, 4); }
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate_logits: logits[t][e] = round_once( sum_h x[t][h] * wg[e][h] ), fp64 accumulation.
+// grid = (E, ceil(T/TT)), block = 256.  fp64 makes the result independent of summation order to
+// ~1e-16, so the bf16/fp32 rounding (and with it the top-k choice) matches the oracle bit for bit.
+// ------------------------------------------------------------------------------------------------
+template <typename XT, typename WT, int TT>
+__global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__ x, const WT* __restrict__ wg,
+                                                          float* __restrict__ logits, int T, int H, int E,
+                                                          int round_bf16) {
+  __shared__ double red[4][TT];
+  const int e = blockIdx.x;
+  const int t0 = blockIdx.y * TT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) acc[i] = 0.0;
+  const WT* wrow = wg + (size_t)e * H;
+  for (int h = tid * 4; h < H; h += 256 * 4) {
+    double wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = (double)DT<WT>::load(wrow + h + j);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = min(t0 + i, T - 1);
+      const XT* xr = x + (size_t)t * H + h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i] = fma(wv[j], (double)DT<XT>::load(xr + j), acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    double v = acc[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (tid < TT && t0 + tid < T) {
+    const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    float f = (float)v;
+    if (round_bf16) f = bf2f(f2bf(f));
+    logits[(size_t)(t0 + tid) * E + e] = f;
+  }
+}
+
+hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
+  constexpr int TT = 4;
+  dim3 grid(a.E, (a.T + TT - 1) / TT);
+  // Mixtral's gate is an nn.Linear in the model dtype (mixtral.py:46): its output is rounded to
+  // that dtype.  The other routers compute fp32 logits from (exactly) up-cast inputs.
+  const int rb = (a.kind == 0 /*MIXTRAL*/ && a.x_dtype == DT_BF16) ? 1 : 0;
+#define GL(XT, WT) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
+  if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
+  else if (a.x_dtype == DT_BF16) GL(uint16_t, float);
+  else if (a.gate_dtype == DT_BF16) GL(float, uint16_t);
+  else GL(float, float);
+#undef GL
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// route_topk: one wave per token.  E <= 256 (<= 4 experts per lane, expert id = lane + 64*j).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// arg-max over the wave of (value desc, index asc); entries with idx < 0 never win
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(idx, o);
+    const bool take = (oi >= 0) && (idx < 0 || ov > v || (ov == v && oi < idx));
+    if (take) { v = ov; idx = oi; }
+  }
+}
+// pick the best not-yet-taken entry among this lane's 4 and reduce
+__device__ __forceinline__ void pick_best(const float key[4], uint32_t taken, int lane, int E, float& bv, int& bi) {
+  bv = 0.f; bi = -1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + 64 * j;
+    if (e < E && !((taken >> j) & 1u)) {
+      if (bi < 0 || key[j] > bv) { bv = key[j]; bi = e; }  // ascending e inside a lane: strict > keeps lowest
+    }
+  }
+  wave_argmax(bv, bi);
+}
+
+__global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= a.T) return;
+  const int E = a.E, K = a.K;
+  const float* lg = a.logits + (size_t)t * E;
+  float l[4], p[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + 64 * j;
+    l[j] = (e < E) ? lg[e] : -INFINITY;
+    m = fmaxf(m, l[j]);
+  }
+  m = wave_max(m);
+  float ssum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + 64 * j;
+    p[j] = (e < E) ? expf(l[j] - m) : 0.f;
+    ssum += p[j];
+  }
+  ssum = wave_sum(ssum);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = p[j] / ssum;
+
+  const bool x_bf16 = (a.x_dtype == DT_BF16);
+  int sel[8];
+  float val[8];
+  int valid[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sel[k] = -1; val[k] = 0.f; valid[k] = 1; }
+  uint32_t taken = 0;
+
+  if (a.kind == 0 /*MIXTRAL*/ || (a.kind == 1 /*DEEPSEEK*/ && a.n_group <= 1)) {
+    for (int k = 0; k < K; ++k) {
+      float bv; int bi;
+      pick_best(p, taken, lane, E, bv, bi);
+      sel[k] = bi; val[k] = bv;
+      if (bi >= 0 && (bi & 63) == lane) taken |= 1u << (bi >> 6);
+    }
+  } else if (a.kind == 1) {  // group_limited_greedy (modeling_deepseek.py:484-503)
+    const int gs = E / a.n_group;
+    // group scores: lane g (< n_group) ends up holding max over group g
+    float gscore = -INFINITY;
+    for (int g = 0; g < a.n_group; ++g) {
+      float gm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = lane + 64 * j;
+        if (e < E && e / gs == g) gm = fmaxf(gm, p[j]);
+      }
+      gm = wave_max(gm);
+      if (lane == g) gscore = gm;
+    }
+    uint64_t gmask = 0;  // selected groups (n_group <= 64)
+    bool gtaken = false;
+    for (int k = 0; k < a.topk_group; ++k) {
+      float bv = gscore; int bi = (lane < a.n_group && !gtaken) ? lane : -1;
+      wave_argmax(bv, bi);
+      if (bi == lane) gtaken = true;
+      if (bi >= 0) gmask |= 1ull << bi;
+    }
+    float pm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j;
+      pm[j] = (e < E && ((gmask >> (e / gs)) & 1ull)) ? p[j] : 0.f;
+    }
+    for (int k = 0; k < K; ++k) {
+      float bv; int bi;
+      pick_best(pm, taken, lane, E, bv, bi);
+      sel[k] = bi; val[k] = bv;
+      if (bi >= 0 && (bi & 63) == lane) taken |= 1u << (bi >> 6);
+    }
+  } else if (a.kind == 2 /*SWITCH*/) {
+    float pin[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pin[j] = x_bf16 ? bf2f(f2bf(p[j])) : p[j];
+    float bv; int bi;
+    pick_best(pin, 0u, lane, E, bv, bi);
+    sel[0] = bi; val[0] = bv;
+  } else {  /*NLLB*/
+    float pin[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pin[j] = x_bf16 ? bf2f(f2bf(p[j])) : p[j];
+    float bv; int bi;
+    pick_best(pin, 0u, lane, E, bv, bi);  // top-1 over probabilities cast to the input dtype
+    sel[0] = bi; val[0] = bv;
+    if ((bi & 63) == lane) taken |= 1u << (bi >> 6);
+    float lv; int li;
+    pick_best(l, taken, lane, E, lv, li);  // top-2 over fp32 logits with top-1 masked out
+    sel[1] = li;
+    // probability (input dtype) of the top-2 expert
+    float p2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j == li) p2 = pin[j];
+    p2 = wave_sum(p2);
+    val[1] = p2;
+  }
+
+  // weights
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = 0.f;
+  if (a.kind == 0) {
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += val[k];
+    for (int k = 0; k < K; ++k) { w[k] = val[k] / den; if (x_bf16) w[k] = bf2f(f2bf(w[k])); }
+  } else if (a.kind == 1) {
+    if (K > 1 && a.norm_topk_prob) {
+      float den = 0.f;
+      for (int k = 0; k < K; ++k) den += val[k];
+      den += 1e-20f;
+      for (int k = 0; k < K; ++k) w[k] = val[k] / den;
+    } else {
+      for (int k = 0; k < K; ++k) w[k] = val[k] * a.scale;
+    }
+  } else if (a.kind == 2) {
+    w[0] = val[0];
+  } else {
+    // normalize_router_probabilities in the input dtype (nllb router, eval: capacity never drops)
+    const float eps = x_bf16 ? 0.0078125f : 1.1920928955078125e-07f;
+    float den = val[0] + val[1];
+    if (x_bf16) den = bf2f(f2bf(den));
+    den = fmaxf(den, eps);
+    w[0] = val[0] / den; w[1] = val[1] / den;
+    if (x_bf16) { w[0] = bf2f(f2bf(w[0])); w[1] = bf2f(f2bf(w[1])); }
+    valid[0] = (w[0] != 0.f); valid[1] = (w[1] != 0.f);  // router_mask = combining_weights.bool()
+  }
+
+  if (lane == 0) {
+    // pair order: k indices by ascending expert id (deterministic combine order)
+    int ord[8];
+    for (int k = 0; k < K; ++k) ord[k] = k;
+    for (int i = 1; i < K; ++i) {
+      const int o = ord[i];
+      int j = i - 1;
+      while (j >= 0 && sel[ord[j]] > sel[o]) { ord[j + 1] = ord[j]; --j; }
+      ord[j + 1] = o;
+    }
+    for (int k = 0; k < K; ++k) {
+      a.topk_idx[(size_t)t * K + k] = sel[k];
+      a.topk_w[(size_t)t * K + k] = w[k];
+      a.pair_valid[(size_t)t * K + k] = (sel[k] >= 0) ? valid[k] : 0;
+      a.pair_order[(size_t)t * K + k] = ord[k];
+    }
+    if (a.router_prob) a.router_prob[t] = val[0];
+  }
+}
+
+hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(route_topk_kernel, dim3((a.T + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch_index: single workgroup (1024 threads = 16 waves), chunks of 1024 pairs in pair order
+// (token-major).  Stable counting sort by expert id built from wave ballots:
+//   rank inside the wave   = popc(ballot(same expert) & lanes-below)
+//   rank across waves      = per-wave counts scanned by one thread per expert
+//   rank across chunks     = running per-expert counters in LDS
+// Outputs replace the dense router_mask[T,E] of the reference (mixtral.py:56-65) and the
+// tokens-per-expert D2H sum of dispatch_local (expert_executor.py:34-43).
+// ------------------------------------------------------------------------------------------------
+constexpr int IDX_THREADS = 1024;
+constexpr int IDX_WAVES = IDX_THREADS / 64;
+constexpr int IDX_MAXE = 257;  // E + shared pseudo-expert
+
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
+
+// rank of each counted lane among earlier counted pairs with the same key; updates running[]
+__device__ __forceinline__ int chunk_rank(int key, bool counted, int* wave_cnt /*[IDX_WAVES][IDX_MAXE]*/,
+                                          int* running /*[IDX_MAXE]*/, int nkeys) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < IDX_WAVES * nkeys; i += IDX_THREADS) wave_cnt[(i / nkeys) * IDX_MAXE + (i % nkeys)] = 0;
+  __syncthreads();
+  int rank_in_wave = 0;
+  uint64_t todo = __ballot(counted);
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const int k = __shfl(key, leader);
+    const uint64_t same = __ballot(counted && key == k);
+    if (counted && key == k) rank_in_wave = __popcll(same & lanes_below(lane));
+    if (lane == leader) wave_cnt[wave * IDX_MAXE + k] = __popcll(same);
+    todo &= ~same;
+  }
+  __syncthreads();
+  if (tid < nkeys) {  // exclusive scan over waves, seeded with the running count
+    int base = running[tid];
+    for (int w = 0; w < IDX_WAVES; ++w) {
+      const int c = wave_cnt[w * IDX_MAXE + tid];
+      wave_cnt[w * IDX_MAXE + tid] = base;
+      base += c;
+    }
+    running[tid] = base;
+  }
+  __syncthreads();
+  const int pos = counted ? wave_cnt[wave * IDX_MAXE + key] + rank_in_wave : -1;
+  __syncthreads();
+  return pos;
+}
+
+__global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a) {
+  __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
+  __shared__ int running[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  __shared__ int scan_tmp[IDX_MAXE];
+  const int tid = threadIdx.x;
+  const int E = a.E, K = a.K, T = a.T;
+  const int nkeys = E;
+  const int npairs = T * K;
+
+  // pass A (Switch): per-batch-row capacity.  token_priority = cumsum over the sequence dim of the
+  // un-masked one-hot; tokens with priority > capacity are dropped (HF SwitchTransformersTop1Router).
+  if (a.capacity > 0 && a.pair_valid) {
+    const int S = T / a.rows;  // K == 1
+    for (int b = 0; b < a.rows; ++b) {
+      for (int i = tid; i < nkeys; i += IDX_THREADS) running[i] = 0;
+      __syncthreads();
+      for (int c0 = 0; c0 < S; c0 += IDX_THREADS) {
+        const int s = c0 + tid;
+        const bool in = s < S;
+        const int p = b * S + s;
+        const int key = in ? a.topk_idx[p] : -1;
+        const bool counted = in && key >= 0 && key < E;
+        const int pos = chunk_rank(counted ? key : 0, counted, wave_cnt, running, nkeys);
+        if (counted && pos + 1 > a.capacity) a.pair_valid[p] = 0;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+
+  // pass B: stable rank of every dispatched pair inside its expert
+  for (int i = tid; i < IDX_MAXE; i += IDX_THREADS) running[i] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < npairs; c0 += IDX_THREADS) {
+    const int p = c0 + tid;
+    const bool in = p < npairs;
+    const int key = in ? a.topk_idx[p] : -1;
+    const bool counted = in && key >= 0 && key < E && (a.pair_valid ? a.pair_valid[p] != 0 : true);
+    const int pos = chunk_rank(counted ? key : 0, counted, wave_cnt, running, nkeys);
+    if (in) a.pair_slot[p] = pos;  // rank for now; rebased below
+  }
+  // counts (+ shared pseudo-expert), exclusive scan, active list
+  const int ne = E + 1;
+  if (tid == 0) running[E] = a.shared ? T : 0;
+  __syncthreads();
+  if (tid < ne) scan_tmp[tid] = running[tid];
+  __syncthreads();
+  if (tid == 0) {  // ne <= 257: a serial scan costs < 1 us and keeps the order obvious
+    int acc = 0, na = 0;
+    for (int e = 0; e < ne; ++e) {
+      offs[e] = acc;
+      acc += scan_tmp[e];
+      if (scan_tmp[e] > 0) a.active[na++] = e;
+    }
+    offs[ne] = acc;
+    *a.n_active = na;
+    if (a.mirror) {
+      a.mirror[0] = na;
+      for (int i = 0; i < na; ++i) a.mirror[1 + ne + i] = a.active[i];
+      for (int i = na; i < ne; ++i) a.mirror[1 + ne + i] = -1;
+    }
+  }
+  __syncthreads();
+  if (tid < ne) {
+    a.counts[tid] = scan_tmp[tid];
+    if (a.mirror) a.mirror[1 + tid] = scan_tmp[tid];
+  }
+  if (tid <= ne) a.offsets[tid] = offs[tid];
+  // rebase ranks to expert-sorted rows
+  for (int p = tid; p < npairs; p += IDX_THREADS) {
+    const int rk = a.pair_slot[p];
+    if (rk >= 0) {
+      const int slot = offs[a.topk_idx[p]] + rk;
+      a.pair_slot[p] = slot;
+      a.slot_token[slot] = p / K;
+      a.slot_pair[slot] = p;
+    }
+  }
+  if (a.shared) {
+    for (int t = tid; t < T; t += IDX_THREADS) {
+      a.slot_token[offs[E] + t] = t;
+      a.slot_pair[offs[E] + t] = -1;
+    }
+  }
+}
+
+hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(dispatch_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// combine: out[t] = sum over the token's experts in ASCENDING expert id of w * y, with the
+// reference block's dtype rounding points (mixtral.py:96-101, deepseek.py:123-136,
+// switch_transformers.py:99-109, nllb_moe.py:84-104).  grid = (ceil(H/(256*4)), T).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
+  const int t = blockIdx.y;
+  const int h0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (h0 >= a.H) return;
+  const int K = a.K;
+  const T* y = reinterpret_cast<const T*>(a.y);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nh = min(4, a.H - h0);
+  if (a.kind == 2 /*SWITCH*/) {
+    const int slot = a.pair_slot[t];
+    const T* src = (slot >= 0) ? y + (size_t)slot * a.H : reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
+    const float pr = a.router_prob[t];
+    for (int j = 0; j < nh; ++j)
+      DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, DT<T>::round(pr * DT<T>::load(src + h0 + j)));
+    return;
+  }
+  for (int kk = 0; kk < K; ++kk) {
+    const int k = a.pair_order[(size_t)t * K + kk];
+    const int slot = a.pair_slot[(size_t)t * K + k];
+    if (slot < 0) continue;
+    const float w = a.topk_w[(size_t)t * K + k];
+    const T* yr = y + (size_t)slot * a.H + h0;
+    for (int j = 0; j < nh; ++j) {
+      float prod = DT<T>::load(yr + j) * w;
+      // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
+      // product in fp32 (fp32 gate weights promote the bf16 expert output)
+      if (a.kind != 1) prod = DT<T>::round(prod);
+      acc[j] = DT<T>::round(acc[j] + prod);
+    }
+  }
+  if (a.kind == 1 && a.shared_row0 >= 0) {
+    const T* sr = y + (size_t)(a.shared_row0 + t) * a.H + h0;
+    for (int j = 0; j < nh; ++j) acc[j] = DT<T>::round(acc[j] + DT<T>::load(sr + j));
+  }
+  if (a.kind == 3 /*NLLB: next_states[next_states == 0] = hidden_states[...] */) {
+    const T* xr = reinterpret_cast<const T*>(a.x) + (size_t)t * a.H + h0;
+    for (int j = 0; j < nh; ++j)
+      if (acc[j] == 0.f) acc[j] = DT<T>::load(xr + j);
+  }
+  for (int j = 0; j < nh; ++j) DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, acc[j]);
+}
+
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st) {
+  dim3 grid((a.H + 1023) / 1024, a.T);
+  if (a.dtype == DT_BF16) hipLaunchKernelGGL(combine_kernel<uint16_t>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(combine_kernel<float>, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void poke_kernel(PokeArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n) a.table[a.idx[i]] = a.val[i];
+}
+hipError_t launch_poke(const PokeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// expert-parallel helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void ep_dest_key_kernel(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n, int ep) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int e = topk_idx[p];
+  key[p] = (e >= 0 && (!pair_valid || pair_valid[p])) ? (e % ep) : -1;
+}
+hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n_pairs,
+                              int ep_size, hipStream_t st) {
+  hipLaunchKernelGGL(ep_dest_key_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, topk_idx, pair_valid, key,
+                     n_pairs, ep_size);
+  return hipGetLastError();
+}
+
+// grid = (ep_size*cap_rows), block = 256: one send row per block
+template <typename T>
+__global__ __launch_bounds__(256) void ep_pack_kernel(EpPackArgs a) {
+  const int row = blockIdx.x;
+  const int d = row / a.cap_rows, pos = row % a.cap_rows;
+  const int cnt = a.counts[d];
+  if (pos >= cnt) {
+    if (threadIdx.x == 0) a.meta[row] = -1;
+    return;
+  }
+  const int pair = a.slot_pair[a.offsets[d] + pos];
+  const int t = pair / a.K;
+  if (threadIdx.x == 0) {
+    a.meta[row] = a.topk_idx[pair];
+    a.pair_pos[pair] = row;
+  }
+  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
+  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.H;
+  constexpr int EPV = DT<T>::EPV;
+  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
+}
+__global__ void ep_fill_kernel(int32_t* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st) {
+  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ep_pack_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ep_unsort_kernel(const T* y_sorted, T* y_rows, const int32_t* row_slot, int H) {
+  const int row = blockIdx.x;
+  const int slot = row_slot[row];
+  constexpr int EPV = DT<T>::EPV;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int h = threadIdx.x * EPV; h < H; h += 256 * EPV)
+    *reinterpret_cast<u32x4*>(y_rows + (size_t)row * H + h) = (slot >= 0) ? ld16(y_sorted + (size_t)slot * H + h) : z;
+}
+hipError_t launch_ep_unsort(const void* y_sorted, void* y_rows, const int32_t* row_slot, int n_rows, int H, int dtype,
+                            hipStream_t st) {
+  if (n_rows <= 0) return hipSuccess;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(ep_unsort_kernel<uint16_t>, dim3(n_rows), dim3(256), 0, st, (const uint16_t*)y_sorted,
+                       (uint16_t*)y_rows, row_slot, H);
+  else
+    hipLaunchKernelGGL(ep_unsort_kernel<float>, dim3(n_rows), dim3(256), 0, st, (const float*)y_sorted, (float*)y_rows,
+                       row_slot, H);
+  return hipGetLastError();
+}
+
+}  // namespace moeinf

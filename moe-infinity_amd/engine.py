@@ -1,0 +1,309 @@
+"""Python host layer over the C ABI (include/moeinf.h).
+
+``MoEEngine`` is the object the reference's Python side talks to through
+``prefetch_op.prefetch_handle`` + ``prefetch_op.expert_dispatcher``
+(core/python/py_archer_prefetch.cpp:10-93) — one object here, because the HIP engine fuses
+router, dispatch, residency, FFN and combine behind ``moe_forward``.  torch is used only for
+device memory and streams.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Config, MoeInfError, Stats, check, load_library
+from .config import DTYPE_BF16, DTYPE_F32, EngineConfig
+
+FWD_DEFAULT, FWD_ROUTE_ONLY, FWD_NO_COMBINE = 0, 1, 2
+_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
+_ALIGN = 4096
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class MoEEngine:
+    """One engine per (process, GPU).  Not thread-safe (one caller thread, like the reference's
+    GIL-held pybind calls)."""
+
+    def __init__(self, cfg: EngineConfig):
+        self._h = C.c_void_p()
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("moe-infinity_amd needs a visible MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.cfg = cfg
+        c = Config()
+        c.abi_version = 1
+        for name, _ in Config._fields_:
+            if name in ("abi_version",):
+                continue
+            v = getattr(cfg, name)
+            if name == "gate_dtype" and v is None:
+                v = cfg.dtype
+            if name == "norm_topk_prob":
+                v = int(bool(v))
+            setattr(c, name, v)
+        check(self.lib.moeinf_create(C.byref(c), C.byref(self._h)))
+        self.dtype = _TORCH_DTYPE[cfg.dtype]
+        self.gate_dtype = _TORCH_DTYPE[cfg.dtype if cfg.gate_dtype is None else cfg.gate_dtype]
+        self.device = torch.device("cuda", cfg.device_id)
+        self._last_T = 0
+
+    # ---- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            check(self.lib.moeinf_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- expert blobs ------------------------------------------------------------------------
+    def expert_layout(self, which: int = 0):
+        off = (C.c_int64 * 4)()
+        siz = (C.c_int64 * 4)()
+        n = C.c_int32()
+        tot = C.c_int64()
+        check(self.lib.moeinf_expert_layout(self._h, which, off, siz, C.byref(n), C.byref(tot)))
+        return list(off)[: n.value], list(siz)[: n.value], tot.value
+
+    def pack_expert(self, tensors: Sequence[torch.Tensor], which: int = 0) -> torch.Tensor:
+        """Tensors in the reference's blob order -> one 4 KiB-aligned uint8 blob (CPU)."""
+        off, siz, tot = self.expert_layout(which)
+        if len(tensors) != len(off):
+            raise ValueError(f"expected {len(off)} tensors, got {len(tensors)}")
+        blob = torch.zeros(tot, dtype=torch.uint8)
+        for t, o, s in zip(tensors, off, siz):
+            t = t.detach().to("cpu", self.dtype).contiguous()
+            if t.numel() * t.element_size() != s:
+                raise ValueError(f"tensor of {t.numel() * t.element_size()} bytes where the layout needs {s}")
+            blob[o:o + s] = t.view(torch.uint8).reshape(-1)
+        return blob
+
+    def register_expert(self, layer: int, expert: int, tensors: Optional[Sequence[torch.Tensor]] = None):
+        """expert_dispatcher.register_expert + prefetch_handle.offload (host copy into the pinned arena).
+        tensors=None reserves an uninitialised arena block (fill it through ``expert_host_view``)."""
+        if tensors is None:
+            check(self.lib.moeinf_register_expert(self._h, layer, expert, None, 0))
+            return
+        blob = self.pack_expert(tensors)
+        check(self.lib.moeinf_register_expert(self._h, layer, expert, _ptr(blob), blob.numel()))
+
+    def expert_host_view(self, layer: int, expert: int) -> torch.Tensor:
+        """uint8 view of the expert's pinned host blob (engine-owned memory)."""
+        p = C.c_void_p()
+        check(self.lib.moeinf_expert_host_ptr(self._h, layer, expert, C.byref(p)))
+        _, _, tot = self.expert_layout(0)
+        buf = (C.c_uint8 * tot).from_address(p.value)
+        return torch.frombuffer(buf, dtype=torch.uint8)
+
+    def register_shared(self, layer: int, tensors: Sequence[torch.Tensor]):
+        blob = self.pack_expert(tensors, which=1)
+        check(self.lib.moeinf_register_shared(self._h, layer, _ptr(blob), blob.numel()))
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def _check_dev(self, t: torch.Tensor, dtype, what):
+        if not t.is_cuda or t.device.index != self.cfg.device_id:
+            raise ValueError(f"{what} must live on cuda:{self.cfg.device_id}")
+        if t.dtype != dtype:
+            raise ValueError(f"{what} must be {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{what} must be contiguous")
+
+    def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, batch_rows: int = 1,
+                out: Optional[torch.Tensor] = None, flags: int = FWD_DEFAULT) -> Optional[torch.Tensor]:
+        """One MoE layer: x [..., H] -> out [..., H] (same shape), enqueued on the current stream."""
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        self._check_dev(x2, self.dtype, "x")
+        self._check_dev(gate_w, self.gate_dtype, "gate_w")
+        if x2.shape[1] != self.cfg.hidden or tuple(gate_w.shape) != (self.cfg.num_experts, self.cfg.hidden):
+            raise ValueError("x / gate_w shape does not match the engine config")
+        T = x2.shape[0]
+        if out is None and not (flags & FWD_ROUTE_ONLY):
+            out = torch.empty_like(x2)
+        if out is not None:
+            self._check_dev(out, self.dtype, "out")
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_moe_forward(self._h, layer, _ptr(x2), T, batch_rows, _ptr(gate_w),
+                                          _ptr(out) if out is not None else None, stream, flags))
+        self._last_T = T
+        return out.reshape(shape) if out is not None else None
+
+    def routing(self) -> Dict[str, np.ndarray]:
+        T, K, E = self._last_T, self.cfg.top_k, self.cfg.num_experts
+        idx = np.empty(T * K, np.int32)
+        w = np.empty(T * K, np.float32)
+        counts = np.empty(E, np.int32)
+        offsets = np.empty(E + 1, np.int32)
+        slot_token = np.empty(T * K, np.int32)
+        pair_slot = np.empty(T * K, np.int32)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        check(self.lib.moeinf_get_routing(self._h, p(idx, C.c_int32), p(w, C.c_float), p(counts, C.c_int32),
+                                          p(offsets, C.c_int32), p(slot_token, C.c_int32), p(pair_slot, C.c_int32)))
+        n = int(offsets[E])
+        return dict(topk_idx=idx.reshape(T, K), topk_w=w.reshape(T, K), counts=counts, offsets=offsets,
+                    slot_token=slot_token[:n], pair_slot=pair_slot.reshape(T, K))
+
+    def expert_outputs(self, rows: int) -> torch.Tensor:
+        """First `rows` expert-sorted FFN output rows of the last forward (CPU tensor, engine dtype)."""
+        out = torch.empty((rows, self.cfg.hidden), dtype=self.dtype)
+        if rows:
+            check(self.lib.moeinf_get_expert_outputs(self._h, _ptr(out), out.numel() * out.element_size()))
+        return out
+
+    def logits(self) -> np.ndarray:
+        a = np.empty((self._last_T, self.cfg.num_experts), np.float32)
+        check(self.lib.moeinf_get_logits(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+        return a
+
+    # ---- cache control -----------------------------------------------------------------------
+    def prefetch(self, layer: int, experts: Sequence[int], scores: Optional[Sequence[float]] = None):
+        e, ep = _i32(list(experts))
+        if scores is None:
+            sp = None
+        else:
+            s = np.ascontiguousarray(scores, dtype=np.float32)
+            sp = s.ctypes.data_as(C.POINTER(C.c_float))
+        check(self.lib.moeinf_prefetch(self._h, layer, ep, sp, len(e)))
+
+    def protect(self, pairs: Sequence[Sequence[int]]):
+        """replace_cache_candidates: pairs = [(layer, expert), ...]"""
+        l, lp = _i32([p[0] for p in pairs])
+        e, ep = _i32([p[1] for p in pairs])
+        check(self.lib.moeinf_protect(self._h, lp, ep, len(l)))
+
+    def clear_expert_cache_counts(self):
+        check(self.lib.moeinf_clear_cache_counts(self._h))
+
+    def is_resident(self, layer: int, expert: int) -> bool:
+        r = C.c_int32()
+        check(self.lib.moeinf_is_resident(self._h, layer, expert, C.byref(r)))
+        return bool(r.value)
+
+    def sync_copies(self):
+        check(self.lib.moeinf_sync_copies(self._h))
+
+    def expert_counters(self) -> np.ndarray:
+        """[L, E, 6] = visit, hit, miss, prefetch, incache_visit_count, resident (get_hit_rate analogue)."""
+        a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 6), np.int64)
+        check(self.lib.moeinf_get_expert_counters(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
+        return a
+
+    def stats(self) -> dict:
+        s = Stats()
+        check(self.lib.moeinf_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        check(self.lib.moeinf_reset_stats(self._h))
+
+    # ---- expert parallel ---------------------------------------------------------------------
+    def ep_pack(self, x2: torch.Tensor, send: torch.Tensor, meta: torch.Tensor, send_counts: torch.Tensor, cap_rows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_pack(self._h, _ptr(x2), _ptr(send), _ptr(meta), _ptr(send_counts), cap_rows, stream))
+
+    def ep_expert_ffn(self, layer: int, recv: torch.Tensor, meta: torch.Tensor, y: torch.Tensor, cap_rows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_expert_ffn(self._h, layer, _ptr(recv), _ptr(meta), _ptr(y), cap_rows, stream))
+
+    def ep_combine(self, x2: torch.Tensor, ret: torch.Tensor, out: torch.Tensor, cap_rows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_combine(self._h, _ptr(x2), _ptr(ret), _ptr(out), cap_rows, stream))
+
+
+class CacheSim:
+    """Host-only replacement-policy simulator (same code the engine uses for eviction)."""
+
+    def __init__(self, num_slots: int, policy: int = 0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        check(self.lib.moeinf_cache_sim_create(num_slots, policy, C.byref(self._h)))
+
+    def access(self, ident: int):
+        hit = C.c_int32()
+        ev = C.c_int64()
+        check(self.lib.moeinf_cache_sim_access(self._h, ident, C.byref(hit), C.byref(ev)))
+        return bool(hit.value), ev.value
+
+    def protect(self, ids: Sequence[int]):
+        a = np.ascontiguousarray(list(ids), dtype=np.int64)
+        check(self.lib.moeinf_cache_sim_protect(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), len(a)))
+
+    def clear_counts(self):
+        check(self.lib.moeinf_cache_sim_clear_counts(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.moeinf_cache_sim_destroy(self._h)
+        except Exception:
+            pass
+
+
+class ExpertTracerNative:
+    """Native tracer/predictor (moe_infinity/memory/expert_tracer.py + expert_predictor.py +
+    expert_prefetcher.py ordering).  Host only."""
+
+    def __init__(self, num_layers: int, num_experts: int, capacity: int):
+        self.lib = load_library()
+        self.L, self.E, self.capacity = num_layers, num_experts, capacity
+        self._h = C.c_void_p()
+        check(self.lib.moeinf_tracer_create(num_layers, num_experts, capacity, C.byref(self._h)))
+
+    def load_trace(self, eams: np.ndarray):
+        a = np.ascontiguousarray(eams, dtype=np.float32)
+        assert a.shape[1:] == (self.L, self.E)
+        check(self.lib.moeinf_tracer_load(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]))
+
+    def create_entry(self) -> int:
+        s = C.c_int64()
+        check(self.lib.moeinf_tracer_create_entry(self._h, C.byref(s)))
+        return s.value
+
+    def finish_entry(self, seq_id: int):
+        check(self.lib.moeinf_tracer_finish_entry(self._h, seq_id))
+
+    def predict(self, seq_id: int, expert_list, layer_idx: int):
+        e, ep = _i32(np.asarray(expert_list).reshape(-1))
+        m = np.empty((self.L, self.E), np.float32)
+        near = C.c_int32()
+        check(self.lib.moeinf_tracer_predict(self._h, seq_id, layer_idx, ep, len(e), m.ctypes.data_as(C.POINTER(C.c_float)),
+                                             C.byref(near)))
+        return m, near.value
+
+    def prefetch_order(self, layer_idx: int, matrix: np.ndarray):
+        m = np.ascontiguousarray(matrix, dtype=np.float32)
+        n = C.c_int32()
+        ls = np.empty(self.L * self.E, np.int32)
+        es = np.empty(self.L * self.E, np.int32)
+        sc = np.empty(self.L * self.E, np.float32)
+        check(self.lib.moeinf_tracer_prefetch_order(self._h, layer_idx, m.ctypes.data_as(C.POINTER(C.c_float)),
+                                                    ls.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    es.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    sc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        return ls[: n.value], es[: n.value], sc[: n.value]
+
+    def get_eam(self, seq_id: int) -> np.ndarray:
+        a = np.empty((self.L, self.E), np.float64)
+        check(self.lib.moeinf_tracer_get_eam(self._h, seq_id, a.ctypes.data_as(C.POINTER(C.c_double))))
+        return a
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.moeinf_tracer_destroy(self._h)
+        except Exception:
+            pass

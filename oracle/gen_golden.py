@@ -311,6 +311,8 @@ def gen_tracer(mods, name, layers, experts, capacity, n_hist, steps, k, seed):
     def to_nocuda(self, *a, **kw):
         if a and isinstance(a[0], str) and a[0].startswith("cuda"):
             return self
+        if a and isinstance(a[0], str) and a[0] == "cpu":
+            return self.clone()  # on the real device .to("cpu") copies; the predictor then edits its copy in place
         return orig_to(self, *a, **kw)
 
     torch.zeros, torch.Tensor.to = zeros_cpu, to_nocuda
@@ -384,7 +386,8 @@ def main():
     gen_switch(mods, "switch_prefill_cap.npz", 2, 40, 192, 384, 8, 6, seed=8)
     gen_nllb(mods, "nllb_decode_b8.npz", 8, 1, 256, 512, 16, seed=9)
     gen_nllb(mods, "nllb_prefill_f32.npz", 2, 12, 256, 512, 16, seed=10, dtype=torch.float32, norm_before=True)
-    gen_tracer(mods, "tracer_l6_e8.npz", 6, 8, 32, 20, 4, 2, seed=11)
+    gen_tracer(mods, "tracer_l6_e8_full.npz", 6, 8, 24, 24, 4, 2, seed=11)
+    gen_tracer(mods, "tracer_l6_e8_partial.npz", 6, 8, 32, 20, 3, 2, seed=12)  # empty slots -> NaN/argmin quirk
 
 
 if __name__ == "__main__":

@@ -1,0 +1,264 @@
+"""Parity of the HIP path (through the C ABI, libmoeinf_hip.so) against the oracle and against the
+golden vectors produced by the reference's own Python blocks.  Needs an MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (R, acts, assert_model_close, checksum, engine_for, load_golden, make_weights, oracle_expert_rows,
+                     register_all, tt)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _routing_sets(idx):
+    return [sorted(int(v) for v in row if v >= 0) for row in idx]
+
+
+def _check_routing_exact(eng, ref, k_sorted=True):
+    r = eng.routing()
+    if k_sorted:  # descending-weight order is defined (Mixtral topk sorted=True)
+        assert np.array_equal(r["topk_idx"], ref.topk_idx.numpy().astype(np.int32)), "routing indices must be bit-exact"
+    else:
+        assert _routing_sets(r["topk_idx"]) == _routing_sets(ref.topk_idx.numpy()), "routing sets must be bit-exact"
+    return r
+
+
+def _check_dispatch_index(r, ref):
+    counts, offsets, slot_token, _ = R.dispatch_index(ref.router_mask)
+    assert np.array_equal(r["counts"], counts.numpy().astype(np.int32))
+    assert np.array_equal(r["offsets"], offsets.numpy().astype(np.int32))
+    assert np.array_equal(r["slot_token"], slot_token.numpy().astype(np.int32))
+
+
+@pytest.mark.parametrize("name", ["mixtral_decode_b1.npz", "mixtral_decode_b4.npz", "mixtral_prefill_t48.npz"])
+def test_mixtral_golden(name):
+    z = load_golden(name)
+    b, s, h, f, e, k, seed = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights("mixtral", h, f, e, seed, torch.bfloat16)
+    np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=b * s)
+    register_all(eng, experts)
+    x = tt(z["x"], torch.bfloat16)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x, gate, experts, top_k=k)
+    r = _check_routing_exact(eng, ref)
+    # also bit-exact against what the reference's block itself chose
+    assert np.array_equal(r["topk_idx"], z["topk_idx"].astype(np.int32))
+    assert np.array_equal(eng.logits(), z["logits"].astype(np.float32)), "bf16 gate logits must be bit-equal"
+    _check_dispatch_index(r, ref)
+    assert_model_close(torch.from_numpy(r["topk_w"]), ref.topk_w, torch.bfloat16, "routing weights")
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle")
+    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["deepseek_decode_b1.npz", "deepseek_prefill_t40.npz", "deepseek_group_t16.npz"])
+def test_deepseek_golden(name):
+    z = load_golden(name)
+    b, s, h, f, e, k, n_shared, seed = [int(v) for v in z["meta"]]
+    method, n_group, topk_group, norm, scaling = [str(v) for v in z["cfg"]]
+    gate, experts, shared = make_weights("deepseek", h, f, e, seed, torch.bfloat16, n_shared=n_shared)
+    kw, okw = {}, dict(topk_method=method, norm_topk_prob=bool(int(norm)), routed_scaling_factor=float(scaling))
+    if method != "greedy":
+        kw.update(n_group=int(n_group), topk_group=int(topk_group))
+        okw.update(n_group=int(n_group), topk_group=int(topk_group))
+    eng = engine_for("deepseek", h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=b * s,
+                     norm_topk_prob=bool(int(norm)), routed_scaling_factor=float(scaling), **kw)
+    register_all(eng, experts, shared)
+    x = tt(z["x"], torch.bfloat16)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_deepseek(x, gate, experts, k, shared=shared, **okw)
+    r = _check_routing_exact(eng, ref, k_sorted=False)
+    assert _routing_sets(r["topk_idx"]) == _routing_sets(z["topk_idx"]), "sets vs the reference's MoEGate"
+    _check_dispatch_index(r, ref)
+    # weights keyed by expert id
+    for t in range(b * s):
+        got = {int(i): float(w) for i, w in zip(r["topk_idx"][t], r["topk_w"][t])}
+        want = {int(i): float(w) for i, w in zip(ref.topk_idx[t], ref.topk_w[t])}
+        for i in want:
+            assert abs(got[i] - want[i]) <= 2e-6 * max(1.0, abs(want[i])), (t, i, got[i], want[i])
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle")
+    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["switch_decode_b1.npz", "switch_prefill_cap.npz"])
+def test_switch_golden(name):
+    z = load_golden(name)
+    b, s, h, f, e, cap, seed = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights("switch", h, f, e, seed, torch.float32, gate_std=0.5)
+    eng = engine_for("switch", h, f, e, 1, torch.float32, max_tokens=b * s, expert_capacity=cap)
+    register_all(eng, experts)
+    x = tt(z["x"], torch.float32)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV), batch_rows=b)
+    ref = R.block_switch(x, gate, experts, expert_capacity=cap)
+    r = eng.routing()
+    want_idx = np.where(z["router_mask"].reshape(b * s, e).sum(-1) > 0, z["router_mask"].reshape(b * s, e).argmax(-1), -1)
+    assert np.array_equal(r["topk_idx"][:, 0], want_idx.astype(np.int32)), "top-1 + capacity drops must be bit-exact"
+    _check_dispatch_index(r, ref)
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.float32, "expert FFN outputs")
+    assert_model_close(out, ref.out, torch.float32, "block output vs oracle")
+    assert_model_close(out, tt(z["out"], torch.float32), torch.float32, "block output vs reference golden")
+    eng.close()
+
+
+@pytest.mark.parametrize("name,dtype", [("nllb_decode_b8.npz", torch.bfloat16), ("nllb_prefill_f32.npz", torch.float32)])
+def test_nllb_golden(name, dtype):
+    z = load_golden(name)
+    b, s, h, f, e, seed, norm_before = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights("nllb", h, f, e, seed, dtype, gate_std=0.5)
+    eng = engine_for("nllb", h, f, e, 2, dtype, max_tokens=b * s, norm_topk_prob=bool(norm_before))
+    register_all(eng, experts)
+    x = tt(z["x"], dtype)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_nllb(x, gate, experts, normalize_router_prob_before_dropping=bool(norm_before))
+    r = eng.routing()
+    want_mask = z["router_probs"].reshape(b * s, e) != 0
+    got_mask = np.zeros_like(want_mask)
+    for t in range(b * s):
+        for i in r["topk_idx"][t]:
+            if i >= 0:
+                got_mask[t, i] = True
+    assert np.array_equal(got_mask, want_mask), "routing sets must be bit-exact vs the reference"
+    assert np.array_equal(r["topk_idx"][:, 0], z["top1"].reshape(-1).astype(np.int32))
+    _check_dispatch_index(r, ref)
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dtype, "expert FFN outputs")
+    assert_model_close(out, ref.out, dtype, "block output vs oracle")
+    assert_model_close(out, tt(z["out"], torch.float32), dtype, "block output vs reference golden")
+    eng.close()
+
+
+# ---- shapes the golden set does not reach -------------------------------------------------------
+@pytest.mark.parametrize("t,h,f,e,k", [(1, 512, 1024, 8, 2), (3, 1024, 2816, 8, 2), (33, 256, 176, 4, 2), (70, 512, 768, 8, 2)])
+def test_mixtral_shapes(t, h, f, e, k):
+    """ragged token counts (more than 16 tokens on one expert -> several MFMA token tiles), partial
+    last 128-byte window (F=176), long reductions (8-wave blocks)."""
+    gate, experts, _ = make_weights("mixtral", h, f, e, 100 + t, torch.bfloat16)
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 5000 + t)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    r = _check_routing_exact(eng, ref)
+    _check_dispatch_index(r, ref)
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+    assert_model_close(out, ref.out[0], torch.bfloat16, "block output")
+    eng.close()
+
+
+def test_all_tokens_one_expert_and_empty_experts():
+    """collision edge: identical tokens -> every token picks the same experts; the rest stay empty."""
+    h, f, e, k, t = 256, 512, 8, 2, 20
+    gate, experts, _ = make_weights("mixtral", h, f, e, 31, torch.bfloat16)
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(1, h, torch.bfloat16, 77).repeat(t, 1)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    r = _check_routing_exact(eng, ref)
+    assert int((r["counts"] > 0).sum()) == k and int(r["counts"].max()) == t
+    assert_model_close(out, ref.out[0], torch.bfloat16, "block output")
+    eng.close()
+
+
+def test_routing_ties_lowest_index():
+    """exact ties in the bf16 gate: two identical gate rows -> tie goes to the lowest expert id."""
+    h, f, e, k, t = 256, 512, 8, 2, 16
+    gate, experts, _ = make_weights("mixtral", h, f, e, 32, torch.bfloat16)
+    gate[5] = gate[2]
+    gate[7] = gate[2]
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 78)
+    eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    _check_routing_exact(eng, ref)
+    eng.close()
+
+
+def test_eviction_keeps_results_exact():
+    """cache smaller than the expert set: results must not depend on residency (policy never
+    changes numerics), hit/miss accounting must add up, evicted experts must be re-fetched."""
+    h, f, e, k, t, L = 256, 512, 8, 2, 4, 3
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    ws = [make_weights("mixtral", h, f, e, 200 + l, torch.bfloat16) for l in range(L)]
+    slot = 3 * f * h * 2
+    cfg = Cf.EngineConfig(num_layers=L, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f, top_k=k,
+                          router_kind=Cf.ROUTER_MIXTRAL, device_memory_bytes=5 * slot, max_tokens=t)
+    eng = MoEEngine(cfg)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    for step in range(6):
+        for l in range(L):
+            x = acts(t, h, torch.bfloat16, 9000 + 10 * step + l)
+            out = eng.forward(l, x.to(DEV), ws[l][0].to(DEV))
+            ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
+            _check_routing_exact(eng, ref)
+            assert_model_close(out, ref.out[0], torch.bfloat16, f"step {step} layer {l}")
+    st = eng.stats()
+    assert st["slots_total"] == 5 and st["slots_used"] <= 5
+    assert st["expert_misses"] > 5 and st["evictions"] > 0
+    c = eng.expert_counters()
+    assert int(c[..., 1].sum()) == st["expert_hits"] and int(c[..., 2].sum()) == st["expert_misses"]
+    assert int(c[..., 0].sum()) == st["expert_hits"] + st["expert_misses"]
+    assert st["h2d_bytes"] == st["expert_misses"] * st["slot_bytes"]
+    eng.close()
+
+
+def test_prefetch_makes_hits_and_protect_blocks_eviction():
+    h, f, e, k, t = 256, 512, 8, 2, 2
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    gate, experts, _ = make_weights("mixtral", h, f, e, 300, torch.bfloat16)
+    slot = 3 * f * h * 2
+    eng = MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f,
+                                    top_k=k, router_kind=Cf.ROUTER_MIXTRAL, device_memory_bytes=4 * slot, max_tokens=t))
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 301)
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    need = sorted({int(v) for v in ref.topk_idx.reshape(-1)})
+    eng.prefetch(0, need)
+    eng.sync_copies()
+    assert all(eng.is_resident(0, i) for i in need)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    st = eng.stats()
+    assert st["expert_misses"] == 0 and st["expert_hits"] == len(need) and st["prefetch_useful"] == len(need)
+    assert_model_close(out, ref.out[0], torch.bfloat16, "prefetched forward")
+    # protected experts survive a prefetch storm of everything else
+    eng.protect([(0, i) for i in need])
+    others = [i for i in range(e) if i not in need]
+    eng.prefetch(0, others)
+    eng.sync_copies()
+    assert all(eng.is_resident(0, i) for i in need)
+    eng.close()
+
+
+def test_error_paths_do_not_abort():
+    from moe_infinity_amd import MoeInfError
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd import MoEEngine
+
+    with pytest.raises(MoeInfError):
+        MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=Cf.EXPERT_SWITCH_GATED, hidden=256, inter=512,
+                                  top_k=1, router_kind=Cf.ROUTER_SWITCH))
+    eng = engine_for("mixtral", 256, 512, 8, 2, torch.bfloat16, max_tokens=4)
+    gate = torch.zeros(8, 256, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(2, 256, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(MoeInfError):  # experts never registered
+        eng.forward(0, x, gate)
+    with pytest.raises(MoeInfError):
+        eng.forward(3, x, gate)
+    with pytest.raises(MoeInfError):
+        eng.forward(0, torch.zeros(9, 256, dtype=torch.bfloat16, device=DEV), gate)
+    eng.close()
