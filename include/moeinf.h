@@ -202,6 +202,24 @@ int moeinf_get_expert_counters(moeinf_engine* eng, int64_t* out, int64_t n_int64
 int moeinf_get_stats(moeinf_engine* eng, moeinf_stats* out);
 int moeinf_reset_stats(moeinf_engine* eng);
 
+/* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------------
+ * With profiling on, every forward brackets its kernels with HIP events ON THE CALLER'S STREAM
+ * (the stream the kernels are launched on) and accumulates durations plus the ALGORITHMIC bytes
+ * each launch had to move (DESIGN.md section "algorithmic bytes"):
+ *   ffn1: active experts' gate/up (or fc1/wi) weights + gathered x rows read + h rows written
+ *   ffn2: active experts' down (fc2/wo) weights + h rows read + y rows written
+ *   route: gate weight + x read, logits/top-k written;  combine: y rows + x read, out written */
+typedef struct moeinf_profile {
+  int64_t forwards;
+  int64_t ffn1_launches, ffn2_launches;
+  int64_t ffn1_bytes, ffn2_bytes, route_bytes, combine_bytes;
+  double route_ms, ffn1_ms, ffn2_ms, combine_ms;
+  double host_wait_ms; /* wall-clock time the host spent blocked on the routing D2H */
+} moeinf_profile;
+int moeinf_set_profiling(moeinf_engine* eng, int enabled);
+/* synchronises the last stream, returns the accumulated numbers and resets them */
+int moeinf_get_profile(moeinf_engine* eng, moeinf_profile* out);
+
 /* ---- activation-aware tracer / predictor ---------------------------------------------------
  * Host-side restatement of moe_infinity/memory/expert_tracer.py, expert_predictor.py,
  * expert_prefetcher.py (EAM = expert activation matrix [L,E]). */

@@ -43,6 +43,18 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Profile(C.Structure):
+    _fields_ = [
+        ("forwards", C.c_int64), ("ffn1_launches", C.c_int64), ("ffn2_launches", C.c_int64),
+        ("ffn1_bytes", C.c_int64), ("ffn2_bytes", C.c_int64), ("route_bytes", C.c_int64), ("combine_bytes", C.c_int64),
+        ("route_ms", C.c_double), ("ffn1_ms", C.c_double), ("ffn2_ms", C.c_double), ("combine_ms", C.c_double),
+        ("host_wait_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _P = C.c_void_p
 _I32P = C.POINTER(C.c_int32)
 _I64P = C.POINTER(C.c_int64)
@@ -71,6 +83,8 @@ PROTOTYPES = {
     "moeinf_get_expert_counters": (C.c_int, [_P, _I64P, C.c_int64]),
     "moeinf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "moeinf_reset_stats": (C.c_int, [_P]),
+    "moeinf_set_profiling": (C.c_int, [_P, C.c_int]),
+    "moeinf_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
     "moeinf_tracer_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "moeinf_tracer_destroy": (C.c_int, [_P]),
     "moeinf_tracer_load": (C.c_int, [_P, _F32P, C.c_int]),

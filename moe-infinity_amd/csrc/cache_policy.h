@@ -31,8 +31,9 @@ struct PolicyEntry {
 };
 
 // Pick a victim among entries[0..n) (index order = tie-break order).  Returns -1 if none.
-// Protected entries are only taken when nothing else is evictable.
-inline int64_t pick_victim(const PolicyEntry* entries, int64_t n, int policy) {
+// Protected entries are only taken when nothing else is evictable AND allow_protected is set
+// (demand fetches must make progress; prefetches must never displace the protected set).
+inline int64_t pick_victim(const PolicyEntry* entries, int64_t n, int policy, bool allow_protected = true) {
   int64_t best = -1, best_prot = -1;
   int64_t best_key = std::numeric_limits<int64_t>::max(), best_prot_key = std::numeric_limits<int64_t>::max();
   for (int64_t i = 0; i < n; ++i) {
@@ -45,7 +46,7 @@ inline int64_t pick_victim(const PolicyEntry* entries, int64_t n, int policy) {
       if (key < best_key) { best_key = key; best = i; }
     }
   }
-  return best >= 0 ? best : best_prot;
+  return best >= 0 ? best : (allow_protected ? best_prot : -1);
 }
 
 // Standalone fixed-capacity cache driven by the same policy (tests, hit-rate studies).

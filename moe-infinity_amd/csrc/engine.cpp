@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,12 @@ struct moeinf_engine {
   int last_rows = 0;
 
   moeinf_stats st;
+
+  // profiling
+  bool profiling = false;
+  struct ProfRec { hipEvent_t ev[6]; };
+  std::vector<ProfRec> prof_pending;
+  moeinf_profile prof;
 };
 
 static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }
@@ -278,6 +285,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   moeinf_engine* g = new moeinf_engine();
   g->cfg = *cfg;
   memset(&g->st, 0, sizeof g->st);
+  memset(&g->prof, 0, sizeof g->prof);
   for (int i = 0; i < kFenceRing; ++i) g->fence_ev[i] = nullptr;
   g->L = cfg->num_layers; g->E = cfg->num_experts; g->K = cfg->top_k; g->H = cfg->hidden; g->F = cfg->inter; g->Fs = cfg->shared_inter;
   g->has_shared = cfg->shared_inter > 0;
@@ -302,7 +310,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   int64_t owned = 0;
   for (int e = 0; e < g->E; ++e) if (owns(g, e)) ++owned;
   g->max_slots = std::min<int64_t>(budget / g->slot_bytes, owned * g->L);
-  if (g->max_slots < std::min<int64_t>(g->K, owned)) { fail(MOEINF_ERR_OOM, "device budget %lld bytes holds %lld experts of %lld bytes; need at least %d", (long long)budget, (long long)g->max_slots, (long long)g->slot_bytes, g->K); return bail(MOEINF_ERR_OOM); }
+  if (g->max_slots < 1) { fail(MOEINF_ERR_OOM, "device budget %lld bytes cannot hold one expert of %lld bytes", (long long)budget, (long long)g->slot_bytes); return bail(MOEINF_ERR_OOM); }
   g->st.slots_total = g->max_slots;
   g->st.slot_bytes = g->slot_bytes;
 
@@ -410,7 +418,7 @@ static void drop_ready_count(moeinf_engine* g, int idx) {
 }
 
 // obtain a device slot for node `idx`; may evict.  Pinned entries (pol[].pinned) are never evicted.
-static int acquire_slot(moeinf_engine* g, int idx, int* slot_out) {
+static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_protected) {
   if (!g->free_slots.empty()) {
     *slot_out = g->free_slots.back();
     g->free_slots.pop_back();
@@ -430,8 +438,8 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out) {
     g->slab_exhausted = true;  // physical memory ran out before the budget did: cache stops growing
     g->st.slots_total = (int64_t)g->slots.size();
   }
-  const int64_t v = pick_victim(g->pol.data(), (int64_t)g->pol.size(), g->cfg.policy);
-  if (v < 0) return fail(MOEINF_ERR_OOM, "no evictable expert: %zu slots all pinned by the current layer", g->slots.size());
+  const int64_t v = pick_victim(g->pol.data(), (int64_t)g->pol.size(), g->cfg.policy, allow_protected);
+  if (v < 0) return fail(MOEINF_ERR_OOM, "no evictable expert: %zu slots all pinned or protected", g->slots.size());
   Node& vn = g->nodes[v];
   drop_ready_count(g, (int)v);
   const int slot = vn.slot;
@@ -447,11 +455,11 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out) {
 }
 
 // start the H2D copy of node idx into a slot on `cs`
-static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs) {
+static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs, bool allow_protected) {
   Node& n = g->nodes[idx];
   if (!n.host) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) was dispatched but never registered", idx % g->L, idx / g->L);
   int slot = -1;
-  CHK(acquire_slot(g, idx, &slot));
+  CHK(acquire_slot(g, idx, &slot, allow_protected));
   Slot& s = g->slots[slot];
   // the slot's previous tenant may still be read by kernels of forward #last_use_seq
   // (fence ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence)
@@ -508,6 +516,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   s.wptr = g->d_wptr + (size_t)layer * (g->E + 1);
   s.active = g->d_active; s.n_active = g->d_n_active; s.counts = g->d_counts; s.offsets = g->d_offsets;
   s.miss_flag = g->d_miss;
+  s.n_active_host = -1;
   s.E = g->E;
   s.dtype = g->dt;
   const int et = g->cfg.expert_type;
@@ -530,15 +539,15 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
 
 // make every active routed expert of `layer` resident and order the compute stream after its copy.
 // h_mirror = {n_active, counts[E+1], active[E+1]} (already on the host).
-static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st) {
+static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 = 0, int a1 = -1) {
   const int E1 = g->E + 1;
-  const int na = g->h_mirror[0];
+  const int na = a1 < 0 ? g->h_mirror[0] : a1;
   const int32_t* counts = g->h_mirror + 1;
   const int32_t* active = g->h_mirror + 1 + E1;
   // pin this layer's active experts so a miss cannot evict a sibling that the same launch reads
-  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
+  for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
   int rc = MOEINF_OK;
-  for (int i = 0; i < na && rc == MOEINF_OK; ++i) {
+  for (int i = a0; i < na && rc == MOEINF_OK; ++i) {
     const int e = active[i];
     if (e >= g->E) continue;  // shared pseudo-expert
     (void)counts;
@@ -552,7 +561,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st) {
     } else {
       n.miss += 1;
       g->st.expert_misses += 1;
-      rc = issue_copy(g, idx, g->demand_stream);
+      rc = issue_copy(g, idx, g->demand_stream, true);
       if (rc != MOEINF_OK) break;
     }
     if (!n.ready_waited) {
@@ -565,8 +574,46 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st) {
     g->pol[idx].last_access = ++g->clock;
     g->slots[n.slot].last_use_seq = g->seq + 1;
   }
-  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
+  for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
   return rc;
+}
+
+// Launch both FFN stages for the active list in h_mirror.  If the layer needs more experts than
+// the device cache holds, the list is processed in chunks (the reference runs experts one at a
+// time, so it has no such limit): each chunk is made resident, launched, and fenced so the next
+// chunk may recycle its slots once its kernels have drained.
+static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_t st, hipEvent_t ev_before,
+                       hipEvent_t ev_mid, hipEvent_t ev_after) {
+  const int E = g->E, E1 = E + 1;
+  const int na = g->h_mirror[0];
+  const int32_t* active = g->h_mirror + 1 + E1;
+  const int64_t cap = g->slab_exhausted ? (int64_t)g->slots.size() : g->max_slots;
+  FfnStage s1, s2;
+  fill_stage(g, layer, 1, s1);
+  s1.in = x_in;
+  fill_stage(g, layer, 2, s2);
+  if (ev_before) HIPCHK(hipEventRecord(ev_before, st));
+  int a = 0;
+  while (a < na) {
+    int b = a;
+    int64_t used = 0;
+    while (b < na && (active[b] >= E || used < cap)) { if (active[b] < E) ++used; ++b; }
+    CHK(ensure_resident(g, layer, st, a, b));
+    CHK(flush_pokes(g, st));
+    s1.active = g->d_active + a; s2.active = g->d_active + a;
+    s1.n_active_host = b - a; s2.n_active_host = b - a;
+    HIPCHK(launch_ffn_stage(s1, b - a, st));
+    if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
+    HIPCHK(launch_ffn_stage(s2, b - a, st));
+    a = b;
+    if (a < na) {
+      g->seq += 1;
+      HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+    }
+  }
+  if (na == 0 && ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
+  if (ev_after) HIPCHK(hipEventRecord(ev_after, st));
+  return MOEINF_OK;
 }
 
 extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
@@ -592,6 +639,9 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
   ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
   ra.router_prob = g->d_router_prob;
+  moeinf_engine::ProfRec pr;
+  const bool prof = g->profiling && !route_only;
+  if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
   HIPCHK(launch_gate_logits(ra, st));
   HIPCHK(launch_route_topk(ra, st));
 
@@ -610,21 +660,29 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
 
   // Residency.  The host needs the active-expert list to decide fetches/evictions (the reference does
   // the same D2H every layer, expert_executor.py:34-43); one small pinned copy + event.
+  if (prof) HIPCHK(hipEventRecord(pr.ev[1], st));
   HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(g->route_ev, st));
+  const auto tw0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(g->route_ev));
-  CHK(ensure_resident(g, layer, st));
-  CHK(flush_pokes(g, st));
-
+  if (g->profiling) g->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
   const int na = g->h_mirror[0];
-  FfnStage s1, s2;
-  fill_stage(g, layer, 1, s1);
-  s1.in = x_dev;
-  fill_stage(g, layer, 2, s2);
-  if (na > 0) {
-    HIPCHK(launch_ffn_stage(s1, na, st));
-    HIPCHK(launch_ffn_stage(s2, na, st));
+  if (prof) {
+    // algorithmic bytes of this forward
+    int64_t U = 0, rows = 0;
+    for (int e = 0; e < E; ++e) { if (g->h_mirror[1 + e] > 0) { ++U; rows += g->h_mirror[1 + e]; } }
+    const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = g->has_shared ? T : 0;
+    const int et = g->cfg.expert_type;
+    const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
+    const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
+    g->prof.ffn1_bytes += U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
+    g->prof.ffn2_bytes += U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
+    g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
+    g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
+    g->prof.forwards += 1;
+    if (na > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
   }
+  CHK(run_experts(g, layer, x_dev, st, prof ? pr.ev[2] : nullptr, prof ? pr.ev[3] : nullptr, prof ? pr.ev[4] : nullptr));
   if (!(flags & MOEINF_FWD_NO_COMBINE)) {
     CombineArgs ca;
     memset(&ca, 0, sizeof ca);
@@ -641,9 +699,34 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     }
     HIPCHK(launch_combine(ca, st));
   }
+  if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
   // fence: slots used by this forward may be recycled only after this point of the stream
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_set_profiling(moeinf_engine* g, int enabled) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  g->profiling = enabled != 0;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
+  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  if (g->last_stream || g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
+  for (auto& r : g->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) g->prof.route_ms += ms;
+    if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) g->prof.ffn1_ms += ms;
+    if (hipEventElapsedTime(&ms, r.ev[3], r.ev[4]) == hipSuccess) g->prof.ffn2_ms += ms;
+    if (hipEventElapsedTime(&ms, r.ev[4], r.ev[5]) == hipSuccess) g->prof.combine_ms += ms;
+    for (int i = 0; i < 6; ++i) g->event_pool.push_back(r.ev[i]);
+  }
+  g->prof_pending.clear();
+  *out = g->prof;
+  memset(&g->prof, 0, sizeof g->prof);
   return MOEINF_OK;
 }
 
@@ -706,7 +789,7 @@ extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* exper
     if (!nd.host) return fail(MOEINF_ERR_STATE, "expert (%d,%d) not registered", layer, e);
     // never evict a protected expert or one hotter than nothing: if no slot can be freed, stop quietly
     g->pol[idx].pinned = true;
-    int rc = issue_copy(g, idx, g->prefetch_stream);
+    int rc = issue_copy(g, idx, g->prefetch_stream, false);
     g->pol[idx].pinned = false;
     if (rc == MOEINF_ERR_OOM) break;
     if (rc != MOEINF_OK) return rc;
@@ -908,17 +991,7 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
     const int e = g->h_mirror[1 + E1 + i];
     if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d received rows for expert %d it does not own", g->cfg.ep_rank, e);
   }
-  CHK(ensure_resident(g, layer, st));
-  CHK(flush_pokes(g, st));
-  FfnStage s1, s2;
-  fill_stage(g, layer, 1, s1);
-  s1.in = recv_dev;
-  fill_stage(g, layer, 2, s2);
-  const int na = g->h_mirror[0];
-  if (na > 0) {
-    HIPCHK(launch_ffn_stage(s1, na, st));
-    HIPCHK(launch_ffn_stage(s2, na, st));
-  }
+  CHK(run_experts(g, layer, recv_dev, st, nullptr, nullptr, nullptr));
   HIPCHK(launch_ep_unsort(g->d_y, y_dev, g->d_pair_slot, nrows, g->H, g->dt, st));
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));

@@ -27,7 +27,8 @@ struct FfnStage {
   const uint64_t* wptr;    // [E+1] device base pointer of every expert blob of this layer (0 = absent);
                            // entry E is the shared expert (DeepSeek) or 0
   const int32_t* active;   // [<= E+1] ids of experts with tokens, ascending
-  const int32_t* n_active; // device scalar
+  const int32_t* n_active; // device scalar (used when n_active_host < 0)
+  int n_active_host;       // >= 0: number of entries of `active` to process (chunked dispatch)
   const int32_t* counts;   // [E+1] rows per expert
   const int32_t* offsets;  // [E+2] first expert-sorted row of each expert
   int32_t* miss_flag;      // set to 1 if an active expert has wptr == 0

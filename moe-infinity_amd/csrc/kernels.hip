@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   __shared__ float red[NW][NMAT][256];
 
   const int u = blockIdx.y;
-  if (u >= *s.n_active) return;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
   const int e = s.active[u];
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;

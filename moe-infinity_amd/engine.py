@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Config, MoeInfError, Stats, check, load_library
+from ._lib import Config, MoeInfError, Profile, Stats, check, load_library
 from .config import DTYPE_BF16, DTYPE_F32, EngineConfig
 
 FWD_DEFAULT, FWD_ROUTE_ONLY, FWD_NO_COMBINE = 0, 1, 2
@@ -209,6 +209,15 @@ class MoEEngine:
 
     def reset_stats(self):
         check(self.lib.moeinf_reset_stats(self._h))
+
+    def set_profiling(self, on: bool):
+        check(self.lib.moeinf_set_profiling(self._h, int(bool(on))))
+
+    def profile(self) -> dict:
+        """Accumulated per-kernel event timings + algorithmic bytes since the last call (resets)."""
+        p = Profile()
+        check(self.lib.moeinf_get_profile(self._h, C.byref(p)))
+        return p.as_dict()
 
     # ---- expert parallel ---------------------------------------------------------------------
     def ep_pack(self, x2: torch.Tensor, send: torch.Tensor, meta: torch.Tensor, send_counts: torch.Tensor, cap_rows: int):

@@ -28,10 +28,12 @@ def ulp_tol(ref: torch.Tensor, got: torch.Tensor, dtype) -> torch.Tensor:
     return mag * 2.0 ** -7 + 1e-30
 
 
-def assert_model_close(got, ref, dtype, what):
+def assert_model_close(got, ref, dtype, what, ulps=1.0):
+    """ulps=1 for a single rounded op chain (expert FFN rows, routing weights); block outputs sum K
+    rounded contributions, each of which may carry a 1-ulp flip from accumulation order -> ulps=2."""
     got, ref = got.float().cpu(), ref.float().cpu()
     err = (got - ref).abs()
-    tol = ulp_tol(ref, got, dtype)
+    tol = ulp_tol(ref, got, dtype) * ulps
     bad = err > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} elements beyond 1 ulp, worst {float((err / tol).max()):.2f} ulp"
     # bulk agreement: well inside the north-star's 1e-3

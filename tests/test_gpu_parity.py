@@ -50,8 +50,8 @@ def test_mixtral_golden(name):
     assert_model_close(torch.from_numpy(r["topk_w"]), ref.topk_w, torch.bfloat16, "routing weights")
     rows = oracle_expert_rows(ref, e)
     assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
-    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle")
-    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden")
+    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle", ulps=2.0)
+    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden", ulps=2.0)
     eng.close()
 
 
@@ -82,8 +82,8 @@ def test_deepseek_golden(name):
             assert abs(got[i] - want[i]) <= 2e-6 * max(1.0, abs(want[i])), (t, i, got[i], want[i])
     rows = oracle_expert_rows(ref, e)
     assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
-    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle")
-    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden")
+    assert_model_close(out, ref.out, torch.bfloat16, "block output vs oracle", ulps=2.0)
+    assert_model_close(out, tt(z["out"], torch.float32), torch.bfloat16, "block output vs reference golden", ulps=2.0)
     eng.close()
 
 
@@ -103,8 +103,8 @@ def test_switch_golden(name):
     _check_dispatch_index(r, ref)
     rows = oracle_expert_rows(ref, e)
     assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.float32, "expert FFN outputs")
-    assert_model_close(out, ref.out, torch.float32, "block output vs oracle")
-    assert_model_close(out, tt(z["out"], torch.float32), torch.float32, "block output vs reference golden")
+    assert_model_close(out, ref.out, torch.float32, "block output vs oracle", ulps=2.0)
+    assert_model_close(out, tt(z["out"], torch.float32), torch.float32, "block output vs reference golden", ulps=2.0)
     eng.close()
 
 
@@ -130,8 +130,8 @@ def test_nllb_golden(name, dtype):
     _check_dispatch_index(r, ref)
     rows = oracle_expert_rows(ref, e)
     assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dtype, "expert FFN outputs")
-    assert_model_close(out, ref.out, dtype, "block output vs oracle")
-    assert_model_close(out, tt(z["out"], torch.float32), dtype, "block output vs reference golden")
+    assert_model_close(out, ref.out, dtype, "block output vs oracle", ulps=2.0)
+    assert_model_close(out, tt(z["out"], torch.float32), dtype, "block output vs reference golden", ulps=2.0)
     eng.close()
 
 
@@ -150,7 +150,7 @@ def test_mixtral_shapes(t, h, f, e, k):
     _check_dispatch_index(r, ref)
     rows = oracle_expert_rows(ref, e)
     assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
-    assert_model_close(out, ref.out[0], torch.bfloat16, "block output")
+    assert_model_close(out, ref.out[0], torch.bfloat16, "block output", ulps=2.0)
     eng.close()
 
 
@@ -165,7 +165,7 @@ def test_all_tokens_one_expert_and_empty_experts():
     ref = R.block_mixtral(x[None], gate, experts, top_k=k)
     r = _check_routing_exact(eng, ref)
     assert int((r["counts"] > 0).sum()) == k and int(r["counts"].max()) == t
-    assert_model_close(out, ref.out[0], torch.bfloat16, "block output")
+    assert_model_close(out, ref.out[0], torch.bfloat16, "block output", ulps=2.0)
     eng.close()
 
 
@@ -204,7 +204,7 @@ def test_eviction_keeps_results_exact():
             out = eng.forward(l, x.to(DEV), ws[l][0].to(DEV))
             ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
             _check_routing_exact(eng, ref)
-            assert_model_close(out, ref.out[0], torch.bfloat16, f"step {step} layer {l}")
+            assert_model_close(out, ref.out[0], torch.bfloat16, f"step {step} layer {l}", ulps=2.0)
     st = eng.stats()
     assert st["slots_total"] == 5 and st["slots_used"] <= 5
     assert st["expert_misses"] > 5 and st["evictions"] > 0
@@ -234,7 +234,7 @@ def test_prefetch_makes_hits_and_protect_blocks_eviction():
     out = eng.forward(0, x.to(DEV), gate.to(DEV))
     st = eng.stats()
     assert st["expert_misses"] == 0 and st["expert_hits"] == len(need) and st["prefetch_useful"] == len(need)
-    assert_model_close(out, ref.out[0], torch.bfloat16, "prefetched forward")
+    assert_model_close(out, ref.out[0], torch.bfloat16, "prefetched forward", ulps=2.0)
     # protected experts survive a prefetch storm of everything else
     eng.protect([(0, i) for i in need])
     others = [i for i in range(e) if i not in need]
@@ -262,3 +262,54 @@ def test_error_paths_do_not_abort():
     with pytest.raises(MoeInfError):
         eng.forward(0, torch.zeros(9, 256, dtype=torch.bfloat16, device=DEV), gate)
     eng.close()
+
+
+def test_ep_two_ranks_emulated_on_one_gpu():
+    """Expert-parallel kernels (pack / grouped FFN on received rows / unsort / combine) with
+    ep_size=2: two engines on the same GPU play rank 0 and rank 1, the test performs the two
+    all-to-alls by swapping buffer halves.  Result per rank must equal the oracle block."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd.engine import FWD_ROUTE_ONLY
+
+    h, f, e, k, world = 256, 512, 8, 2, 2
+    ts = [5, 3]  # ragged token counts per rank
+    cap = max(ts) * k
+    gate, experts, _ = make_weights("mixtral", h, f, e, 400, torch.bfloat16)
+    engs = []
+    for r in range(world):
+        eng = MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f,
+                                        top_k=k, router_kind=Cf.ROUTER_MIXTRAL, device_memory_ratio=0.25,
+                                        ep_rank=r, ep_size=world, max_tokens=world * max(ts)))
+        for i in range(e):
+            if i % world == r:
+                eng.register_expert(0, i, experts[i])
+        engs.append(eng)
+    g = gate.to(DEV)
+    xs = [acts(t, h, torch.bfloat16, 410 + r).to(DEV) for r, t in enumerate(ts)]
+    mk = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+    send = [mk(world * cap, h) for _ in range(world)]
+    meta = [mk(world * cap, dt=torch.int32) for _ in range(world)]
+    cnts = [mk(world, dt=torch.int32) for _ in range(world)]
+    for r in range(world):
+        engs[r].forward(0, xs[r], g, flags=FWD_ROUTE_ONLY)
+        engs[r].ep_pack(xs[r], send[r], meta[r], cnts[r], cap)
+    torch.cuda.synchronize()
+    # all_to_all: block d of rank r's send buffer becomes block r of rank d's receive buffer
+    recv = [torch.cat([send[src][dst * cap:(dst + 1) * cap] for src in range(world)]) for dst in range(world)]
+    mrecv = [torch.cat([meta[src][dst * cap:(dst + 1) * cap] for src in range(world)]) for dst in range(world)]
+    ys = [mk(world * cap, h) for _ in range(world)]
+    for r in range(world):
+        owned = mrecv[r][mrecv[r] >= 0]
+        assert bool((owned % world == r).all())
+        engs[r].ep_expert_ffn(0, recv[r].contiguous(), mrecv[r].contiguous(), ys[r], cap)
+    torch.cuda.synchronize()
+    ret = [torch.cat([ys[src][dst * cap:(dst + 1) * cap] for src in range(world)]).contiguous() for dst in range(world)]
+    for r in range(world):
+        out = torch.empty_like(xs[r])
+        engs[r].ep_combine(xs[r], ret[r], out, cap)
+        ref = R.block_mixtral(xs[r].cpu()[None], gate, experts, top_k=k)
+        assert int(cnts[r].sum()) == ts[r] * k
+        assert_model_close(out, ref.out[0], torch.bfloat16, f"EP rank {r} output", ulps=2.0)
+    for eng in engs:
+        eng.close()
