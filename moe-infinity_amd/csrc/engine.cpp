@@ -85,6 +85,33 @@ static BlobLayout make_layout(int expert_type, int64_t H, int64_t F, int64_t es)
   return b;
 }
 
+// Device-side (HBM slot) layout: matrices in MFMA-tile order (kernels.hip), biases raw; 4 KiB aligned.
+struct DevLayout {
+  int n = 0;
+  int64_t off[4] = {0, 0, 0, 0}, size[4] = {0, 0, 0, 0};
+  int R[4] = {0, 0, 0, 0}, K[4] = {0, 0, 0, 0};  // K == 0: not a matrix (bias vector, copied as is)
+  int64_t total = 0;
+};
+static DevLayout make_dev_layout(int expert_type, int64_t H, int64_t F, int dt, int64_t es) {
+  DevLayout d;
+  auto mat = [&](int64_t R, int64_t K) {
+    d.off[d.n] = d.total; d.R[d.n] = (int)R; d.K[d.n] = (int)K; d.size[d.n] = tiled_bytes(R, K, dt);
+    d.total += align_up(d.size[d.n], kAioAlignment); ++d.n;
+  };
+  auto vec = [&](int64_t n) {
+    d.off[d.n] = d.total; d.R[d.n] = (int)n; d.K[d.n] = 0; d.size[d.n] = n * es;
+    d.total += align_up(d.size[d.n], kAioAlignment); ++d.n;
+  };
+  switch (expert_type) {
+    case MOEINF_EXPERT_MIXTRAL: mat(F, H); mat(H, F); mat(F, H); break;
+    case MOEINF_EXPERT_DEEPSEEK: mat(F, H); mat(F, H); mat(H, F); break;
+    case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: mat(F, H); vec(F); mat(H, F); vec(H); break;
+    case MOEINF_EXPERT_SWITCH: mat(F, H); mat(H, F); break;
+    default: break;
+  }
+  return d;
+}
+
 // ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
@@ -108,7 +135,9 @@ struct moeinf_engine {
   moeinf_config cfg;
   int64_t es = 2;  // element size
   int dt = DT_BF16;
-  BlobLayout lay, lay_sh;
+  BlobLayout lay, lay_sh;   // host blob (reference layout)
+  DevLayout dlay, dlay_sh;  // HBM slot (tiled)
+  void *stage_demand = nullptr, *stage_prefetch = nullptr;  // H2D landing buffers, one per copy stream
   int64_t slot_bytes = 0;
   int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
   bool has_shared = false;
@@ -264,6 +293,8 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
                   g->d_mirror, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
+  if (g->stage_demand) hipFree(g->stage_demand);
+  if (g->stage_prefetch) hipFree(g->stage_prefetch);
   if (g->h_mirror) hipHostFree(g->h_mirror);
   if (g->h_miss) hipHostFree(g->h_miss);
   if (g->route_ev) hipEventDestroy(g->route_ev);
@@ -293,7 +324,9 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   g->es = g->dt == DT_BF16 ? 2 : 4;
   g->lay = make_layout(cfg->expert_type, g->H, g->F, g->es);
   if (g->has_shared) g->lay_sh = make_layout(cfg->expert_type, g->H, g->Fs, g->es);
-  g->slot_bytes = g->lay.total;
+  g->dlay = make_dev_layout(cfg->expert_type, g->H, g->F, g->dt, g->es);
+  if (g->has_shared) g->dlay_sh = make_dev_layout(cfg->expert_type, g->H, g->Fs, g->dt, g->es);
+  g->slot_bytes = g->dlay.total;
   g->nodes.resize((size_t)g->L * g->E);
   g->pol.resize((size_t)g->L * g->E);
   g->shared_dev.assign(g->L, nullptr);
@@ -335,6 +368,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
   TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
+  TRYHIP(hipMalloc(&g->stage_demand, (size_t)std::max(g->lay.total, g->lay_sh.total)));
+  TRYHIP(hipMalloc(&g->stage_prefetch, (size_t)g->lay.total));
   TRYHIP(hipHostMalloc((void**)&g->h_mirror, (1 + 2 * E1) * sizeof(int32_t), hipHostMallocDefault));
   TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
   *out = g;
@@ -342,6 +377,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
 #undef TRY
 #undef TRYHIP
 }
+
+static int retile_blob(const moeinf_engine* g, const BlobLayout& lay, const DevLayout& dl, const void* staged, void* slot, hipStream_t cs);
 
 // ---- registration --------------------------------------------------------------------------
 extern "C" int moeinf_expert_layout(const moeinf_engine* g, int which, int64_t offsets[4], int64_t sizes[4], int32_t* n_tensors, int64_t* total_bytes) {
@@ -386,8 +423,11 @@ extern "C" int moeinf_register_shared(moeinf_engine* g, int layer, const void* b
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   if (!blob || nbytes != g->lay_sh.total) return fail(MOEINF_ERR_INVALID, "shared blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay_sh.total);
   HIPCHK(hipSetDevice(g->cfg.device_id));
-  if (!g->shared_dev[layer]) HIPCHK(hipMalloc(&g->shared_dev[layer], (size_t)nbytes));
-  HIPCHK(hipMemcpy(g->shared_dev[layer], blob, (size_t)nbytes, hipMemcpyHostToDevice));
+  if (!g->shared_dev[layer]) HIPCHK(hipMalloc(&g->shared_dev[layer], (size_t)g->dlay_sh.total));
+  HIPCHK(hipStreamSynchronize(g->demand_stream));
+  HIPCHK(hipMemcpyAsync(g->stage_demand, blob, (size_t)nbytes, hipMemcpyHostToDevice, g->demand_stream));
+  CHK(retile_blob(g, g->lay_sh, g->dlay_sh, g->stage_demand, g->shared_dev[layer], g->demand_stream));
+  HIPCHK(hipStreamSynchronize(g->demand_stream));
   uint64_t p = (uint64_t)g->shared_dev[layer];
   HIPCHK(hipMemcpy(g->d_wptr + (size_t)layer * (g->E + 1) + g->E, &p, sizeof p, hipMemcpyHostToDevice));
   return MOEINF_OK;
@@ -454,6 +494,17 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   return MOEINF_OK;
 }
 
+// staged row-major blob (device) -> tiled slot, on stream cs
+static int retile_blob(const moeinf_engine* g, const BlobLayout& lay, const DevLayout& dl, const void* staged, void* slot, hipStream_t cs) {
+  for (int i = 0; i < dl.n; ++i) {
+    const char* src = (const char*)staged + lay.off[i];
+    char* dst = (char*)slot + dl.off[i];
+    if (dl.K[i] > 0) HIPCHK(launch_retile(src, dst, dl.R[i], dl.K[i], g->dt, cs));
+    else HIPCHK(hipMemcpyAsync(dst, src, (size_t)dl.size[i], hipMemcpyDeviceToDevice, cs));
+  }
+  return MOEINF_OK;
+}
+
 // start the H2D copy of node idx into a slot on `cs`
 static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs, bool allow_protected) {
   Node& n = g->nodes[idx];
@@ -474,7 +525,9 @@ static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs, bool allow_prot
   hipEvent_t start = get_event(g), stop = get_event(g);
   if (!n.ready) HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
   if (start && stop) HIPCHK(hipEventRecord(start, cs));
-  HIPCHK(hipMemcpyAsync(s.dev, n.host, (size_t)g->lay.total, hipMemcpyHostToDevice, cs));
+  void* staged = (cs == g->demand_stream) ? g->stage_demand : g->stage_prefetch;
+  HIPCHK(hipMemcpyAsync(staged, n.host, (size_t)g->lay.total, hipMemcpyHostToDevice, cs));
+  CHK(retile_blob(g, g->lay, g->dlay, staged, s.dev, cs));
   if (start && stop) {
     HIPCHK(hipEventRecord(stop, cs));
     g->copy_timers.push_back({start, stop});
@@ -510,8 +563,8 @@ static void settle_copy_timers(moeinf_engine* g, bool wait) {
 
 // ---- the hot path --------------------------------------------------------------------------
 static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s) {
-  const BlobLayout& b = g->lay;
-  const BlobLayout& bs = g->lay_sh;
+  const DevLayout& b = g->dlay;
+  const DevLayout& bs = g->dlay_sh;
   memset(&s, 0, sizeof s);
   s.wptr = g->d_wptr + (size_t)layer * (g->E + 1);
   s.active = g->d_active; s.n_active = g->d_n_active; s.counts = g->d_counts; s.offsets = g->d_offsets;

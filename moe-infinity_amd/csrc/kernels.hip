@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace moeinf {
 
@@ -57,16 +58,47 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// ffn_rows: grouped expert FFN, one stage.  grid = (ceil(Rmax/16), max_active), block = NW waves.
+// Weight layout in an HBM slot ("tiled"): every [R,K] matrix is stored as MFMA A-operand tiles.
+// Tile (rg, kb) covers rows [16rg,16rg+16) x 64 bytes of k (32 bf16 / 16 fp32) and occupies 1 KiB
+// laid out in LANE ORDER: bytes [16*lane, 16*lane+16) = W[16rg + (lane&15)][kb*EPT + (lane>>4)*EPV ...].
+// Tiles of one row group are consecutive (kb fastest), so a wave that streams a row group issues
+// plain contiguous 1-KiB loads — the access pattern that measured 6.8-7.2 TB/s on this chip
+// (tools/stream_patterns.hip, pattern E) against 6.0-6.1 TB/s for 16 strided 64-byte row segments.
+// The host arena keeps the reference's row-major blob; retile_kernel converts after each H2D copy.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void retile_kernel(const T* __restrict__ src, char* __restrict__ dst, int R, int K) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int EPT = 4 * EPV;  // k elements per tile
+  const int KB = (K + EPT - 1) / EPT;
+  const int lane = threadIdx.x & 63;
+  const int kb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rg = blockIdx.y;
+  if (kb >= KB) return;
+  const int row = rg * 16 + (lane & 15);
+  const int k = kb * EPT + (lane >> 4) * EPV;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < R && k < K) v = ld16(src + (size_t)row * K + k);  // K % EPV == 0
+  *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = v;
+}
+hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st) {
+  const int ept = dtype == DT_BF16 ? 32 : 16;
+  dim3 grid(((K + ept - 1) / ept + 3) / 4, (R + 15) / 16);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(retile_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, (char*)dst, R, K);
+  else hipLaunchKernelGGL(retile_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (char*)dst, R, K);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ffn_rows: grouped expert FFN, one stage.  grid = (ceil(Rmax/16), n_active), block = NW waves.
 //
 // Block (rg, u) owns 16 consecutive output rows [16*rg, 16*rg+16) of expert active[u] (for the
 // gated stage: the same 16 rows of BOTH the gate and the up matrix).  The reduction dimension is
-// split over the block's NW waves in interleaved 128-byte windows, so the 4/8 waves of a block
-// read 512/1024 contiguous bytes of every weight row per step: each weight byte is read exactly
-// once from HBM, straight into VGPRs (no LDS round trip: the stream is not shared between waves).
-// MFMA operands: A = weights (lane: row r = lane&15, quad q = lane>>4), B = activations of up to
-// 16 tokens (lane: token n = lane&15, quad q).  A lane's two 16-byte loads cover 32 contiguous
-// bytes of its row; any k <-> MFMA-slot assignment is legal as long as A and B agree.
+// split over the block's NW waves, which take interleaved k-tiles: every weight byte is read exactly
+// once from HBM, contiguous 1 KiB per wave-instruction, non-temporal, straight into VGPRs (no LDS
+// round trip: the stream is not shared between waves).
+// MFMA operands: A = one weight tile (lane: row r = lane&15, quad q = lane>>4), B = activations of
+// up to 16 tokens (lane: token n = lane&15, quad q, same k elements as A's quad).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
@@ -81,11 +113,10 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
 }
 
-template <typename T, int NMAT, int NW>
+template <typename T, int NMAT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   constexpr int EPV = DT<T>::EPV;
-  constexpr int WE = 128 / (int)sizeof(T);  // elements per 128-byte window
-  constexpr int U = 4;                      // windows in flight per wave
+  constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
   __shared__ float red[NW][NMAT][256];
 
   const int u = blockIdx.y;
@@ -106,64 +137,44 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row = min(r0 + r, R - 1);
-  const T* a0 = reinterpret_cast<const T*>(W + (sh ? s.off_a_sh : s.off_a)) + (size_t)row * K;
-  const T* a1 = NMAT == 2 ? reinterpret_cast<const T*>(W + (sh ? s.off_b_sh : s.off_b)) + (size_t)row * K : nullptr;
-  const int nfull = K / WE;
-  const int kq = q * 2 * EPV;  // this lane's element offset inside a window
+  const int n = lane & 15, q = lane >> 4;
+  const int KB = (K + EPT - 1) / EPT;  // tiles per row group (last one zero-padded)
+  const int KBfull = K / EPT;
+  const char* a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)blockIdx.x * KB * 1024 + lane * 16;
+  const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)blockIdx.x * KB * 1024 + lane * 16 : nullptr;
+  const int kq = q * EPV;  // this lane's k offset inside a tile
 
   for (int tile = 0; tile * 16 < cnt; ++tile) {
-    const int srow = off + min(tile * 16 + r, cnt - 1);  // r doubles as the token column n
+    const int srow = off + min(tile * 16 + n, cnt - 1);
     const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-    const T* xr = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in;
+    const T* xr = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    int w = wave;
-    for (; w + (U - 1) * NW < nfull; w += U * NW) {
-      u32x4 av[U][2], bv[U][2], xv[U][2];
+    int kb = wave;
+    for (; kb + (U - 1) * NW < KBfull; kb += U * NW) {
+      u32x4 av[U], bv[U], xv[U];
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        const size_t k = (size_t)(w + i * NW) * WE + kq;
-        av[i][0] = ld16_nt(a0 + k);
-        av[i][1] = ld16_nt(a0 + k + EPV);
-        if (NMAT == 2) {
-          bv[i][0] = ld16_nt(a1 + k);
-          bv[i][1] = ld16_nt(a1 + k + EPV);
-        }
-        xv[i][0] = ld16(xr + k);
-        xv[i][1] = ld16(xr + k + EPV);
+        av[i] = ld16_nt(a0 + (size_t)(kb + i * NW) * 1024);
+        if (NMAT == 2) bv[i] = ld16_nt(a1 + (size_t)(kb + i * NW) * 1024);
+        xv[i] = ld16(xr + (size_t)(kb + i * NW) * EPT);
       }
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        mma16<T>(acc0, av[i][0], xv[i][0]);
-        mma16<T>(acc0, av[i][1], xv[i][1]);
-        if (NMAT == 2) {
-          mma16<T>(acc1, bv[i][0], xv[i][0]);
-          mma16<T>(acc1, bv[i][1], xv[i][1]);
-        }
+        mma16<T>(acc0, av[i], xv[i]);
+        if (NMAT == 2) mma16<T>(acc1, bv[i], xv[i]);
       }
     }
-    for (; w < nfull; w += NW) {
-      const size_t k = (size_t)w * WE + kq;
-      u32x4 x0 = ld16(xr + k), x1 = ld16(xr + k + EPV);
-      mma16<T>(acc0, ld16_nt(a0 + k), x0);
-      mma16<T>(acc0, ld16_nt(a0 + k + EPV), x1);
-      if (NMAT == 2) {
-        mma16<T>(acc1, ld16_nt(a1 + k), x0);
-        mma16<T>(acc1, ld16_nt(a1 + k + EPV), x1);
-      }
+    for (; kb < KBfull; kb += NW) {
+      const u32x4 x0 = ld16(xr + (size_t)kb * EPT);
+      mma16<T>(acc0, ld16_nt(a0 + (size_t)kb * 1024), x0);
+      if (NMAT == 2) mma16<T>(acc1, ld16_nt(a1 + (size_t)kb * 1024), x0);
     }
-    if ((K % WE) != 0 && wave == (nfull % NW)) {  // partial last window (K % EPV == 0 required)
+    if (KB != KBfull && wave == (KBfull % NW)) {  // zero-padded last tile: guard only the activation read
       const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf) {
-        const size_t k = (size_t)nfull * WE + kq + hlf * EPV;
-        const bool ok = (int)k + EPV <= K;
-        u32x4 xx = ok ? ld16(xr + k) : z;
-        mma16<T>(acc0, ok ? ld16_nt(a0 + k) : z, xx);
-        if (NMAT == 2) mma16<T>(acc1, ok ? ld16_nt(a1 + k) : z, xx);
-      }
+      const u32x4 x0 = (KBfull * EPT + kq < K) ? ld16(xr + (size_t)KBfull * EPT) : z;
+      mma16<T>(acc0, ld16_nt(a0 + (size_t)KBfull * 1024), x0);
+      if (NMAT == 2) mma16<T>(acc1, ld16_nt(a1 + (size_t)KBfull * 1024), x0);
     }
     // cross-wave reduction of the K split
 #pragma unroll
@@ -180,9 +191,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
         if (NMAT == 2) s1 += red[ww][1][i];
       }
       const int l = i >> 2, j = i & 3;
-      const int n = l & 15;                 // token column
+      const int tn = l & 15;                    // token column
       const int orow = r0 + (l >> 4) * 4 + j;  // output row
-      if (tile * 16 + n < cnt && orow < R) {
+      if (tile * 16 + tn < cnt && orow < R) {
         float v = DT<T>::round(s0);
         if (s.epi == EPI_GATED_SILU) {
           const float b = DT<T>::round(s1);
@@ -193,30 +204,42 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
             v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
           if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         }
-        DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + n) * s.ld_out + orow, v);
+        DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
       }
     }
     __syncthreads();
   }
 }
 
+// tuning knobs (overridable for sweeps: MOEINF_FFN_NW=4|8, MOEINF_FFN_U=2|4|8)
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+template <typename T, int NMAT>
+static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, hipStream_t st) {
+#define LAUNCH(NWV, UU) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU>), grid, dim3(NWV * 64), 0, st, s)
+  if (nw == 8) { if (u == 2) LAUNCH(8, 2); else if (u == 8) LAUNCH(8, 8); else LAUNCH(8, 4); }
+  else         { if (u == 2) LAUNCH(4, 2); else if (u == 8) LAUNCH(4, 8); else LAUNCH(4, 4); }
+#undef LAUNCH
+}
+
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st) {
+  static const int env_nw = env_int("MOEINF_FFN_NW", 0), env_u = env_int("MOEINF_FFN_U", 0);
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   dim3 grid((rmax + 15) / 16, max_active);
   const bool gated = (s.epi == EPI_GATED_SILU);
   // long reductions get 8 waves per block (more bytes in flight per CU), short ones 4
   const int kmax = s.K > s.K_sh ? s.K : s.K_sh;
   const size_t kbytes = (size_t)kmax * (s.dtype == DT_BF16 ? 2 : 4);
-  const bool wide = kbytes >= 16384;
-#define LAUNCH(TT, NM, NWV) hipLaunchKernelGGL((ffn_rows_kernel<TT, NM, NWV>), grid, dim3(NWV * 64), 0, st, s)
+  const int nw = env_nw ? env_nw : (kbytes >= 16384 ? 8 : 4);
+  const int u = env_u ? env_u : 4;
   if (s.dtype == DT_BF16) {
-    if (gated) { if (wide) LAUNCH(uint16_t, 2, 8); else LAUNCH(uint16_t, 2, 4); }
-    else       { if (wide) LAUNCH(uint16_t, 1, 8); else LAUNCH(uint16_t, 1, 4); }
+    if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, st);
   } else {
-    if (gated) { if (wide) LAUNCH(float, 2, 8); else LAUNCH(float, 2, 4); }
-    else       { if (wide) LAUNCH(float, 1, 8); else LAUNCH(float, 1, 4); }
+    if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, st); else launch_ffn_t<float, 1>(s, grid, nw, u, st);
   }
-#undef LAUNCH
   return hipGetLastError();
 }
 
