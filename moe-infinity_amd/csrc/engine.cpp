@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -177,6 +178,14 @@ struct moeinf_engine {
   int32_t* h_mirror = nullptr;  // pinned: {n_active, counts[E+1], active[E+1]}
   int32_t* h_miss = nullptr;
   std::vector<PokeArgs> pending_pokes;
+  // sync-free forwards: their routing mirrors are copied to pinned buffers and applied to the
+  // counters/statistics lazily (no residency decision depends on them while every expert of the
+  // layer is resident)
+  struct PendingMirror { hipEvent_t ev; int32_t* buf; int layer; int T; bool prof; };
+  std::deque<PendingMirror> pend;
+  std::vector<int32_t*> mirror_pool;
+  std::vector<hipEvent_t> mirror_events;
+  int owned_experts = 0;
 
   // EP workspace (lazily allocated)
   int32_t *d_ep_key = nullptr, *d_ep_counts = nullptr, *d_ep_offsets = nullptr, *d_ep_active = nullptr,
@@ -293,6 +302,9 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
                   g->d_mirror, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
+  for (auto& pm : g->pend) { hipHostFree(pm.buf); hipEventDestroy(pm.ev); }
+  for (auto b : g->mirror_pool) hipHostFree(b);
+  for (auto e : g->mirror_events) hipEventDestroy(e);
   if (g->stage_demand) hipFree(g->stage_demand);
   if (g->stage_prefetch) hipFree(g->stage_prefetch);
   if (g->h_mirror) hipHostFree(g->h_mirror);
@@ -342,6 +354,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   const int64_t budget = cfg->device_memory_bytes > 0 ? cfg->device_memory_bytes : (int64_t)((double)total_b * cfg->device_memory_ratio);
   int64_t owned = 0;
   for (int e = 0; e < g->E; ++e) if (owns(g, e)) ++owned;
+  g->owned_experts = (int)owned;
   g->max_slots = std::min<int64_t>(budget / g->slot_bytes, owned * g->L);
   if (g->max_slots < 1) { fail(MOEINF_ERR_OOM, "device budget %lld bytes cannot hold one expert of %lld bytes", (long long)budget, (long long)g->slot_bytes); return bail(MOEINF_ERR_OOM); }
   g->st.slots_total = g->max_slots;
@@ -590,6 +603,54 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   }
 }
 
+// algorithmic bytes of one forward (profiling), from its routing mirror
+static void account_profile(moeinf_engine* g, const int32_t* mirror, int T) {
+  const int E = g->E, K = g->K;
+  int64_t U = 0, rows = 0;
+  for (int e = 0; e < E; ++e) { if (mirror[1 + e] > 0) { ++U; rows += mirror[1 + e]; } }
+  const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = g->has_shared ? T : 0;
+  const int et = g->cfg.expert_type;
+  const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
+  const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
+  g->prof.ffn1_bytes += U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
+  g->prof.ffn2_bytes += U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
+  g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
+  g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
+  g->prof.forwards += 1;
+  if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
+}
+
+// apply the routing mirrors of finished sync-free forwards to counters / stats (all were hits)
+static void drain_mirrors(moeinf_engine* g, bool block) {
+  while (!g->pend.empty()) {
+    auto& pm = g->pend.front();
+    if (block) {
+      hipEventSynchronize(pm.ev);
+    } else if (hipEventQuery(pm.ev) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+    const int E1 = g->E + 1;
+    const int na = pm.buf[0];
+    const int32_t* active = pm.buf + 1 + E1;
+    for (int i = 0; i < na; ++i) {
+      const int e = active[i];
+      if (e >= g->E) continue;
+      const int idx = node_index(g, pm.layer, e);
+      Node& n = g->nodes[idx];
+      n.visit += 1; n.hit += 1;
+      g->st.expert_hits += 1;
+      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; }
+      g->pol[idx].incache += 1;
+      g->pol[idx].last_access = ++g->clock;
+    }
+    if (pm.prof) account_profile(g, pm.buf, pm.T);
+    g->mirror_pool.push_back(pm.buf);
+    g->mirror_events.push_back(pm.ev);
+    g->pend.pop_front();
+  }
+}
+
 // make every active routed expert of `layer` resident and order the compute stream after its copy.
 // h_mirror = {n_active, counts[E+1], active[E+1]} (already on the host).
 static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 = 0, int a1 = -1) {
@@ -696,7 +757,6 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool prof = g->profiling && !route_only;
   if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
   HIPCHK(launch_gate_logits(ra, st));
-  HIPCHK(launch_route_topk(ra, st));
 
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
@@ -706,50 +766,69 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   ia.shared = g->has_shared ? 1 : 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
-  HIPCHK(launch_dispatch_index(ia, st));
+  if (T <= 64) {
+    HIPCHK(launch_route_index(ra, ia, st));  // decode: top-k + dispatch index in one launch
+  } else {
+    HIPCHK(launch_route_topk(ra, st));
+    HIPCHK(launch_dispatch_index(ia, st));
+  }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
   if (route_only) return MOEINF_OK;
-
-  // Residency.  The host needs the active-expert list to decide fetches/evictions (the reference does
-  // the same D2H every layer, expert_executor.py:34-43); one small pinned copy + event.
   if (prof) HIPCHK(hipEventRecord(pr.ev[1], st));
-  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(g->route_ev, st));
-  const auto tw0 = std::chrono::steady_clock::now();
-  HIPCHK(hipEventSynchronize(g->route_ev));
-  if (g->profiling) g->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-  const int na = g->h_mirror[0];
-  if (prof) {
-    // algorithmic bytes of this forward
-    int64_t U = 0, rows = 0;
-    for (int e = 0; e < E; ++e) { if (g->h_mirror[1 + e] > 0) { ++U; rows += g->h_mirror[1 + e]; } }
-    const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = g->has_shared ? T : 0;
-    const int et = g->cfg.expert_type;
-    const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
-    const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
-    g->prof.ffn1_bytes += U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
-    g->prof.ffn2_bytes += U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
-    g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
-    g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
-    g->prof.forwards += 1;
-    if (na > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
+
+  const size_t mirror_bytes = (size_t)(1 + 2 * E1) * sizeof(int32_t);
+  // Sync-free path: every owned expert of this layer is resident and already ordered before the
+  // compute stream, so whatever the router picks is a hit — no host decision is needed and the host
+  // does not wait for the routing result (the reference blocks on a D2H sum every layer,
+  // expert_executor.py:34-43).  The mirror is applied to the counters lazily.
+  const bool fast = g->resident_per_layer[layer] == g->owned_experts && g->cfg.ep_size == 1;
+  if (fast) {
+    drain_mirrors(g, g->pend.size() > 256);
+    moeinf_engine::PendingMirror pm;
+    if (!g->mirror_pool.empty()) { pm.buf = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
+    else HIPCHK(hipHostMalloc((void**)&pm.buf, mirror_bytes, hipHostMallocDefault));
+    if (!g->mirror_events.empty()) { pm.ev = g->mirror_events.back(); g->mirror_events.pop_back(); }
+    else HIPCHK(hipEventCreateWithFlags(&pm.ev, hipEventDisableTiming));
+    pm.layer = layer; pm.T = T; pm.prof = prof;
+    HIPCHK(hipMemcpyAsync(pm.buf, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(pm.ev, st));
+    g->pend.push_back(pm);
+    for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
+      const Node& n = g->nodes[node_index(g, layer, e)];
+      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
+    }
+    CHK(flush_pokes(g, st));
+    FfnStage s1, s2;
+    fill_stage(g, layer, 1, s1);
+    s1.in = x_dev;
+    fill_stage(g, layer, 2, s2);
+    const int max_active = std::min(E, T * K) + (g->has_shared ? 1 : 0);
+    if (prof) HIPCHK(hipEventRecord(pr.ev[2], st));
+    HIPCHK(launch_ffn_stage(s1, max_active, st));
+    if (prof) HIPCHK(hipEventRecord(pr.ev[3], st));
+    HIPCHK(launch_ffn_stage(s2, max_active, st));
+    if (prof) HIPCHK(hipEventRecord(pr.ev[4], st));
+  } else {
+    // Residency decisions need the active-expert list on the host: one small pinned copy + event.
+    drain_mirrors(g, true);
+    HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(g->route_ev, st));
+    const auto tw0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(g->route_ev));
+    if (g->profiling) g->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+    if (prof) account_profile(g, g->h_mirror, T);
+    CHK(run_experts(g, layer, x_dev, st, prof ? pr.ev[2] : nullptr, prof ? pr.ev[3] : nullptr, prof ? pr.ev[4] : nullptr));
   }
-  CHK(run_experts(g, layer, x_dev, st, prof ? pr.ev[2] : nullptr, prof ? pr.ev[3] : nullptr, prof ? pr.ev[4] : nullptr));
   if (!(flags & MOEINF_FWD_NO_COMBINE)) {
     CombineArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
     ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
     ca.router_prob = g->d_router_prob;
-    ca.shared_row0 = -1;
+    ca.shared_offsets = g->has_shared ? g->d_offsets : nullptr;  // shared rows start at offsets[E]
+    ca.shared_E = E;
     ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
-    if (g->has_shared) {
-      // first row of the shared expert = offsets[E] = number of routed rows
-      int routed = 0;
-      for (int e = 0; e < E; ++e) routed += g->h_mirror[1 + e];
-      ca.shared_row0 = routed;
-    }
     HIPCHK(launch_combine(ca, st));
   }
   if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
@@ -769,6 +848,7 @@ extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   if (g->last_stream || g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
+  drain_mirrors(g, true);
   for (auto& r : g->prof_pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) g->prof.route_ms += ms;
@@ -828,6 +908,7 @@ extern "C" int moeinf_get_logits(moeinf_engine* g, float* host_out, int64_t n_fl
 // ---- prefetch / cache control ----------------------------------------------------------------
 extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* experts, const float* scores, int n) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  drain_mirrors(g, true);
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   if (n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "experts is NULL");
   (void)scores;  // the caller passes experts in priority order; scores are kept for tracing only
@@ -864,6 +945,7 @@ extern "C" int moeinf_protect(moeinf_engine* g, const int32_t* layers, const int
 
 extern "C" int moeinf_clear_cache_counts(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  drain_mirrors(g, true);
   for (auto& p : g->pol) p.incache = 0;
   return MOEINF_OK;
 }
@@ -886,6 +968,7 @@ extern "C" int moeinf_sync_copies(moeinf_engine* g) {
 
 extern "C" int moeinf_get_expert_counters(moeinf_engine* g, int64_t* out, int64_t n_int64) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  drain_mirrors(g, true);
   if (n_int64 != (int64_t)g->L * g->E * 6) return fail(MOEINF_ERR_INVALID, "n_int64 must be L*E*6");
   for (int l = 0; l < g->L; ++l)
     for (int e = 0; e < g->E; ++e) {
@@ -899,6 +982,7 @@ extern "C" int moeinf_get_expert_counters(moeinf_engine* g, int64_t* out, int64_
 
 extern "C" int moeinf_get_stats(moeinf_engine* g, moeinf_stats* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  drain_mirrors(g, true);
   settle_copy_timers(g, false);
   *out = g->st;
   return MOEINF_OK;
@@ -906,6 +990,7 @@ extern "C" int moeinf_get_stats(moeinf_engine* g, moeinf_stats* out) {
 
 extern "C" int moeinf_reset_stats(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  drain_mirrors(g, true);
   settle_copy_timers(g, false);
   const int64_t st = g->st.slots_total, su = g->st.slots_used, sb = g->st.slot_bytes, ha = g->st.host_arena_bytes;
   memset(&g->st, 0, sizeof g->st);
@@ -1060,7 +1145,7 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
   memset(&ca, 0, sizeof ca);
   ca.x = x_dev; ca.y = ret_dev; ca.out = out_dev;
   ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
-  ca.router_prob = g->d_router_prob; ca.shared_row0 = -1;
+  ca.router_prob = g->d_router_prob; ca.shared_offsets = nullptr; ca.shared_E = g->E;
   ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
   HIPCHK(launch_combine(ca, (hipStream_t)stream));
   return MOEINF_OK;

@@ -81,6 +81,8 @@ struct IndexArgs {
   int32_t* mirror;          // device staging of {n_active, counts[E+1], active[E+1]} for one D2H copy
 };
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
+// fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
+hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
 
 struct CombineArgs {
   const void* x;            // [T,H] (Switch/NLLB passthrough)
@@ -91,7 +93,8 @@ struct CombineArgs {
   const int32_t* pair_slot; // [T,K]
   const int32_t* pair_order;// [T,K]
   const float* router_prob; // [T] Switch
-  int shared_row0;          // first row of the shared expert's outputs in y, -1: none
+  const int32_t* shared_offsets;  // non-null: shared expert rows start at y[shared_offsets[shared_E]] (device)
+  int shared_E;
   int T, H, K;
   int kind;                 // MOEINF_ROUTER_* (selects the reference block's combine semantics)
   int dtype;

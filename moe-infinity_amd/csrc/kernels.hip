@@ -335,10 +335,7 @@ __device__ __forceinline__ void pick_best(const float key[4], uint32_t taken, in
   wave_argmax(bv, bi);
 }
 
-__global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= a.T) return;
+__device__ __forceinline__ void route_token(const RouteArgs& a, const int t, const int lane) {
   const int E = a.E, K = a.K;
   const float* lg = a.logits + (size_t)t * E;
   float l[4], p[4];
@@ -487,6 +484,11 @@ __global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t < a.T) route_token(a, t, threadIdx.x & 63);
+}
+
 hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(route_topk_kernel, dim3((a.T + 3) / 4), dim3(256), 0, st, a);
   return hipGetLastError();
@@ -539,11 +541,7 @@ __device__ __forceinline__ int chunk_rank(int key, bool counted, int* wave_cnt /
   return pos;
 }
 
-__global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a) {
-  __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
-  __shared__ int running[IDX_MAXE];
-  __shared__ int offs[IDX_MAXE + 1];
-  __shared__ int scan_tmp[IDX_MAXE];
+__device__ __forceinline__ void index_body(const IndexArgs& a, int* wave_cnt, int* running, int* offs, int* scan_tmp) {
   const int tid = threadIdx.x;
   const int E = a.E, K = a.K, T = a.T;
   const int nkeys = E;
@@ -626,8 +624,34 @@ __global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a
   }
 }
 
+__global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a) {
+  __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
+  __shared__ int running[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  __shared__ int scan_tmp[IDX_MAXE];
+  index_body(a, wave_cnt, running, offs, scan_tmp);
+}
+
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(dispatch_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
+// decode-sized batches: softmax/top-k of every token (one wave each) and the dispatch index in ONE
+// launch of one workgroup — saves a kernel boundary per layer where launches dominate the layer time
+__global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, IndexArgs a) {
+  __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
+  __shared__ int running[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  __shared__ int scan_tmp[IDX_MAXE];
+  for (int t = threadIdx.x >> 6; t < r.T; t += IDX_WAVES) route_token(r, t, threadIdx.x & 63);
+  __threadfence_block();
+  __syncthreads();
+  index_body(a, wave_cnt, running, offs, scan_tmp);
+}
+
+hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(route_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, r, a);
   return hipGetLastError();
 }
 
@@ -667,8 +691,8 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
       acc[j] = DT<T>::round(acc[j] + prod);
     }
   }
-  if (a.kind == 1 && a.shared_row0 >= 0) {
-    const T* sr = y + (size_t)(a.shared_row0 + t) * a.H + h0;
+  if (a.kind == 1 && a.shared_offsets) {
+    const T* sr = y + (size_t)(a.shared_offsets[a.shared_E] + t) * a.H + h0;
     for (int j = 0; j < nh; ++j) acc[j] = DT<T>::round(acc[j] + DT<T>::load(sr + j));
   }
   if (a.kind == 3 /*NLLB: next_states[next_states == 0] = hidden_states[...] */) {
