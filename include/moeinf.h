@@ -163,6 +163,23 @@ int moeinf_register_shared(moeinf_engine* eng, int layer, const void* blob, int6
 int moeinf_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tokens, int batch_rows,
                        const void* gate_w_dev, void* out_dev, void* stream, uint32_t flags);
 
+/* expert_dispatcher.set_inputs + enqueue_expert(...) for every active expert + wait_expert
+ * (core/parallel/expert_dispatcher.cpp:111-158,436-450; driven by dispatch_local,
+ * moe_infinity/distributed/expert_executor.py:32-58) for callers that keep the reference's PYTHON
+ * router and combine: router_mask_dev is the dense [tokens, E] mask (mask_elem_bytes = 1 for
+ * bool/uint8, 4 for int32, 8 for int64; non-zero = token routed to expert).  Runs residency + the
+ * grouped expert FFN; y_dev receives the expert outputs as expert-sorted rows (expert ascending,
+ * tokens ascending inside an expert), i.e. the concatenation of wait_expert()'s tensors.
+ * Host outputs (any may be NULL): counts_host[E] tokens per expert, hit_host[E] = 1 if the expert was
+ * already resident when dispatched (wait_expert's 4th tuple field), 0 if fetched on demand, -1 if idle. */
+int moeinf_dispatch_mask(moeinf_engine* eng, int layer, const void* x_dev, int tokens, const void* router_mask_dev,
+                         int mask_elem_bytes, void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream);
+
+/* Device-side copies of the LAST forward's router results into caller tensors (async on `stream`;
+ * any pointer may be NULL): logits [tokens,E] f32, topk_idx [tokens,K] i32, topk_w [tokens,K] f32.
+ * These are the tensors the reference's blocks return to HF (e.g. router_logits, mixtral.py:118). */
+int moeinf_copy_routing_dev(moeinf_engine* eng, float* logits_dev, int32_t* topk_idx_dev, float* topk_w_dev, void* stream);
+
 /* Decomposed results of the LAST forward, copied to host (synchronises `stream`).
  * Any output pointer may be NULL.  Replaces the values the reference's blocks hold in Python
  * locals: selected_experts/routing_weights (mixtral.py:48-54), topk_idx/topk_weight

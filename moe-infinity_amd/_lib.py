@@ -72,6 +72,8 @@ PROTOTYPES = {
     "moeinf_expert_host_ptr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "moeinf_register_shared": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "moeinf_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_uint32]),
+    "moeinf_dispatch_mask": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _I32P, _I32P, _P]),
+    "moeinf_copy_routing_dev": (C.c_int, [_P, _P, _P, _P, _P]),
     "moeinf_get_routing": (C.c_int, [_P, _I32P, _F32P, _I32P, _I32P, _I32P, _I32P]),
     "moeinf_get_expert_outputs": (C.c_int, [_P, _P, C.c_int64]),
     "moeinf_get_logits": (C.c_int, [_P, _F32P, C.c_int64]),

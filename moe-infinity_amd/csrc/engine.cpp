@@ -838,6 +838,56 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   return MOEINF_OK;
 }
 
+extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_dev, int tokens, const void* mask_dev, int mask_elem_bytes,
+                                    void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
+  if (!x_dev || !mask_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "x_dev/router_mask_dev/y_dev is NULL");
+  if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail(MOEINF_ERR_INVALID, "mask_elem_bytes must be 1, 4 or 8");
+  // a token may be routed to up to E experts in a mask; the workspace holds max_tokens*K rows
+  if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = g->E, E1 = E + 1;
+  drain_mirrors(g, true);
+  IndexArgs ia;
+  memset(&ia, 0, sizeof ia);
+  ia.T = tokens; ia.K = 1; ia.E = E;
+  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  HIPCHK(launch_mask_index(mask_dev, mask_elem_bytes, tokens, E, ia, st));
+  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(g->route_ev, st));
+  HIPCHK(hipEventSynchronize(g->route_ev));
+  int64_t rows = 0;
+  for (int e = 0; e < E; ++e) rows += g->h_mirror[1 + e];
+  if (rows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "mask routes %lld rows but the workspace holds max_tokens*K = %lld", (long long)rows, (long long)g->cfg.max_tokens * g->K);
+  if (hit_host) {
+    for (int e = 0; e < E; ++e) hit_host[e] = g->h_mirror[1 + e] > 0 ? (g->nodes[node_index(g, layer, e)].slot >= 0 ? 1 : 0) : -1;
+  }
+  if (counts_host) memcpy(counts_host, g->h_mirror + 1, (size_t)E * sizeof(int32_t));
+  // the shared pseudo-expert is not part of a mask dispatch (the reference runs it in Python, deepseek.py:133-136)
+  CHK(run_experts(g, layer, x_dev, st, nullptr, nullptr, nullptr));
+  if (rows > 0) HIPCHK(hipMemcpyAsync(y_dev, g->d_y, (size_t)rows * g->H * g->es, hipMemcpyDeviceToDevice, st));
+  g->last_T = tokens; g->last_layer = layer; g->last_stream = st;
+  g->st.forwards += 1;
+  g->seq += 1;
+  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int32_t* topk_idx_dev, float* topk_w_dev, void* stream) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "no forward has run yet");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t T = (size_t)g->last_T;
+  if (logits_dev) HIPCHK(hipMemcpyAsync(logits_dev, g->d_logits, T * g->E * 4, hipMemcpyDeviceToDevice, st));
+  if (topk_idx_dev) HIPCHK(hipMemcpyAsync(topk_idx_dev, g->d_topk_idx, T * g->K * 4, hipMemcpyDeviceToDevice, st));
+  if (topk_w_dev) HIPCHK(hipMemcpyAsync(topk_w_dev, g->d_topk_w, T * g->K * 4, hipMemcpyDeviceToDevice, st));
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_set_profiling(moeinf_engine* g, int enabled) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   g->profiling = enabled != 0;

@@ -81,6 +81,8 @@ struct IndexArgs {
   int32_t* mirror;          // device staging of {n_active, counts[E+1], active[E+1]} for one D2H copy
 };
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
+// dispatch index from a dense router_mask[T,E] (element size 1, 4 or 8 bytes, non-zero = routed)
+hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st);
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
 

@@ -656,6 +656,72 @@ hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
+// mask_index: dispatch index from a dense router_mask[T,E] (what the reference's Python blocks hand to
+// dispatch_local, expert_executor.py:32-58).  One workgroup; wave w owns experts w, w+16, ...; tokens
+// are scanned 64 at a time with a ballot, so each expert's rows come out in ascending token order
+// (= the boolean-mask gather order of expert_dispatcher.cpp:274-284).
+// ------------------------------------------------------------------------------------------------
+template <typename MT>
+__global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __restrict__ mask, int T, int E, IndexArgs a) {
+  __shared__ int cnt[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = wave; e < E; e += IDX_WAVES) {
+    int c = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const bool on = t < T && mask[(size_t)t * E + e] != (MT)0;
+      c += __popcll(__ballot(on));
+    }
+    if (lane == 0) cnt[e] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, na = 0;
+    for (int e = 0; e < E; ++e) {
+      offs[e] = acc;
+      acc += cnt[e];
+      if (cnt[e] > 0) a.active[na++] = e;
+    }
+    offs[E] = acc;
+    offs[E + 1] = acc;  // no shared pseudo-expert on this path
+    cnt[E] = 0;
+    *a.n_active = na;
+    if (a.mirror) {
+      a.mirror[0] = na;
+      for (int i = 0; i < na; ++i) a.mirror[1 + (E + 1) + i] = a.active[i];
+      for (int i = na; i <= E; ++i) a.mirror[1 + (E + 1) + i] = -1;
+    }
+  }
+  __syncthreads();
+  if (tid <= E) {
+    a.counts[tid] = cnt[tid];
+    if (a.mirror) a.mirror[1 + tid] = cnt[tid];
+  }
+  if (tid <= E + 1) a.offsets[tid] = offs[tid];
+  for (int e = wave; e < E; e += IDX_WAVES) {
+    int base = offs[e];
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const bool on = t < T && mask[(size_t)t * E + e] != (MT)0;
+      const uint64_t b = __ballot(on);
+      if (on) {
+        const int slot = base + __popcll(b & lanes_below(lane));
+        a.slot_token[slot] = t;
+        a.slot_pair[slot] = t * E + e;
+      }
+      base += __popcll(b);
+    }
+  }
+}
+hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st) {
+  if (mask_elem_bytes == 1) hipLaunchKernelGGL(mask_index_kernel<uint8_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const uint8_t*)mask, T, E, a);
+  else if (mask_elem_bytes == 4) hipLaunchKernelGGL(mask_index_kernel<int32_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int32_t*)mask, T, E, a);
+  else hipLaunchKernelGGL(mask_index_kernel<int64_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int64_t*)mask, T, E, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // combine: out[t] = sum over the token's experts in ASCENDING expert id of w * y, with the
 // reference block's dtype rounding points (mixtral.py:96-101, deepseek.py:123-136,
 // switch_transformers.py:99-109, nllb_moe.py:84-104).  grid = (ceil(H/(256*4)), T).

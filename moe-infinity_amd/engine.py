@@ -142,6 +142,40 @@ class MoEEngine:
         self._last_T = T
         return out.reshape(shape) if out is not None else None
 
+    def dispatch_mask(self, layer: int, x2: torch.Tensor, router_mask: torch.Tensor):
+        """Grouped expert FFN for a dense router_mask[T,E] (the reference's dispatch_local contract).
+        Returns (y [rows,H] expert-sorted device tensor, counts[E], hit[E])."""
+        self._check_dev(x2, self.dtype, "x")
+        T, E = x2.shape[0], self.cfg.num_experts
+        m = router_mask.reshape(T, E)
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8) if m.is_contiguous() else m.contiguous().view(torch.uint8)
+        if m.dtype not in (torch.uint8, torch.int8, torch.int32, torch.int64):
+            m = m.to(torch.uint8)
+        m = m.contiguous()
+        if not m.is_cuda:
+            raise ValueError("router_mask must live on the engine's GPU")
+        y = torch.empty((self.cfg.max_tokens * self.cfg.top_k, self.cfg.hidden), dtype=self.dtype, device=self.device)
+        counts = np.empty(E, np.int32)
+        hit = np.empty(E, np.int32)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_dispatch_mask(self._h, layer, _ptr(x2), T, _ptr(m), m.element_size(), _ptr(y),
+                                            counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            hit.ctypes.data_as(C.POINTER(C.c_int32)), stream))
+        self._last_T = T
+        return y[: int(counts.sum())], counts, hit
+
+    def routing_tensors(self, logits: bool = True, topk: bool = False):
+        """Device copies of the last forward's router results (logits f32 [T,E], topk_idx i32, topk_w f32)."""
+        T, K, E = self._last_T, self.cfg.top_k, self.cfg.num_experts
+        lg = torch.empty((T, E), dtype=torch.float32, device=self.device) if logits else None
+        ti = torch.empty((T, K), dtype=torch.int32, device=self.device) if topk else None
+        tw = torch.empty((T, K), dtype=torch.float32, device=self.device) if topk else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_copy_routing_dev(self._h, _ptr(lg) if logits else None, _ptr(ti) if topk else None,
+                                               _ptr(tw) if topk else None, stream))
+        return lg, ti, tw
+
     def routing(self) -> Dict[str, np.ndarray]:
         T, K, E = self._last_T, self.cfg.top_k, self.cfg.num_experts
         idx = np.empty(T * K, np.int32)
