@@ -651,6 +651,21 @@ static void drain_mirrors(moeinf_engine* g, bool block) {
   }
 }
 
+// experts whose copy has already landed need no stream wait any more: count them as ordered
+static void settle_ready(moeinf_engine* g, int layer) {
+  if (g->resident_per_layer[layer] == g->owned_experts) return;
+  for (int e = 0; e < g->E; ++e) {
+    Node& n = g->nodes[node_index(g, layer, e)];
+    if (n.slot < 0 || n.ready_waited || !n.ready) continue;
+    if (hipEventQuery(n.ready) == hipSuccess) {
+      n.ready_waited = true;
+      g->resident_per_layer[layer] += 1;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+}
+
 // make every active routed expert of `layer` resident and order the compute stream after its copy.
 // h_mirror = {n_active, counts[E+1], active[E+1]} (already on the host).
 static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 = 0, int a1 = -1) {
@@ -782,6 +797,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // compute stream, so whatever the router picks is a hit — no host decision is needed and the host
   // does not wait for the routing result (the reference blocks on a D2H sum every layer,
   // expert_executor.py:34-43).  The mirror is applied to the counters lazily.
+  settle_ready(g, layer);
   const bool fast = g->resident_per_layer[layer] == g->owned_experts && g->cfg.ep_size == 1;
   if (fast) {
     drain_mirrors(g, g->pend.size() > 256);

@@ -248,6 +248,24 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st) {
 // grid = (E, ceil(T/TT)), block = 256.  fp64 makes the result independent of summation order to
 // ~1e-16, so the bf16/fp32 rounding (and with it the top-k choice) matches the oracle bit for bit.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float out[8]);
+template <>
+__device__ __forceinline__ void load8<uint16_t>(const uint16_t* p, float out[8]) {
+  const u32x4 v = ld16(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __uint_as_float(v[j] << 16);
+    out[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+  }
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float out[8]) {
+  const u32x4 a = ld16(p), b = ld16(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { out[j] = __uint_as_float(a[j]); out[4 + j] = __uint_as_float(b[j]); }
+}
+
 template <typename XT, typename WT, int TT>
 __global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__ x, const WT* __restrict__ wg,
                                                           float* __restrict__ logits, int T, int H, int E,
@@ -260,16 +278,18 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__
 #pragma unroll
   for (int i = 0; i < TT; ++i) acc[i] = 0.0;
   const WT* wrow = wg + (size_t)e * H;
-  for (int h = tid * 4; h < H; h += 256 * 4) {
-    double wv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wv[j] = (double)DT<WT>::load(wrow + h + j);
+  const int nt = min(TT, T - t0);
+  for (int h = tid * 8; h < H; h += 256 * 8) {  // H % 8 == 0
+    float wv[8];
+    load8<WT>(wrow + h, wv);
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
-      const int t = min(t0 + i, T - 1);
-      const XT* xr = x + (size_t)t * H + h;
+      if (i < nt) {
+        float xv[8];
+        load8<XT>(x + (size_t)(t0 + i) * H + h, xv);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i] = fma(wv[j], (double)DT<XT>::load(xr + j), acc[i]);
+        for (int j = 0; j < 8; ++j) acc[i] = fma((double)wv[j], (double)xv[j], acc[i]);
+      }
     }
   }
 #pragma unroll
@@ -637,6 +657,77 @@ hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// <= 64 (token,k) pairs: the whole dispatch index in ONE wave, no workgroup barriers.  Same outputs as
+// index_body (stable ranks by ballot/popc, prefix sums by wave shuffles).  Not for per-row capacity.
+__device__ __forceinline__ void index_small(const IndexArgs& a, int* cnt /*LDS [IDX_MAXE]*/, int* offs /*LDS [IDX_MAXE+1]*/) {
+  const int lane = threadIdx.x & 63;
+  const int E = a.E, K = a.K, T = a.T, npairs = T * K, ne = E + 1;
+  for (int e = lane; e < ne; e += 64) cnt[e] = 0;
+  const bool in = lane < npairs;
+  const int key = in ? a.topk_idx[lane] : -1;
+  const bool counted = in && key >= 0 && key < E && (a.pair_valid ? a.pair_valid[lane] != 0 : true);
+  int rank = 0;
+  uint64_t todo = __ballot(counted);
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const int k = __shfl(key, leader);
+    const uint64_t same = __ballot(counted && key == k);
+    if (counted && key == k) rank = __popcll(same & lanes_below(lane));
+    if (lane == leader) cnt[k] = __popcll(same);
+    todo &= ~same;
+  }
+  if (lane == 0) cnt[E] = a.shared ? T : 0;
+  __builtin_amdgcn_wave_barrier();
+  // exclusive scan over ne <= 257 experts: 5 consecutive experts per lane
+  int c[5], loc = 0, nz = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int e = lane * 5 + j;
+    c[j] = (e < ne) ? cnt[e] : 0;
+    loc += c[j];
+    nz += c[j] > 0;
+  }
+  int pre = loc, pnz = nz;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(pre, o), w = __shfl_up(pnz, o);
+    if (lane >= o) { pre += v; pnz += w; }
+  }
+  const int total_nz = __shfl(pnz, 63), total = __shfl(pre, 63);
+  pre -= loc; pnz -= nz;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int e = lane * 5 + j;
+    if (e < ne) {
+      offs[e] = pre;
+      a.offsets[e] = pre;
+      a.counts[e] = c[j];
+      if (a.mirror) a.mirror[1 + e] = c[j];
+      if (c[j] > 0) { a.active[pnz] = e; if (a.mirror) a.mirror[1 + ne + pnz] = e; ++pnz; }
+      pre += c[j];
+    }
+  }
+  if (lane == 0) {
+    a.offsets[ne] = total;
+    *a.n_active = total_nz;
+    if (a.mirror) a.mirror[0] = total_nz;
+  }
+  if (a.mirror) for (int i = total_nz + lane; i < ne; i += 64) a.mirror[1 + ne + i] = -1;
+  __builtin_amdgcn_wave_barrier();
+  if (in) {
+    int slot = -1;
+    if (counted) {
+      slot = offs[key] + rank;
+      a.slot_token[slot] = lane / K;
+      a.slot_pair[slot] = lane;
+    }
+    a.pair_slot[lane] = slot;
+  }
+  if (a.shared) {
+    const int base = offs[E];
+    for (int t = lane; t < T; t += 64) { a.slot_token[base + t] = t; a.slot_pair[base + t] = -1; }
+  }
+}
+
 // decode-sized batches: softmax/top-k of every token (one wave each) and the dispatch index in ONE
 // launch of one workgroup — saves a kernel boundary per layer where launches dominate the layer time
 __global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, IndexArgs a) {
@@ -647,7 +738,11 @@ __global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, I
   for (int t = threadIdx.x >> 6; t < r.T; t += IDX_WAVES) route_token(r, t, threadIdx.x & 63);
   __threadfence_block();
   __syncthreads();
-  index_body(a, wave_cnt, running, offs, scan_tmp);
+  if (a.T * a.K <= 64 && !(a.capacity > 0 && a.T > a.rows)) {
+    if (threadIdx.x < 64) index_small(a, running, offs);
+  } else {
+    index_body(a, wave_cnt, running, offs, scan_tmp);
+  }
 }
 
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st) {
@@ -743,18 +838,32 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
       DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, DT<T>::round(pr * DT<T>::load(src + h0 + j)));
     return;
   }
-  for (int kk = 0; kk < K; ++kk) {
-    const int k = a.pair_order[(size_t)t * K + kk];
-    const int slot = a.pair_slot[(size_t)t * K + k];
-    if (slot < 0) continue;
-    const float w = a.topk_w[(size_t)t * K + k];
-    const T* yr = y + (size_t)slot * a.H + h0;
-    for (int j = 0; j < nh; ++j) {
-      float prod = DT<T>::load(yr + j) * w;
-      // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
-      // product in fp32 (fp32 gate weights promote the bf16 expert output)
-      if (a.kind != 1) prod = DT<T>::round(prod);
-      acc[j] = DT<T>::round(acc[j] + prod);
+  int slot[8];
+  float w[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    slot[kk] = -1; w[kk] = 0.f;
+    if (kk < K) {
+      const int k = a.pair_order[(size_t)t * K + kk];
+      slot[kk] = a.pair_slot[(size_t)t * K + k];
+      w[kk] = a.topk_w[(size_t)t * K + k];
+    }
+  }
+  float yv[8][4];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+    if (kk < K && slot[kk] >= 0)
+      for (int j = 0; j < nh; ++j) yv[kk][j] = DT<T>::load(y + (size_t)slot[kk] * a.H + h0 + j);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    if (kk < K && slot[kk] >= 0) {
+      for (int j = 0; j < nh; ++j) {
+        float prod = yv[kk][j] * w[kk];
+        // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
+        // product in fp32 (fp32 gate weights promote the bf16 expert output)
+        if (a.kind != 1) prod = DT<T>::round(prod);
+        acc[j] = DT<T>::round(acc[j] + prod);
+      }
     }
   }
   if (a.kind == 1 && a.shared_offsets) {
