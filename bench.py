@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override the number of MoE layers (0 = the model's)")
     ap.add_argument("--policy", default="lfu_incache", choices=["lfu_incache", "lru"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
     ap.add_argument("--cpu-sample-layers", type=int, default=4)
     ap.add_argument("--cpu-sample-steps", type=int, default=3)
     args = ap.parse_args()
@@ -125,9 +126,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ep = world > 1 or args.force_ep
+    if use_ep:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
 
@@ -166,7 +169,7 @@ def main():
     out = torch.empty(B, H, dtype=dt, device=dev)
     batch_rows = B if family == "switch" else 1
 
-    if world > 1:
+    if use_ep:
         ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev)
 
         def layer_fwd(l, x):
@@ -219,7 +222,7 @@ def main():
 
     # ---- same K steps again with per-kernel HIP events on the launch stream (roofline leg)
     roof, kernels = None, {}
-    if world == 1:
+    if world == 1 and not use_ep:
         eng.set_profiling(True)
         fence()
         run_steps(args.warmup, args.steps)
@@ -241,15 +244,23 @@ def main():
                    "combine": kstat(p["combine_ms"], p["forwards"], p["combine_bytes"]),
                    "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)}
         k1 = kernels["ffn_stage1"]
+        # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; tools/pmc_summary.py)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_mixtral8x7b.json")
+        if args.workload == "mixtral-8x7b" and B == 1 and os.path.exists(pmc):
+            for name, v in json.load(open(pmc))["kernels"].items():
+                if "ffn_rows_kernel<unsigned short, 2" in name:
+                    traffic = v["hbm_bytes"]
         if k1:
             roof = {"bound": "hbm", "kernel": "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)",
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
-                    "traffic": None, "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"]}
+                    "traffic": traffic, "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"]}
 
     # ---- CPU baseline + full-size parity: the oracle on a bounded sample of the same workload
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not use_ep and not args.no_cpu_baseline:
         from oracle import moe_ref as R
 
         ncores = os.cpu_count() or 1
@@ -311,7 +322,7 @@ def main():
                                    + (f" +shared F={cfg.shared_inter}" if cfg.shared_inter else "")
                                    + f", decode batch {B}/rank, device_memory_ratio={args.ratio}"
                                    + (f", expert-cache budget {args.budget_gib} GiB" if args.budget_gib else ""),
-                       "parallelism": f"ep{world}" if world > 1 else "single", "per_token_decode_latency_ms": round(ms_per_step, 4),
+                       "parallelism": f"ep{world}" if use_ep else "single", "per_token_decode_latency_ms": round(ms_per_step, 4),
                        "cache_policy": args.policy},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -330,7 +341,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_ep:
         dist.destroy_process_group()
 
 
