@@ -335,6 +335,8 @@ def main():
                 "frac_of_hbm_peak": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6 / HBM_PEAK_GBS, 4)},
             "timed_region_h2d": {"bytes": st["h2d_bytes"], "busy_ms": round(st["h2d_busy_ms"], 2),
                                  "GBps": round(st["h2d_bytes"] / st["h2d_busy_ms"] / 1e6, 2) if st["h2d_busy_ms"] > 0 else None,
+                                 "exposed_wait_ms": round(st["exposed_wait_ms"], 2),
+                                 "overlap": None if st["h2d_busy_ms"] <= 0 else round(max(0.0, 1.0 - st["exposed_wait_ms"] / st["h2d_busy_ms"]), 4),
                                  "hit_rate": round(st["expert_hits"] / max(1, st["expert_hits"] + st["expert_misses"]), 4)},
             "cache": {k: st[k] for k in ("expert_hits", "expert_misses", "evictions", "h2d_bytes", "slots_total", "slots_used", "slot_bytes", "host_arena_bytes")},
             "parity": parity,

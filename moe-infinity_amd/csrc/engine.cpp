@@ -164,6 +164,7 @@ struct moeinf_engine {
   hipEvent_t fence_ev[kFenceRing];
   uint64_t seq = 0;  // forwards issued
   std::vector<std::pair<hipEvent_t, hipEvent_t>> copy_timers;  // (start, end) pairs not yet accumulated
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_timers;  // compute-stream stalls on copies
   std::vector<hipEvent_t> event_pool;
 
   // device workspace
@@ -572,6 +573,21 @@ static void settle_copy_timers(moeinf_engine* g, bool wait) {
     }
   }
   g->copy_timers.resize(keep);
+  keep = 0;
+  for (size_t i = 0; i < g->wait_timers.size(); ++i) {
+    auto pr = g->wait_timers[i];
+    if (wait) hipEventSynchronize(pr.second);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      g->st.exposed_wait_ms += ms;
+      g->event_pool.push_back(pr.first);
+      g->event_pool.push_back(pr.second);
+    } else {
+      (void)hipGetLastError();
+      g->wait_timers[keep++] = pr;
+    }
+  }
+  g->wait_timers.resize(keep);
 }
 
 // ---- the hot path --------------------------------------------------------------------------
@@ -676,6 +692,11 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 =
   // pin this layer's active experts so a miss cannot evict a sibling that the same launch reads
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
   int rc = MOEINF_OK;
+  // if the compute stream will have to wait for a copy, time the stall (exposed copy time)
+  bool will_wait = false;
+  for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) { const Node& n = g->nodes[node_index(g, layer, e)]; if (n.slot < 0 || !n.ready_waited) will_wait = true; } }
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  if (will_wait) { w0 = get_event(g); w1 = get_event(g); if (w0 && w1) hipEventRecord(w0, st); }
   for (int i = a0; i < na && rc == MOEINF_OK; ++i) {
     const int e = active[i];
     if (e >= g->E) continue;  // shared pseudo-expert
@@ -704,6 +725,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 =
     g->slots[n.slot].last_use_seq = g->seq + 1;
   }
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
+  if (w0 && w1) { hipEventRecord(w1, st); g->wait_timers.push_back({w0, w1}); }
   return rc;
 }
 
