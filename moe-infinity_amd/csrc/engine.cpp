@@ -753,9 +753,11 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     CHK(flush_pokes(g, st));
     s1.active = g->d_active + a; s2.active = g->d_active + a;
     s1.n_active_host = b - a; s2.n_active_host = b - a;
-    HIPCHK(launch_ffn_stage(s1, b - a, st));
+    int max_rows = 0;
+    for (int i = a; i < b; ++i) max_rows = std::max(max_rows, (int)g->h_mirror[1 + active[i]]);
+    HIPCHK(launch_ffn_stage(s1, b - a, max_rows, st));
     if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
-    HIPCHK(launch_ffn_stage(s2, b - a, st));
+    HIPCHK(launch_ffn_stage(s2, b - a, max_rows, st));
     a = b;
     if (a < na) {
       g->seq += 1;
@@ -843,9 +845,10 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     fill_stage(g, layer, 2, s2);
     const int max_active = std::min(E, T * K) + (g->has_shared ? 1 : 0);
     if (prof) HIPCHK(hipEventRecord(pr.ev[2], st));
-    HIPCHK(launch_ffn_stage(s1, max_active, st));
+    const int exp_rows = (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1);  // ~1.5x the mean rows per expert
+    HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr.ev[3], st));
-    HIPCHK(launch_ffn_stage(s2, max_active, st));
+    HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr.ev[4], st));
   } else {
     // Residency decisions need the active-expert list on the host: one small pinned copy + event.

@@ -40,7 +40,8 @@ struct FfnStage {
   int epi;
   int dtype;
 };
-hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st);
+// max_rows_per_expert: upper bound of rows any one expert receives (selects the multi-token-tile variant)
+hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
 // row-major [R,K] -> MFMA A-operand tiles (see kernels.hip); dst needs tiled_bytes(R,K) bytes
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st);
 inline int64_t tiled_bytes(int64_t R, int64_t K, int dtype) { const int64_t ept = dtype == DT_BF16 ? 32 : 16; return ((R + 15) / 16) * ((K + ept - 1) / ept) * 1024; }

@@ -113,7 +113,7 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
 }
 
-template <typename T, int NMAT, int NW, int U>
+template <typename T, int NMAT, int NW, int U, int NT>
 __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
@@ -144,70 +144,106 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)blockIdx.x * KB * 1024 + lane * 16 : nullptr;
   const int kq = q * EPV;  // this lane's k offset inside a tile
 
-  for (int tile = 0; tile * 16 < cnt; ++tile) {
-    const int srow = off + min(tile * 16 + n, cnt - 1);
-    const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-    const T* xr = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+  // NT token tiles (16 tokens each) share one pass over the weights: experts with many tokens
+  // (prefill, big batches) re-stream their weights every 16*NT tokens instead of every 16
+  for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NT) {
+    const int ntl = min(NT, (cnt - tile0 * 16 + 15) / 16);  // live token tiles in this pass (block-uniform)
+    const T* xr[NT];
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int srow = off + min((tile0 + tt) * 16 + n, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      xr[tt] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
+      acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     int kb = wave;
     for (; kb + (U - 1) * NW < KBfull; kb += U * NW) {
-      u32x4 av[U], bv[U], xv[U];
+      u32x4 av[U], bv[U], xv[U][NT];
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         av[i] = ld16_nt(a0 + (size_t)(kb + i * NW) * 1024);
         if (NMAT == 2) bv[i] = ld16_nt(a1 + (size_t)(kb + i * NW) * 1024);
-        xv[i] = ld16(xr + (size_t)(kb + i * NW) * EPT);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if (tt < ntl) xv[i][tt] = ld16(xr[tt] + (size_t)(kb + i * NW) * EPT);
       }
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        mma16<T>(acc0, av[i], xv[i]);
-        if (NMAT == 2) mma16<T>(acc1, bv[i], xv[i]);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          if (tt < ntl) {
+            mma16<T>(acc0[tt], av[i], xv[i][tt]);
+            if (NMAT == 2) mma16<T>(acc1[tt], bv[i], xv[i][tt]);
+          }
+        }
       }
     }
     for (; kb < KBfull; kb += NW) {
-      const u32x4 x0 = ld16(xr + (size_t)kb * EPT);
-      mma16<T>(acc0, ld16_nt(a0 + (size_t)kb * 1024), x0);
-      if (NMAT == 2) mma16<T>(acc1, ld16_nt(a1 + (size_t)kb * 1024), x0);
+      const u32x4 w0 = ld16_nt(a0 + (size_t)kb * 1024);
+      u32x4 w1 = w0;
+      if (NMAT == 2) w1 = ld16_nt(a1 + (size_t)kb * 1024);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt < ntl) {
+          const u32x4 x0 = ld16(xr[tt] + (size_t)kb * EPT);
+          mma16<T>(acc0[tt], w0, x0);
+          if (NMAT == 2) mma16<T>(acc1[tt], w1, x0);
+        }
+      }
     }
     if (KB != KBfull && wave == (KBfull % NW)) {  // zero-padded last tile: guard only the activation read
       const u32x4 z = {0u, 0u, 0u, 0u};
-      const u32x4 x0 = (KBfull * EPT + kq < K) ? ld16(xr + (size_t)KBfull * EPT) : z;
-      mma16<T>(acc0, ld16_nt(a0 + (size_t)KBfull * 1024), x0);
-      if (NMAT == 2) mma16<T>(acc1, ld16_nt(a1 + (size_t)KBfull * 1024), x0);
-    }
-    // cross-wave reduction of the K split
+      const u32x4 w0 = ld16_nt(a0 + (size_t)KBfull * 1024);
+      u32x4 w1 = w0;
+      if (NMAT == 2) w1 = ld16_nt(a1 + (size_t)KBfull * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[wave][0][lane * 4 + j] = acc0[j];
-      if (NMAT == 2) red[wave][1][lane * 4 + j] = acc1[j];
-    }
-    __syncthreads();
-    for (int i = tid; i < 256; i += NW * 64) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < NW; ++ww) {
-        s0 += red[ww][0][i];
-        if (NMAT == 2) s1 += red[ww][1][i];
-      }
-      const int l = i >> 2, j = i & 3;
-      const int tn = l & 15;                    // token column
-      const int orow = r0 + (l >> 4) * 4 + j;  // output row
-      if (tile * 16 + tn < cnt && orow < R) {
-        float v = DT<T>::round(s0);
-        if (s.epi == EPI_GATED_SILU) {
-          const float b = DT<T>::round(s1);
-          const float sl = DT<T>::round(v / (1.0f + expf(-v)));
-          v = DT<T>::round(sl * b);
-        } else {
-          if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
-            v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
-          if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt < ntl) {
+          const u32x4 x0 = (KBfull * EPT + kq < K) ? ld16(xr[tt] + (size_t)KBfull * EPT) : z;
+          mma16<T>(acc0[tt], w0, x0);
+          if (NMAT == 2) mma16<T>(acc1[tt], w1, x0);
         }
-        DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
       }
     }
-    __syncthreads();
+    // cross-wave reduction of the K split + epilogue, one token tile at a time
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      if (tt >= ntl) break;
+      const int tile = tile0 + tt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[wave][0][lane * 4 + j] = acc0[tt][j];
+        if (NMAT == 2) red[wave][1][lane * 4 + j] = acc1[tt][j];
+      }
+      __syncthreads();
+      for (int i = tid; i < 256; i += NW * 64) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+          s0 += red[ww][0][i];
+          if (NMAT == 2) s1 += red[ww][1][i];
+        }
+        const int l = i >> 2, j = i & 3;
+        const int tn = l & 15;                    // token column
+        const int orow = r0 + (l >> 4) * 4 + j;  // output row
+        if (tile * 16 + tn < cnt && orow < R) {
+          float v = DT<T>::round(s0);
+          if (s.epi == EPI_GATED_SILU) {
+            const float b = DT<T>::round(s1);
+            const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+            v = DT<T>::round(sl * b);
+          } else {
+            if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
+              v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+            if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          }
+          DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -218,14 +254,18 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <typename T, int NMAT>
-static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, hipStream_t st) {
-#define LAUNCH(NWV, UU) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU>), grid, dim3(NWV * 64), 0, st, s)
-  if (nw == 8) { if (u == 2) LAUNCH(8, 2); else if (u == 8) LAUNCH(8, 8); else LAUNCH(8, 4); }
-  else         { if (u == 2) LAUNCH(4, 2); else if (u == 8) LAUNCH(4, 8); else LAUNCH(4, 4); }
+static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, hipStream_t st) {
+#define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
+  if (many_tokens) {  // up to 64 tokens per pass over an expert's weights
+    if (nw == 8) LAUNCH(8, 1, 4); else LAUNCH(4, 1, 4);
+    return;
+  }
+  if (nw == 8) { if (u == 2) LAUNCH(8, 2, 1); else if (u == 8) LAUNCH(8, 8, 1); else LAUNCH(8, 4, 1); }
+  else         { if (u == 2) LAUNCH(4, 2, 1); else if (u == 8) LAUNCH(4, 8, 1); else LAUNCH(4, 4, 1); }
 #undef LAUNCH
 }
 
-hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st) {
+hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st) {
   static const int env_nw = env_int("MOEINF_FFN_NW", 0), env_u = env_int("MOEINF_FFN_U", 0);
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   dim3 grid((rmax + 15) / 16, max_active);
@@ -235,10 +275,13 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, hipStream_t st) {
   const size_t kbytes = (size_t)kmax * (s.dtype == DT_BF16 ? 2 : 4);
   const int nw = env_nw ? env_nw : (kbytes >= 16384 ? 8 : 4);
   const int u = env_u ? env_u : 4;
+  static const int env_nt = env_int("MOEINF_FFN_NT", 0);
+  // the 64-token variant runs at low occupancy (~240 VGPRs): it only pays once an expert needs >= 3 token tiles
+  const bool many = env_nt ? env_nt > 1 : max_rows_per_expert > 32;
   if (s.dtype == DT_BF16) {
-    if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, st);
+    if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, st);
   } else {
-    if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, st); else launch_ffn_t<float, 1>(s, grid, nw, u, st);
+    if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, many, st); else launch_ffn_t<float, 1>(s, grid, nw, u, many, st);
   }
   return hipGetLastError();
 }
