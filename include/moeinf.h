@@ -275,16 +275,18 @@ int moeinf_cache_sim_clear_counts(moeinf_cache_sim* sim);
 /* ---- expert-parallel exchange helpers (multi-GPU) ---------------------
  * Pack routed rows for an all-to-all and unpack the replies.  The collective itself (RCCL
  * all_to_all over xGMI) is issued by the host layer (torch.distributed) between these calls. */
+/* Exchange rows have ep_row_elems = H + 16/sizeof(elem) elements: H activations followed by a 16-byte
+ * tail whose first int32 is the row's expert id (-1 = padding row), so activations and ids cross the
+ * fabric in ONE all-to-all per direction. */
+int moeinf_ep_row_elems(const moeinf_engine* eng, int32_t* elems);
 /* After a MOEINF_FWD_ROUTE_ONLY forward: write, for each destination rank r, the rows of x whose
- * expert lives on r ((e % ep_size) == r) into send_dev[r*cap_rows ...] (cfg.dtype, [ep_size*cap_rows, H]),
- * and per-row metadata meta_dev[ep_size*cap_rows] (int32: expert id, -1 = padding).
- * send_counts_dev[ep_size] int32 receives the row counts. */
-int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* meta_dev,
-                   int32_t* send_counts_dev, int cap_rows, void* stream);
-/* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, H] with
- * meta_dev (expert ids, -1 padding); writes y_dev in the same row order. */
-int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, const int32_t* meta_dev,
-                         void* y_dev, int cap_rows, void* stream);
+ * expert lives on r ((e % ep_size) == r) into send_dev[r*cap_rows ...] ([ep_size*cap_rows, ep_row_elems],
+ * cfg.dtype).  send_counts_dev[ep_size] (optional) receives the row counts. */
+int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows,
+                   void* stream);
+/* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, ep_row_elems];
+ * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows zero). */
+int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream);
 /* Combine replies: ret_dev [ep_size*cap_rows, H] holds, in the order moeinf_ep_pack produced,
  * the expert outputs for this rank's routed rows; writes out_dev [tokens, H]. */
 int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows,

@@ -100,8 +100,9 @@ PROTOTYPES = {
     "moeinf_cache_sim_access": (C.c_int, [_P, C.c_int64, _I32P, _I64P]),
     "moeinf_cache_sim_protect": (C.c_int, [_P, _I64P, C.c_int]),
     "moeinf_cache_sim_clear_counts": (C.c_int, [_P]),
-    "moeinf_ep_pack": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
-    "moeinf_ep_expert_ffn": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "moeinf_ep_row_elems": (C.c_int, [_P, _I32P]),
+    "moeinf_ep_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    "moeinf_ep_expert_ffn": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P]),
     "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
 }
 

@@ -591,7 +591,7 @@ static void settle_copy_timers(moeinf_engine* g, bool wait) {
 }
 
 // ---- the hot path --------------------------------------------------------------------------
-static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s) {
+static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
   const DevLayout& b = g->dlay;
   const DevLayout& bs = g->dlay_sh;
   memset(&s, 0, sizeof s);
@@ -604,7 +604,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   const int et = g->cfg.expert_type;
   if (stage == 1) {
     s.K = g->H; s.R = g->F; s.K_sh = g->H; s.R_sh = g->Fs;
-    s.ld_in = g->H; s.row_map = g->d_slot_token; s.out = g->d_h; s.ld_out = g->ldh;
+    s.ld_in = ld_x > 0 ? ld_x : g->H; s.row_map = g->d_slot_token; s.out = g->d_h; s.ld_out = g->ldh;
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[0]; s.off_b = b.off[2]; s.epi = EPI_GATED_SILU; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[0]; s.off_b = b.off[1]; s.off_a_sh = bs.off[0]; s.off_b_sh = bs.off[1]; s.epi = EPI_GATED_SILU; }
     else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[0]; s.epi = EPI_RELU; }
@@ -734,13 +734,13 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 =
 // time, so it has no such limit): each chunk is made resident, launched, and fenced so the next
 // chunk may recycle its slots once its kernels have drained.
 static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_t st, hipEvent_t ev_before,
-                       hipEvent_t ev_mid, hipEvent_t ev_after) {
+                       hipEvent_t ev_mid, hipEvent_t ev_after, int64_t ld_x = 0) {
   const int E = g->E, E1 = E + 1;
   const int na = g->h_mirror[0];
   const int32_t* active = g->h_mirror + 1 + E1;
   const int64_t cap = g->slab_exhausted ? (int64_t)g->slots.size() : g->max_slots;
   FfnStage s1, s2;
-  fill_stage(g, layer, 1, s1);
+  fill_stage(g, layer, 1, s1, ld_x);
   s1.in = x_in;
   fill_stage(g, layer, 2, s2);
   if (ev_before) HIPCHK(hipEventRecord(ev_before, st));
@@ -769,6 +769,61 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
   return MOEINF_OK;
 }
 
+// Residency + the two FFN launches for the routing result that the index kernel just produced
+// (d_mirror/d_active/d_counts/...).  x rows have stride ld_x elements (0: H).
+//   Sync-free path: every owned expert of this layer is resident and already ordered before the
+//   compute stream, so whatever the router picked is a hit — no host decision is needed and the host
+//   does not wait for the routing result (the reference blocks on a D2H sum every layer,
+//   expert_executor.py:34-43).  The mirror is applied to the counters lazily.
+//   Decision path: some expert may be missing: small pinned D2H + event wait, then fetch/evict.
+static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
+                            hipStream_t st, bool prof, moeinf_engine::ProfRec* pr) {
+  const int E = g->E, E1 = E + 1;
+  const size_t mirror_bytes = (size_t)(1 + 2 * E1) * sizeof(int32_t);
+  settle_ready(g, layer);
+  const bool fast = g->resident_per_layer[layer] == g->owned_experts;
+  if (fast) {
+    drain_mirrors(g, g->pend.size() > 256);
+    moeinf_engine::PendingMirror pm;
+    if (!g->mirror_pool.empty()) { pm.buf = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
+    else HIPCHK(hipHostMalloc((void**)&pm.buf, mirror_bytes, hipHostMallocDefault));
+    if (!g->mirror_events.empty()) { pm.ev = g->mirror_events.back(); g->mirror_events.pop_back(); }
+    else HIPCHK(hipEventCreateWithFlags(&pm.ev, hipEventDisableTiming));
+    pm.layer = layer; pm.T = T; pm.prof = prof;
+    HIPCHK(hipMemcpyAsync(pm.buf, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(pm.ev, st));
+    g->pend.push_back(pm);
+    for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
+      const Node& n = g->nodes[node_index(g, layer, e)];
+      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
+    }
+    CHK(flush_pokes(g, st));
+    FfnStage s1, s2;
+    fill_stage(g, layer, 1, s1, ld_x);
+    s1.in = x_in;
+    fill_stage(g, layer, 2, s2);
+    if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
+    HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
+    if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
+    HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
+    if (prof) HIPCHK(hipEventRecord(pr->ev[4], st));
+  } else {
+    drain_mirrors(g, true);
+    HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(g->route_ev, st));
+    const auto tw0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(g->route_ev));
+    if (g->profiling) g->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+    for (int i = 0; i < g->h_mirror[0]; ++i) {
+      const int e = g->h_mirror[1 + E1 + i];
+      if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d was handed rows for expert %d it does not own", g->cfg.ep_rank, e);
+    }
+    if (prof) account_profile(g, g->h_mirror, T);
+    CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x));
+  }
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                                   void* out_dev, void* stream, uint32_t flags) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
@@ -778,6 +833,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
   if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
   const bool route_only = flags & MOEINF_FWD_ROUTE_ONLY;
+  if (!route_only && g->cfg.ep_size > 1) return fail(MOEINF_ERR_STATE, "engine is expert-parallel (ep_size %d): run ROUTE_ONLY here and moeinf_ep_pack / ep_expert_ffn / ep_combine around the all-to-alls", g->cfg.ep_size);
   if (!route_only && !(flags & MOEINF_FWD_NO_COMBINE) && !out_dev) return fail(MOEINF_ERR_INVALID, "out_dev is NULL");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
@@ -816,51 +872,8 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (route_only) return MOEINF_OK;
   if (prof) HIPCHK(hipEventRecord(pr.ev[1], st));
 
-  const size_t mirror_bytes = (size_t)(1 + 2 * E1) * sizeof(int32_t);
-  // Sync-free path: every owned expert of this layer is resident and already ordered before the
-  // compute stream, so whatever the router picks is a hit — no host decision is needed and the host
-  // does not wait for the routing result (the reference blocks on a D2H sum every layer,
-  // expert_executor.py:34-43).  The mirror is applied to the counters lazily.
-  settle_ready(g, layer);
-  const bool fast = g->resident_per_layer[layer] == g->owned_experts && g->cfg.ep_size == 1;
-  if (fast) {
-    drain_mirrors(g, g->pend.size() > 256);
-    moeinf_engine::PendingMirror pm;
-    if (!g->mirror_pool.empty()) { pm.buf = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
-    else HIPCHK(hipHostMalloc((void**)&pm.buf, mirror_bytes, hipHostMallocDefault));
-    if (!g->mirror_events.empty()) { pm.ev = g->mirror_events.back(); g->mirror_events.pop_back(); }
-    else HIPCHK(hipEventCreateWithFlags(&pm.ev, hipEventDisableTiming));
-    pm.layer = layer; pm.T = T; pm.prof = prof;
-    HIPCHK(hipMemcpyAsync(pm.buf, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(pm.ev, st));
-    g->pend.push_back(pm);
-    for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
-      const Node& n = g->nodes[node_index(g, layer, e)];
-      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
-    }
-    CHK(flush_pokes(g, st));
-    FfnStage s1, s2;
-    fill_stage(g, layer, 1, s1);
-    s1.in = x_dev;
-    fill_stage(g, layer, 2, s2);
-    const int max_active = std::min(E, T * K) + (g->has_shared ? 1 : 0);
-    if (prof) HIPCHK(hipEventRecord(pr.ev[2], st));
-    const int exp_rows = (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1);  // ~1.5x the mean rows per expert
-    HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
-    if (prof) HIPCHK(hipEventRecord(pr.ev[3], st));
-    HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
-    if (prof) HIPCHK(hipEventRecord(pr.ev[4], st));
-  } else {
-    // Residency decisions need the active-expert list on the host: one small pinned copy + event.
-    drain_mirrors(g, true);
-    HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(g->route_ev, st));
-    const auto tw0 = std::chrono::steady_clock::now();
-    HIPCHK(hipEventSynchronize(g->route_ev));
-    if (g->profiling) g->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-    if (prof) account_profile(g, g->h_mirror, T);
-    CHK(run_experts(g, layer, x_dev, st, prof ? pr.ev[2] : nullptr, prof ? pr.ev[3] : nullptr, prof ? pr.ev[4] : nullptr));
-  }
+  CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + (g->has_shared ? 1 : 0),
+                       (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr));
   if (!(flags & MOEINF_FWD_NO_COMBINE)) {
     CombineArgs ca;
     memset(&ca, 0, sizeof ca);
@@ -1174,8 +1187,16 @@ static int ep_alloc(moeinf_engine* g, int cap_rows) {
   return MOEINF_OK;
 }
 
-extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* meta_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
-  if (!g || !x_dev || !send_dev || !meta_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+static int64_t ep_row_elems(const moeinf_engine* g) { return g->H + 16 / g->es; }
+
+extern "C" int moeinf_ep_row_elems(const moeinf_engine* g, int32_t* elems) {
+  if (!g || !elems) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  *elems = (int32_t)ep_row_elems(g);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
+  if (!g || !x_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack needs a preceding ROUTE_ONLY forward");
   if (cap_rows < g->last_T * g->K) return fail(MOEINF_ERR_INVALID, "cap_rows %d < tokens*K %d (worst case: every pair goes to one rank)", cap_rows, g->last_T * g->K);
   HIPCHK(hipSetDevice(g->cfg.device_id));
@@ -1192,7 +1213,7 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   HIPCHK(hipMemsetAsync(g->d_ep_pair_pos, 0xFF, (size_t)np * 4, st));
   EpPackArgs pa;
   memset(&pa, 0, sizeof pa);
-  pa.x = x_dev; pa.send = send_dev; pa.meta = meta_dev; pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
+  pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
   pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
   pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
   HIPCHK(launch_ep_pack(pa, st));
@@ -1200,28 +1221,28 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   return MOEINF_OK;
 }
 
-extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, const int32_t* meta_dev, void* y_dev, int cap_rows, void* stream) {
-  if (!g || !recv_dev || !meta_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream) {
+  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
-  const int ep = g->cfg.ep_size, nrows = ep * cap_rows, E = g->E, E1 = E + 1;
+  const int ep = g->cfg.ep_size, nrows = ep * cap_rows, E = g->E;
   if ((int64_t)nrows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "ep rows %d exceed workspace (max_tokens*K = %d): create the engine with max_tokens >= ep_size*cap_rows/K", nrows, g->cfg.max_tokens * g->K);
+  const int64_t ld = ep_row_elems(g);
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
-  ia.topk_idx = meta_dev; ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
+  // the expert id of every received row sits in the row's 16-byte tail
+  ia.topk_idx = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(recv_dev) + (size_t)g->H * g->es);
+  ia.idx_stride = (int)(ld * g->es / 4);
+  ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
   HIPCHK(launch_dispatch_index(ia, st));
-  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(g->route_ev, st));
-  HIPCHK(hipEventSynchronize(g->route_ev));
-  for (int i = 0; i < g->h_mirror[0]; ++i) {
-    const int e = g->h_mirror[1 + E1 + i];
-    if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d received rows for expert %d it does not own", g->cfg.ep_rank, e);
-  }
-  CHK(run_experts(g, layer, recv_dev, st, nullptr, nullptr, nullptr));
+  const int owned = std::max(1, g->owned_experts);
+  CHK(dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
+                       (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr));
   HIPCHK(launch_ep_unsort(g->d_y, y_dev, g->d_pair_slot, nrows, g->H, g->dt, st));
+  g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
   return MOEINF_OK;

@@ -67,6 +67,7 @@ hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st);
 
 struct IndexArgs {
   const int32_t* topk_idx;  // [T,K]; entries < 0 are never dispatched
+  int idx_stride;           // distance between consecutive entries of topk_idx in int32 units (0/1: contiguous)
   int32_t* pair_valid;      // [T,K] in/out (Switch capacity clears entries); nullptr: all valid
   int T, K, E;
   int rows;                 // batch rows B (T = B*S); capacity applies per row
@@ -119,8 +120,9 @@ hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid
                               int ep_size, hipStream_t st);
 struct EpPackArgs {
   const void* x;              // [T,H]
-  void* send;                 // [ep_size*cap_rows, H]
-  int32_t* meta;              // [ep_size*cap_rows] expert id, -1 = padding
+  void* send;                 // [ep_size*cap_rows, ld_send]: H activations + a 16-byte tail whose first int32 is
+                              // the expert id of the row (-1 = padding) -> rows and ids travel in ONE all-to-all
+  int64_t ld_send;            // elements per send row (H + 16/sizeof(elem))
   int32_t* pair_pos;          // [T*K] row of every pair inside `send`, -1 if not dispatched
   const int32_t* topk_idx;    // [T*K]
   const int32_t* counts;      // [ep_size] rows per destination (from dispatch_index on the dest keys)

@@ -569,6 +569,7 @@ hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st) {
 constexpr int IDX_THREADS = 1024;
 constexpr int IDX_WAVES = IDX_THREADS / 64;
 constexpr int IDX_MAXE = 257;  // E + shared pseudo-expert
+#define IDX_AT(a, p) ((a).topk_idx[(size_t)(p) * ((a).idx_stride > 1 ? (a).idx_stride : 1)])
 
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
 
@@ -621,7 +622,7 @@ __device__ __forceinline__ void index_body(const IndexArgs& a, int* wave_cnt, in
         const int s = c0 + tid;
         const bool in = s < S;
         const int p = b * S + s;
-        const int key = in ? a.topk_idx[p] : -1;
+        const int key = in ? IDX_AT(a, p) : -1;
         const bool counted = in && key >= 0 && key < E;
         const int pos = chunk_rank(counted ? key : 0, counted, wave_cnt, running, nkeys);
         if (counted && pos + 1 > a.capacity) a.pair_valid[p] = 0;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void index_body(const IndexArgs& a, int* wave_cnt, in
   for (int c0 = 0; c0 < npairs; c0 += IDX_THREADS) {
     const int p = c0 + tid;
     const bool in = p < npairs;
-    const int key = in ? a.topk_idx[p] : -1;
+    const int key = in ? IDX_AT(a, p) : -1;
     const bool counted = in && key >= 0 && key < E && (a.pair_valid ? a.pair_valid[p] != 0 : true);
     const int pos = chunk_rank(counted ? key : 0, counted, wave_cnt, running, nkeys);
     if (in) a.pair_slot[p] = pos;  // rank for now; rebased below
@@ -673,7 +674,7 @@ __device__ __forceinline__ void index_body(const IndexArgs& a, int* wave_cnt, in
   for (int p = tid; p < npairs; p += IDX_THREADS) {
     const int rk = a.pair_slot[p];
     if (rk >= 0) {
-      const int slot = offs[a.topk_idx[p]] + rk;
+      const int slot = offs[IDX_AT(a, p)] + rk;
       a.pair_slot[p] = slot;
       a.slot_token[slot] = p / K;
       a.slot_pair[slot] = p;
@@ -707,7 +708,7 @@ __device__ __forceinline__ void index_small(const IndexArgs& a, int* cnt /*LDS [
   const int E = a.E, K = a.K, T = a.T, npairs = T * K, ne = E + 1;
   for (int e = lane; e < ne; e += 64) cnt[e] = 0;
   const bool in = lane < npairs;
-  const int key = in ? a.topk_idx[lane] : -1;
+  const int key = in ? IDX_AT(a, lane) : -1;
   const bool counted = in && key >= 0 && key < E && (a.pair_valid ? a.pair_valid[lane] != 0 : true);
   int rank = 0;
   uint64_t todo = __ballot(counted);
@@ -960,18 +961,19 @@ __global__ __launch_bounds__(256) void ep_pack_kernel(EpPackArgs a) {
   const int row = blockIdx.x;
   const int d = row / a.cap_rows, pos = row % a.cap_rows;
   const int cnt = a.counts[d];
+  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
+  int32_t* tail = reinterpret_cast<int32_t*>(dst + a.H);
   if (pos >= cnt) {
-    if (threadIdx.x == 0) a.meta[row] = -1;
+    if (threadIdx.x == 0) tail[0] = -1;
     return;
   }
   const int pair = a.slot_pair[a.offsets[d] + pos];
   const int t = pair / a.K;
   if (threadIdx.x == 0) {
-    a.meta[row] = a.topk_idx[pair];
+    tail[0] = a.topk_idx[pair];
     a.pair_pos[pair] = row;
   }
   const T* src = reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
-  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.H;
   constexpr int EPV = DT<T>::EPV;
   for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
 }

@@ -254,13 +254,19 @@ class MoEEngine:
         return p.as_dict()
 
     # ---- expert parallel ---------------------------------------------------------------------
-    def ep_pack(self, x2: torch.Tensor, send: torch.Tensor, meta: torch.Tensor, send_counts: torch.Tensor, cap_rows: int):
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self.lib.moeinf_ep_pack(self._h, _ptr(x2), _ptr(send), _ptr(meta), _ptr(send_counts), cap_rows, stream))
+    def ep_row_elems(self) -> int:
+        n = C.c_int32()
+        check(self.lib.moeinf_ep_row_elems(self._h, C.byref(n)))
+        return n.value
 
-    def ep_expert_ffn(self, layer: int, recv: torch.Tensor, meta: torch.Tensor, y: torch.Tensor, cap_rows: int):
+    def ep_pack(self, x2: torch.Tensor, send: torch.Tensor, send_counts: Optional[torch.Tensor], cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self.lib.moeinf_ep_expert_ffn(self._h, layer, _ptr(recv), _ptr(meta), _ptr(y), cap_rows, stream))
+        check(self.lib.moeinf_ep_pack(self._h, _ptr(x2), _ptr(send), _ptr(send_counts) if send_counts is not None else None,
+                                      cap_rows, stream))
+
+    def ep_expert_ffn(self, layer: int, recv: torch.Tensor, y: torch.Tensor, cap_rows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_expert_ffn(self._h, layer, _ptr(recv), _ptr(y), cap_rows, stream))
 
     def ep_combine(self, x2: torch.Tensor, ret: torch.Tensor, out: torch.Tensor, cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

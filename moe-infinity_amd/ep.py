@@ -10,9 +10,10 @@ rows travel with one all-to-all each way (RCCL over xGMI; torch.distributed back
     owner  ->  all_to_all back  ->  deterministic combine (local)
 
 Buffers have a fixed per-peer capacity (tokens*K rows: worst case every pair goes to one rank), so
-the exchange needs no host-side size negotiation; padding rows carry expert id -1.  At decode sizes
-the exchange is latency-bound (KBs per peer), which is why payload and metadata are not
-size-negotiated.
+the exchange needs no host-side size negotiation.  Every exchange row is H activations plus a
+16-byte tail holding the row's expert id (-1 = padding), so payload and metadata cross the fabric
+in ONE all-to-all per direction: at decode sizes the exchange is latency-bound (KBs per peer) and the
+number of collectives is what matters.
 
 ``ops`` abstracts the four compute steps so the host logic here can be exercised on CPU with the
 gloo backend (tests/test_ep_gloo.py supplies oracle-backed ops); the product ops are
@@ -35,11 +36,14 @@ class HipEpOps:
 
         self.engine.forward(layer, x2, gate_w, flags=FWD_ROUTE_ONLY)
 
-    def pack(self, x2, send, meta, counts, cap_rows):
-        self.engine.ep_pack(x2, send, meta, counts, cap_rows)
+    def row_elems(self):
+        return self.engine.ep_row_elems()
 
-    def expert_ffn(self, layer, recv, meta, y, cap_rows):
-        self.engine.ep_expert_ffn(layer, recv, meta, y, cap_rows)
+    def pack(self, x2, send, counts, cap_rows):
+        self.engine.ep_pack(x2, send, counts, cap_rows)
+
+    def expert_ffn(self, layer, recv, y, cap_rows):
+        self.engine.ep_expert_ffn(layer, recv, y, cap_rows)
 
     def combine(self, x2, ret, out, cap_rows):
         self.engine.ep_combine(x2, ret, out, cap_rows)
@@ -56,9 +60,9 @@ class ExpertParallelMoE:
         self.cap_rows = max_tokens * top_k
         n = self.world * self.cap_rows
         mk = lambda *s, dt=dtype: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
-        self.send, self.recv, self.y, self.ret = mk(n, hidden), mk(n, hidden), mk(n, hidden), mk(n, hidden)
-        self.meta_send = mk(n, dt=torch.int32)
-        self.meta_recv = mk(n, dt=torch.int32)
+        ld = ops.row_elems()  # H + 16-byte tail (expert id)
+        self.send, self.recv = mk(n, ld), mk(n, ld)
+        self.y, self.ret = mk(n, hidden), mk(n, hidden)
         self.send_counts = mk(self.world, dt=torch.int32)
 
     def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, out: Optional[torch.Tensor] = None):
@@ -69,11 +73,10 @@ class ExpertParallelMoE:
         if out is None:
             out = torch.empty_like(x2)
         self.ops.route(layer, x2, gate_w)
-        self.ops.pack(x2, self.send, self.meta_send, self.send_counts, self.cap_rows)
-        # dispatch all-to-all: rows + expert ids, equal splits of cap_rows per peer
+        self.ops.pack(x2, self.send, self.send_counts, self.cap_rows)
+        # dispatch all-to-all: rows with their expert ids in the tail, equal splits of cap_rows per peer
         dist.all_to_all_single(self.recv, self.send, group=self.group)
-        dist.all_to_all_single(self.meta_recv, self.meta_send, group=self.group)
-        self.ops.expert_ffn(layer, self.recv, self.meta_recv, self.y, self.cap_rows)
+        self.ops.expert_ffn(layer, self.recv, self.y, self.cap_rows)
         # combine all-to-all: expert outputs return to the rows' home rank, same row positions
         dist.all_to_all_single(self.ret, self.y, group=self.group)
         self.ops.combine(x2, self.ret, out, self.cap_rows)

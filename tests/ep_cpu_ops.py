@@ -7,16 +7,26 @@ from oracle import moe_ref as R
 
 
 class OracleEpOps:
-    def __init__(self, experts_by_layer, rank, world, top_k, num_experts):
-        self.experts, self.rank, self.world, self.K, self.E = experts_by_layer, rank, world, top_k, num_experts
+    def __init__(self, experts_by_layer, rank, world, top_k, num_experts, hidden):
+        self.experts, self.rank, self.world, self.K, self.E, self.H = experts_by_layer, rank, world, top_k, num_experts, hidden
 
     def route(self, layer, x2, gate_w):
         self.sel, self.w, _ = R.route_mixtral(x2, gate_w, self.K)
 
-    def pack(self, x2, send, meta, counts, cap_rows):
+    def row_elems(self):
+        return self.H + 8  # bf16: 16-byte tail = 8 elements; first int32 of the tail = expert id
+
+    @staticmethod
+    def _meta(buf, H):
+        """int32 view of the first 4 bytes of every row's tail."""
+        return buf[:, H:H + 2].view(torch.int32).reshape(-1)
+
+    def pack(self, x2, send, counts, cap_rows):
         T = x2.shape[0]
-        meta.fill_(-1)
+        H = x2.shape[1]
         send.zero_()
+        meta = self._meta(send, H)
+        meta.fill_(-1)
         cnt = [0] * self.world
         self.pair_pos = torch.full((T, self.K), -1, dtype=torch.int64)
         for t in range(T):  # pair order = token-major, the order the dispatch-index kernel ranks in
@@ -25,17 +35,19 @@ class OracleEpOps:
                 d = e % self.world
                 row = d * cap_rows + cnt[d]
                 cnt[d] += 1
-                send[row] = x2[t]
+                send[row, :H] = x2[t]
                 meta[row] = e
                 self.pair_pos[t, k] = row
         counts.copy_(torch.tensor(cnt, dtype=counts.dtype))
 
-    def expert_ffn(self, layer, recv, meta, y, cap_rows):
+    def expert_ffn(self, layer, recv, y, cap_rows):
         y.zero_()
+        H = y.shape[1]
+        meta = self._meta(recv, H)
         for e in sorted({int(v) for v in meta.tolist() if v >= 0}):
             assert e % self.world == self.rank, "received rows for an expert this rank does not own"
             rows = (meta == e).nonzero().flatten()
-            y[rows] = R.expert_ffn(recv[rows], self.experts[layer][e], R.MIXTRAL_DENSE_ACT_DENSE)
+            y[rows] = R.expert_ffn(recv[rows][:, :H].contiguous(), self.experts[layer][e], R.MIXTRAL_DENSE_ACT_DENSE)
 
     def combine(self, x2, ret, out, cap_rows):
         T = x2.shape[0]

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
 
         h, f, e, k, t, L = 128, 256, 8, 2, 6, 2
         ws = [make_weights("mixtral", h, f, e, 50 + l, torch.bfloat16) for l in range(L)]
-        ops = OracleEpOps([w[1] for w in ws], rank, world, k, e)
+        ops = OracleEpOps([w[1] for w in ws], rank, world, k, e, h)
         ep = ExpertParallelMoE(ops, h, k, t, torch.bfloat16, "cpu")
         worst = 0.0
         for step in range(3):

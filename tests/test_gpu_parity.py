@@ -288,21 +288,22 @@ def test_ep_two_ranks_emulated_on_one_gpu():
     g = gate.to(DEV)
     xs = [acts(t, h, torch.bfloat16, 410 + r).to(DEV) for r, t in enumerate(ts)]
     mk = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
-    send = [mk(world * cap, h) for _ in range(world)]
-    meta = [mk(world * cap, dt=torch.int32) for _ in range(world)]
+    ld = engs[0].ep_row_elems()
+    assert ld == h + 8
+    send = [mk(world * cap, ld) for _ in range(world)]
     cnts = [mk(world, dt=torch.int32) for _ in range(world)]
     for r in range(world):
         engs[r].forward(0, xs[r], g, flags=FWD_ROUTE_ONLY)
-        engs[r].ep_pack(xs[r], send[r], meta[r], cnts[r], cap)
+        engs[r].ep_pack(xs[r], send[r], cnts[r], cap)
     torch.cuda.synchronize()
     # all_to_all: block d of rank r's send buffer becomes block r of rank d's receive buffer
-    recv = [torch.cat([send[src][dst * cap:(dst + 1) * cap] for src in range(world)]) for dst in range(world)]
-    mrecv = [torch.cat([meta[src][dst * cap:(dst + 1) * cap] for src in range(world)]) for dst in range(world)]
+    recv = [torch.cat([send[src][dst * cap:(dst + 1) * cap] for src in range(world)]).contiguous() for dst in range(world)]
     ys = [mk(world * cap, h) for _ in range(world)]
     for r in range(world):
-        owned = mrecv[r][mrecv[r] >= 0]
+        ids = recv[r][:, h:h + 2].contiguous().view(torch.int32).reshape(-1)
+        owned = ids[ids >= 0]
         assert bool((owned % world == r).all())
-        engs[r].ep_expert_ffn(0, recv[r].contiguous(), mrecv[r].contiguous(), ys[r], cap)
+        engs[r].ep_expert_ffn(0, recv[r], ys[r], cap)
     torch.cuda.synchronize()
     ret = [torch.cat([ys[src][dst * cap:(dst + 1) * cap] for src in range(world)]).contiguous() for dst in range(world)]
     for r in range(world):
