@@ -368,22 +368,67 @@ hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // route_topk: one wave per token.  E <= 256 (<= 4 experts per lane, expert id = lane + 64*j).
 // ------------------------------------------------------------------------------------------------
+// Wave-wide reductions on DPP (data-parallel primitives: register-to-register lane permutes on the
+// VALU) instead of __shfl_xor, which lowers to ds_bpermute through the LDS crossbar (~100+ cycles of
+// latency per step, and these chains are serial on the single wave that routes a token).
+// Inside a row of 16 lanes: swap neighbours, swap pairs, half-row mirror, row mirror -> every lane holds
+// the row result; the four row results are then read with v_readlane and combined on the scalar unit.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+#define MOEINF_ROW_REDUCE(OP)      \
+  OP(0xB1)  /* quad_perm [1,0,3,2] */ \
+  OP(0x4E)  /* quad_perm [2,3,0,1] */ \
+  OP(0x141) /* row_half_mirror */     \
+  OP(0x140) /* row_mirror */
 __device__ __forceinline__ float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+#define STEP(C) v = fmaxf(v, __uint_as_float(dpp_mov<C>(__float_as_uint(v))));
+  MOEINF_ROW_REDUCE(STEP)
+#undef STEP
+  const int b = __float_as_int(v);
+  float r = __int_as_float(__builtin_amdgcn_readlane(b, 0));
+  r = fmaxf(r, __int_as_float(__builtin_amdgcn_readlane(b, 16)));
+  r = fmaxf(r, __int_as_float(__builtin_amdgcn_readlane(b, 32)));
+  r = fmaxf(r, __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+  return r;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+#define STEP(C) v += __uint_as_float(dpp_mov<C>(__float_as_uint(v)));
+  MOEINF_ROW_REDUCE(STEP)
+#undef STEP
+  const int b = __float_as_int(v);
+  return ((__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+          __int_as_float(__builtin_amdgcn_readlane(b, 32))) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
 }
-// arg-max over the wave of (value desc, index asc); entries with idx < 0 never win
+// arg-max over the wave of (value desc, index asc); entries with idx < 0 never win.
+// (value, index) is packed into one order-preserving 64-bit key so a single max-reduction decides.
 __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o);
-    const int oi = __shfl_xor(idx, o);
-    const bool take = (oi >= 0) && (idx < 0 || ov > v || (ov == v && oi < idx));
-    if (take) { v = ov; idx = oi; }
+  uint32_t ub = __float_as_uint(v);
+  ub ^= (ub >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // monotone map float -> uint32 (handles negatives, -inf)
+  uint32_t hi = idx >= 0 ? ub : 0u;
+  uint32_t lo = idx >= 0 ? (0xFFFFFFFFu - (uint32_t)idx) : 0u;  // larger lo = smaller index
+#define STEP(C)                                                        \
+  {                                                                    \
+    const uint32_t oh = dpp_mov<C>(hi), ol = dpp_mov<C>(lo);           \
+    const bool take = (oh > hi) || (oh == hi && ol > lo);              \
+    hi = take ? oh : hi;                                               \
+    lo = take ? ol : lo;                                               \
   }
+  MOEINF_ROW_REDUCE(STEP)
+#undef STEP
+  uint32_t bh = 0, bl = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_readlane((int)hi, r * 16), ol = (uint32_t)__builtin_amdgcn_readlane((int)lo, r * 16);
+    const bool take = (oh > bh) || (oh == bh && ol > bl);
+    bh = take ? oh : bh;
+    bl = take ? ol : bl;
+  }
+  if (bh == 0 && bl == 0) { idx = -1; v = 0.f; return; }
+  idx = (int)(0xFFFFFFFFu - bl);
+  bh ^= (bh >> 31) ? 0x80000000u : 0xFFFFFFFFu;  // inverse map
+  v = __uint_as_float(bh);
 }
 // pick the best not-yet-taken entry among this lane's 4 and reduce
 __device__ __forceinline__ void pick_best(const float key[4], uint32_t taken, int lane, int E, float& bv, int& bi) {

@@ -65,3 +65,37 @@ def oracle_expert_rows(ref: R.BlockResult, e_total):
     """Oracle per-expert outputs concatenated in expert-sorted row order."""
     rows = [ref.expert_out[e] for e in range(e_total) if e in ref.expert_out]
     return torch.cat(rows, 0) if rows else None
+
+
+def block_magnitude(ref: R.BlockResult) -> torch.Tensor:
+    """Per output element: sum of |weighted expert contributions| (+ |shared expert|).  One rounding flip
+    in a contribution moves the block output by up to one ulp AT THE SCALE OF THAT CONTRIBUTION, which
+    can exceed an ulp of the (possibly cancelling) sum."""
+    out = ref.out.reshape(-1, ref.out.shape[-1]).float()
+    mag = torch.zeros_like(out)
+    if ref.weights_mask is not None:
+        wm = ref.weights_mask.reshape(out.shape[0], -1).float()
+        rm = ref.router_mask.reshape(out.shape[0], -1).bool()
+        for e, y in ref.expert_out.items():
+            tok = rm[:, e]
+            mag[tok] += (y.float() * wm[tok, e][:, None]).abs()
+    if "shared_out" in ref.extra:
+        mag += ref.extra["shared_out"].reshape(out.shape).float().abs()
+    return mag.reshape(ref.out.shape)
+
+
+def assert_block_close(got, ref: R.BlockResult, dtype, what, golden=None):
+    """Block-output bar (bf16): |err| <= ulp * (2 * sum_k |contribution_k| + |result|) per element, ulp =
+    2^-7 relative: an expert output that differs by one rounding flip (accumulation order) passes
+    through two more roundings (Tr(y*w), Tr(acc + prod)), each able to move the value by one ulp at
+    its own scale; plus mean relative error <= 1e-3 (north_star's tolerance).  fp32: 2e-5 relative.
+    `golden`: optionally the reference block's own output to compare against instead of the oracle's."""
+    want = (golden if golden is not None else ref.out).float().cpu().reshape(ref.out.shape)
+    got = got.float().cpu().reshape(ref.out.shape)
+    scale = 2.0 * block_magnitude(ref) + torch.maximum(want.abs(), want.abs().mean())
+    tol = scale * (2e-5 if dtype == torch.float32 else 2.0 ** -7) + 1e-30
+    err = (got - want).abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} elements beyond tolerance, worst {float((err / tol).max()):.2f}x"
+    rel = err.mean().item() / (want.abs().mean().item() + 1e-30)
+    assert rel <= 1e-3, f"{what}: mean relative error {rel:.2e} > 1e-3"

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import R, acts, assert_model_close, engine_for, make_weights, register_all
+from helpers import R, acts, assert_block_close, assert_model_close, engine_for, make_weights, register_all
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -38,7 +38,7 @@ def test_dispatch_local_like_the_reference_blocks_use_it():
             assert_model_close(out, ref.expert_out[idx], torch.bfloat16, f"expert {idx} output")
             tok = router_mask[:, idx]
             final[tok, :] += out.cpu() * weights_mask[tok, idx][:, None]  # mixtral.py:96-101
-        assert_model_close(final, ref.out[0], torch.bfloat16, "python-combined block output", ulps=2.0)
+        assert_block_close(final, ref, torch.bfloat16, "python-combined block output")
     eng.close()
 
 
@@ -60,7 +60,7 @@ def test_sync_mixtral_block_returns_what_the_reference_block_returns():
     ref = R.block_mixtral(x, gate, experts, top_k=k)
     assert out.shape == x.shape and router_logits.shape == (10, e)
     assert torch.equal(router_logits.float().cpu(), ref.logits.float())
-    assert_model_close(out, ref.out, torch.bfloat16, "block output", ulps=2.0)
+    assert_block_close(out, ref, torch.bfloat16, "block output")
     eng.close()
 
 
@@ -82,7 +82,7 @@ def test_deepseek_and_switch_and_nllb_blocks():
     blk.attach_engine(eng, 0)
     blk.register_experts(experts, shared)
     x = acts(6, h, torch.bfloat16, 521).reshape(1, 6, h)
-    assert_model_close(blk(x.to(DEV)), R.block_deepseek(x, gate, experts, k, shared=shared).out, torch.bfloat16, "deepseek block", ulps=2.0)
+    assert_block_close(blk(x.to(DEV)), R.block_deepseek(x, gate, experts, k, shared=shared), torch.bfloat16, "deepseek block")
     eng.close()
     # switch (fp32)
     e = 8
@@ -99,7 +99,7 @@ def test_deepseek_and_switch_and_nllb_blocks():
     ref = R.block_switch(x, gate, experts, expert_capacity=3)
     assert logits.shape == (2, 12, e) and expert_index.shape == (2, 12)
     assert int((ref.router_mask.sum(-1) == 0).sum()) > 0, "the case must exercise capacity drops"
-    assert_model_close(out, ref.out, torch.float32, "switch block", ulps=2.0)
+    assert_block_close(out, ref, torch.float32, "switch block")
     eng.close()
     # nllb
     e = 16
@@ -116,7 +116,7 @@ def test_deepseek_and_switch_and_nllb_blocks():
     ref = R.block_nllb(x, gate, experts)
     assert torch.equal(router_probs.bool().cpu(), ref.weights_mask.bool())
     assert torch.equal(top1.cpu(), torch.argmax(ref.extra["top_1_mask"], dim=-1))
-    assert_model_close(out, ref.out, torch.bfloat16, "nllb block", ulps=2.0)
+    assert_block_close(out, ref, torch.bfloat16, "nllb block")
     eng.close()
 
 
@@ -163,7 +163,7 @@ def test_predictor_and_prefetcher_drive_the_engine():
         for l in range(L):
             out, _ = blocks[l](xs[s][l].to(DEV)[None])
             ref = R.block_mixtral(xs[s][l][None], ws[l][0], ws[l][1], top_k=k)
-            assert_model_close(out, ref.out, torch.bfloat16, f"step {s} layer {l}", ulps=2.0)
+            assert_block_close(out, ref, torch.bfloat16, f"step {s} layer {l}")
     st = eng.stats()
     assert st["prefetch_issued"] > 0 and st["prefetch_useful"] > 0
     assert st["expert_hits"] + st["expert_misses"] == 6 * L * k  # every dispatch accounted for exactly once
