@@ -59,11 +59,21 @@ class ExpertPrefetcher:
     def fetch_experts_lock_cache(self, layer_id, expert_list):
         self.archer_engine.protect([(layer_id, int(e)) for e in expert_list])
 
-    def prefetch_experts(self, layer_id, expert_matrix, max_experts=None):
+    def prefetch_experts(self, layer_id, expert_matrix, max_experts=None, min_share=0.0, lookahead=None):
         """expert_prefetcher.py:42-59: every (layer >= layer_id, expert) with a positive score, by
         descending score: replace_cache_candidates(all) then enqueue_prefetch(each) in that order."""
         ls, es, sc = self._native.prefetch_order(layer_id, expert_matrix)
-        if max_experts is not None:  # addition: cap the list (the reference enqueues everything it predicts)
+        # additions (the reference enqueues everything it predicts, which thrashes a small cache):
+        #   min_share  keep an expert only if it holds >= this share of its layer's predicted activations
+        #   lookahead  keep only layers < layer_id + lookahead
+        #   max_experts cap the list
+        if min_share > 0.0 or lookahead is not None:
+            m = np.asarray(expert_matrix, dtype=np.float64)
+            share = m / np.maximum(m.sum(axis=1, keepdims=True), 1e-30)
+            keep = np.array([share[l, e] >= min_share and (lookahead is None or l < layer_id + lookahead)
+                             for l, e in zip(ls, es)], dtype=bool) if len(ls) else np.zeros(0, bool)
+            ls, es, sc = ls[keep], es[keep], sc[keep]
+        if max_experts is not None:
             ls, es, sc = ls[:max_experts], es[:max_experts], sc[:max_experts]
         self.archer_engine.protect(list(zip(ls.tolist(), es.tolist())))
         i = 0
