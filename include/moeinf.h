@@ -261,6 +261,32 @@ int moeinf_tracer_prefetch_order(const moeinf_tracer* tr, int layer, const float
                                  int32_t* experts_out, float* scores_out, int32_t* n_out);
 int moeinf_tracer_get_eam(moeinf_tracer* tr, int64_t seq_id, double* eam_out);
 
+/* ---- disk tier: the reference's offload directory (host only) ----------------
+ * Reads and writes `<offload_path>/archer_index` + `archer_param_<n>` in the reference's own format
+ * (core/aio/archer_tensor_index.cpp:11-25,51-67,101-132; archer_tensor_handle.cpp:53-86), so directories
+ * produced by MoE-Infinity load here and vice versa.  scalar_type = c10::ScalarType code
+ * (Float 6, Half 5, BFloat16 15, ...). */
+typedef struct moeinf_store moeinf_store;
+int moeinf_store_open(const char* offload_path, moeinf_store** out); /* ArcherTensorHandle ctor (archer_tensor_handle.cpp:23-51) */
+int moeinf_store_close(moeinf_store* st);                            /* flushes the index if it changed */
+/* prefetch_handle.offload(tensor, id) = StoreTensor (archer_tensor_handle.cpp:53-86) */
+int moeinf_store_put(moeinf_store* st, uint32_t tensor_id, const void* data, uint64_t nbytes, const int64_t* dims,
+                     int ndim, int scalar_type);
+int moeinf_store_flush(moeinf_store* st); /* ArcherTensorIndex::Serialize */
+int moeinf_store_count(const moeinf_store* st, int64_t* n);
+int moeinf_store_ids(const moeinf_store* st, uint32_t* ids_out, int64_t capacity);
+/* prefetch_handle.is_tensor_offloaded(id) + index lookup: *found = 0/1; dims_out has room for 8 dims */
+int moeinf_store_meta(const moeinf_store* st, uint32_t tensor_id, int32_t* found, uint64_t* nbytes, int64_t* offset,
+                      int32_t* ndim, int64_t* dims_out, int32_t* scalar_type);
+/* ReadTensor (archer_tensor_handle.cpp:189-201): payload -> dst (O_DIRECT when dst is 4 KiB-aligned and
+ * has room for the 4 KiB-padded size) */
+int moeinf_store_get(const moeinf_store* st, uint32_t tensor_id, void* dst, uint64_t capacity);
+/* Node::SetDevice disk->host leg (model_topology.cpp:76-100, SetModuleMemoryFromDisk :647-674):
+ * read the n tensors of one expert (tensor_ids in blob order, as expert_dispatcher.register_expert
+ * receives them) from the store straight into the expert's pinned arena blob. */
+int moeinf_register_expert_from_store(moeinf_engine* eng, int layer, int expert, const moeinf_store* st,
+                                      const uint32_t* tensor_ids, int n);
+
 /* ---- cache-policy simulator (host only, no GPU) --------------------------------------------
  * The engine's replacement policy as a standalone object, so the policy can be checked against
  * the oracle without a device (tests -m "not gpu"). ids are arbitrary non-negative ints. */

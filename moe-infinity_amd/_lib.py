@@ -95,6 +95,15 @@ PROTOTYPES = {
     "moeinf_tracer_predict": (C.c_int, [_P, C.c_int64, C.c_int, _I32P, C.c_int, _F32P, _I32P]),
     "moeinf_tracer_prefetch_order": (C.c_int, [_P, C.c_int, _F32P, _I32P, _I32P, _F32P, _I32P]),
     "moeinf_tracer_get_eam": (C.c_int, [_P, C.c_int64, _F64P]),
+    "moeinf_store_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "moeinf_store_close": (C.c_int, [_P]),
+    "moeinf_store_put": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _I64P, C.c_int, C.c_int]),
+    "moeinf_store_flush": (C.c_int, [_P]),
+    "moeinf_store_count": (C.c_int, [_P, _I64P]),
+    "moeinf_store_ids": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int64]),
+    "moeinf_store_meta": (C.c_int, [_P, C.c_uint32, _I32P, C.POINTER(C.c_uint64), _I64P, _I32P, _I64P, _I32P]),
+    "moeinf_store_get": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64]),
+    "moeinf_register_expert_from_store": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_uint32), C.c_int]),
     "moeinf_cache_sim_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "moeinf_cache_sim_destroy": (C.c_int, [_P]),
     "moeinf_cache_sim_access": (C.c_int, [_P, C.c_int64, _I32P, _I64P]),

@@ -22,6 +22,7 @@
 #include "../../include/moeinf.h"
 #include "cache_policy.h"
 #include "kernels.h"
+#include "offload_store.h"
 #include "tracer.h"
 
 using namespace moeinf;
@@ -1099,6 +1100,84 @@ extern "C" int moeinf_reset_stats(moeinf_engine* g) {
   const int64_t st = g->st.slots_total, su = g->st.slots_used, sb = g->st.slot_bytes, ha = g->st.host_arena_bytes;
   memset(&g->st, 0, sizeof g->st);
   g->st.slots_total = st; g->st.slots_used = su; g->st.slot_bytes = sb; g->st.host_arena_bytes = ha;
+  return MOEINF_OK;
+}
+
+// ---- disk tier -------------------------------------------------------------------------------
+struct moeinf_store { OffloadStore s; };
+extern "C" int moeinf_store_open(const char* path, moeinf_store** out) {
+  if (!path || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  moeinf_store* st = new moeinf_store();
+  const std::string err = st->s.open(path);
+  if (!err.empty()) { delete st; return fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
+  *out = st;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_store_close(moeinf_store* st) {
+  if (!st) return MOEINF_OK;
+  int rc = MOEINF_OK;
+  if (st->s.dirty()) { const std::string err = st->s.flush(); if (!err.empty()) rc = fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
+  delete st;
+  return rc;
+}
+extern "C" int moeinf_store_put(moeinf_store* st, uint32_t id, const void* data, uint64_t nbytes, const int64_t* dims, int ndim, int scalar_type) {
+  if (!st || !data || ndim < 0 || ndim > 8 || (ndim > 0 && !dims)) return fail(MOEINF_ERR_INVALID, "bad store_put arguments");
+  const std::string err = st->s.put(id, data, nbytes, dims, ndim, scalar_type);
+  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+}
+extern "C" int moeinf_store_flush(moeinf_store* st) {
+  if (!st) return fail(MOEINF_ERR_INVALID, "store is NULL");
+  const std::string err = st->s.flush();
+  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+}
+extern "C" int moeinf_store_count(const moeinf_store* st, int64_t* n) {
+  if (!st || !n) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  *n = (int64_t)st->s.count();
+  return MOEINF_OK;
+}
+extern "C" int moeinf_store_ids(const moeinf_store* st, uint32_t* ids_out, int64_t capacity) {
+  if (!st || !ids_out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const auto v = st->s.ids();
+  if ((int64_t)v.size() > capacity) return fail(MOEINF_ERR_INVALID, "ids_out holds %lld ids, store has %zu", (long long)capacity, v.size());
+  std::copy(v.begin(), v.end(), ids_out);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_store_meta(const moeinf_store* st, uint32_t id, int32_t* found, uint64_t* nbytes, int64_t* offset, int32_t* ndim, int64_t* dims_out, int32_t* scalar_type) {
+  if (!st || !found) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const TensorMeta* m = st->s.find(id);
+  *found = m ? 1 : 0;
+  if (!m) return MOEINF_OK;
+  if (nbytes) *nbytes = m->size;
+  if (offset) *offset = m->offset;
+  if (ndim) *ndim = (int32_t)m->shape.size();
+  if (dims_out) for (size_t i = 0; i < m->shape.size() && i < 8; ++i) dims_out[i] = m->shape[i];
+  if (scalar_type) *scalar_type = m->dtype;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_store_get(const moeinf_store* st, uint32_t id, void* dst, uint64_t capacity) {
+  if (!st || !dst) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const std::string err = st->s.get(id, dst, capacity);
+  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+}
+extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, int expert, const moeinf_store* st, const uint32_t* tensor_ids, int n) {
+  CHK(check_le(g, layer, expert));
+  if (!st || !tensor_ids) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (!owns(g, expert)) return fail(MOEINF_ERR_INVALID, "expert %d is not owned by ep_rank %d of %d", expert, g->cfg.ep_rank, g->cfg.ep_size);
+  if (n != g->lay.n) return fail(MOEINF_ERR_INVALID, "expert type %d has %d tensors, got %d ids", g->cfg.expert_type, g->lay.n, n);
+  for (int i = 0; i < n; ++i) {
+    const TensorMeta* m = st->s.find(tensor_ids[i]);
+    if (!m) return fail(MOEINF_ERR_INVALID, "tensor %u is not in the offload index", tensor_ids[i]);
+    if ((int64_t)m->size != g->lay.size[i]) return fail(MOEINF_ERR_INVALID, "tensor %u is %llu bytes on disk, blob slot %d needs %lld", tensor_ids[i], (unsigned long long)m->size, i, (long long)g->lay.size[i]);
+  }
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  Node& nd = g->nodes[node_index(g, layer, expert)];
+  if (!nd.host) CHK(arena_alloc(g, g->lay.total, &nd.host));
+  for (int i = 0; i < n; ++i) {
+    // each tensor's region in the blob is 4 KiB aligned and padded -> eligible for O_DIRECT
+    const uint64_t room = (uint64_t)((i + 1 < n ? g->lay.off[i + 1] : g->lay.total) - g->lay.off[i]);
+    const std::string err = st->s.get(tensor_ids[i], (char*)nd.host + g->lay.off[i], room);
+    if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+  }
   return MOEINF_OK;
 }
 

@@ -168,3 +168,35 @@ def test_predictor_and_prefetcher_drive_the_engine():
     assert st["prefetch_issued"] > 0 and st["prefetch_useful"] > 0
     assert st["expert_hits"] + st["expert_misses"] == 6 * L * k  # every dispatch accounted for exactly once
     eng.close()
+
+
+def test_experts_loaded_from_a_reference_format_offload_directory(tmp_path):
+    """disk tier -> pinned arena -> HBM: experts written with prefetch_handle.offload() semantics into an
+    archer_index/archer_param directory are registered by tensor id (blob order) and give the same block
+    output as the in-memory registration."""
+    from moe_infinity_amd.offload_store import OffloadStore
+
+    h, f, e, k, t = 256, 512, 8, 2, 6
+    gate, experts, _ = make_weights("mixtral", h, f, e, 700, torch.bfloat16)
+    st = OffloadStore(str(tmp_path))
+    ids, tid = {}, 10
+    for i, ex in enumerate(experts):  # tensor ids in named_parameters order: w1, w2, w3 (model_offload.py:645-671)
+        ids[i] = []
+        for w in ex:
+            st.offload(w, tid)
+            ids[i].append(tid)
+            tid += 1
+    st.close()
+    st = OffloadStore(str(tmp_path))  # reopen: the index is parsed from disk
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    for i in range(e):
+        st.register_expert(eng, 0, i, ids[i])
+    x = acts(t, h, torch.bfloat16, 701)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    assert_block_close(out, ref, torch.bfloat16, "block output from a disk-loaded model")
+    from moe_infinity_amd import MoeInfError
+    with pytest.raises(MoeInfError):
+        st.register_expert(eng, 0, 0, [ids[0][0], 9999, ids[0][2]])  # unknown tensor id
+    eng.close()
+    st.close()
