@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--budget-gib", type=float, default=0.0, help="explicit expert-cache budget (miss-heavy runs)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of MoE layers (0 = the model's)")
     ap.add_argument("--policy", default="lfu_incache", choices=["lfu_incache", "lru"])
+    ap.add_argument("--prompt", type=int, default=512, help="prefill length run once before decoding (examples/interface_example.py protocol); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
     ap.add_argument("--cpu-sample-layers", type=int, default=4)
@@ -147,7 +148,7 @@ def main():
     cfg = getattr(Cf, factory)(device_id=local_rank, device_memory_ratio=args.ratio,
                                device_memory_bytes=int(args.budget_gib * 2**30),
                                policy=Cf.POLICY_LRU if args.policy == "lru" else Cf.POLICY_LFU_INCACHE,
-                               ep_rank=rank, ep_size=world, max_tokens=B * world)
+                               ep_rank=rank, ep_size=world, max_tokens=max(B * world, B * args.prompt if world == 1 else 0))
     if args.layers:
         cfg.num_layers = args.layers
     L, E, K, H = cfg.num_layers, cfg.num_experts, cfg.top_k, cfg.hidden
@@ -199,6 +200,21 @@ def main():
     eng.sync_copies()
     log(f"cache warm ({eng.stats()['slots_used']} experts resident) in {time.time() - t0:.1f}s, h2d {eng.stats()['h2d_bytes'] / 2**30:.1f} GiB, copy-busy {eng.stats()['h2d_busy_ms']:.0f} ms")
     warm = eng.stats()
+    # prefill of the prompt (B sequences x --prompt tokens) through every layer: exercises the large-T
+    # path; timed separately, NOT part of `value`
+    prefill_ms = None
+    if args.prompt > 0 and not use_ep:
+        xp = acts(B * args.prompt, H, dt, 777).to(dev)
+        outp = torch.empty_like(xp)
+        for l in range(L):  # untimed pass: makes every expert the prompt touches resident
+            eng.forward(l, xp, gates[l], batch_rows=batch_rows, out=outp)
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter()
+        for l in range(L):
+            eng.forward(l, xp, gates[l], batch_rows=batch_rows, out=outp)
+        torch.cuda.synchronize(dev)
+        prefill_ms = (time.perf_counter() - tp) * 1e3
+        del xp, outp
     run_steps(0, args.warmup)
     eng.sync_copies()
     fence()
@@ -324,6 +340,8 @@ def main():
                                    + (f", expert-cache budget {args.budget_gib} GiB" if args.budget_gib else ""),
                        "parallelism": f"ep{world}" if use_ep else "single", "per_token_decode_latency_ms": round(ms_per_step, 4),
                        "cache_policy": args.policy},
+            "prefill": None if prefill_ms is None else {"tokens": B * args.prompt, "ms_all_layers": round(prefill_ms, 2),
+                                                        "tokens_per_s": round(B * args.prompt / prefill_ms * 1e3, 1)},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,
