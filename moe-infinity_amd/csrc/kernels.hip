@@ -247,6 +247,152 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ffn_gemm: the same stage for experts with MANY tokens (prefill, large batches) — a register-tiled
+// grouped GEMM on MFMA.  A block owns RG row groups (16*RG weight rows, for the gated stage of BOTH
+// matrices) and walks the expert's tokens 64 at a time; per k-tile a wave issues RG*NMAT weight-tile
+// loads (contiguous 1 KiB each, the tiled layout IS the MFMA A fragment) + 4 activation-fragment loads
+// and RG*NMAT*4 MFMAs — 16 MFMAs per 8 loads, against 8 per 6 in ffn_rows' 64-token variant — and the
+// next k-tile's fragments are loaded into a second register set BEFORE the current MFMAs issue, so the
+// L2 latency hides behind the matrix pipe even at 2-3 waves per SIMD.  K is split over the block's
+// waves (no operand is loaded twice inside a block); partial tiles meet in LDS for the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NMAT, int RG, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int EPT = 4 * EPV;
+  // NT = token groups (16 tokens each) per pass over the weights.  At t_e < ridge (~300 tokens) the stage
+  // is still bound by HBM weight traffic, so the launcher picks NT to cover an expert's tokens in as few
+  // passes as possible (weights stream from HBM once per pass; activations are re-read from L2).
+  __shared__ float red[NW][NMAT][256];
+
+  const int u = blockIdx.y;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int rg0 = blockIdx.x * RG;  // first row group of this block
+  if (rg0 * 16 >= R) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int KB = (K + EPT - 1) / EPT, KBfull = K / EPT;
+  const int nrg = min(RG, (R + 15) / 16 - rg0);  // live row groups (block-uniform)
+  const char* a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg0 * KB * 1024 + lane * 16;
+  const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg0 * KB * 1024 + lane * 16 : nullptr;
+  const size_t rg_stride = (size_t)KB * 1024;
+  const int kq = q * EPV;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+
+  for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NT) {
+    const int ntl = min(NT, (cnt - tile0 * 16 + 15) / 16);
+    const T* xr[NT];
+    f32x4 acc[RG][NT][NMAT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int srow = off + min((tile0 + tt) * 16 + n, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      xr[tt] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) acc[rg][tt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 ca[RG][NMAT], cx[NT], na[RG][NMAT], nx[NT];
+    auto load_frags = [&](u32x4 (&fa)[RG][NMAT], u32x4 (&fx)[NT], int kb, bool guard_x) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        if (rg < nrg) {
+          fa[rg][0] = ld16(a0 + rg * rg_stride + (size_t)kb * 1024);
+          if (NMAT == 2) fa[rg][1] = ld16(a1 + rg * rg_stride + (size_t)kb * 1024);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+        if (tt < ntl) fx[tt] = (!guard_x || kb * EPT + kq < K) ? ld16(xr[tt] + (size_t)kb * EPT) : z;
+    };
+    auto mma_frags = [&](const u32x4 (&fa)[RG][NMAT], const u32x4 (&fx)[NT]) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        if (rg < nrg) {
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            if (tt < ntl) {
+              mma16<T>(acc[rg][tt][0], fa[rg][0], fx[tt]);
+              if (NMAT == 2) mma16<T>(acc[rg][tt][1], fa[rg][1], fx[tt]);
+            }
+          }
+        }
+      }
+    };
+    // k-tiles wave, wave+NW, ... (the zero-padded last tile, if any, is just one more tile with a guarded x read)
+    int kb = wave;
+    if (kb < KB) load_frags(ca, cx, kb, kb >= KBfull);
+    for (; kb < KB; kb += NW) {
+      const int nk = kb + NW;
+      if (nk < KB) load_frags(na, nx, nk, nk >= KBfull);
+      mma_frags(ca, cx);
+      if (nk < KB) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) ca[rg][m] = na[rg][m];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) cx[tt] = nx[tt];
+      }
+    }
+    // reduction over the K split + epilogue, one 16x16 tile at a time
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+      if (rg >= nrg) break;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt >= ntl) break;
+        const int tile = tile0 + tt;
+        const int r0 = (rg0 + rg) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[wave][0][lane * 4 + j] = acc[rg][tt][0][j];
+          if (NMAT == 2) red[wave][1][lane * 4 + j] = acc[rg][tt][1][j];
+        }
+        __syncthreads();
+        for (int i = tid; i < 256; i += NW * 64) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) {
+            s0 += red[ww][0][i];
+            if (NMAT == 2) s1 += red[ww][1][i];
+          }
+          const int l = i >> 2, j = i & 3;
+          const int tn = l & 15;
+          const int orow = r0 + (l >> 4) * 4 + j;
+          if (tile * 16 + tn < cnt && orow < R) {
+            float v = DT<T>::round(s0);
+            if (s.epi == EPI_GATED_SILU) {
+              const float b = DT<T>::round(s1);
+              const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+              v = DT<T>::round(sl * b);
+            } else {
+              if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
+                v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+              if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            }
+            DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // tuning knobs (overridable for sweeps: MOEINF_FFN_NW=4|8, MOEINF_FFN_U=2|4|8)
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -254,10 +400,23 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <typename T, int NMAT>
-static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, hipStream_t st) {
+static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, int max_rows, hipStream_t st) {
 #define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
-  if (many_tokens) {  // up to 64 tokens per pass over an expert's weights
-    if (nw == 8) LAUNCH(8, 1, 4); else LAUNCH(4, 1, 4);
+  if (many_tokens) {  // register-tiled grouped GEMM; 16 accumulator tiles per wave in every shape
+    static const int use_gemm = env_int("MOEINF_FFN_GEMM", 1);
+    static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
+    if (use_gemm) {
+      const int nt = force_nt ? force_nt : 4;  // measured: (RG,NT)=(2,4)/(4,4) beats (1,8)/(2,8) at t_e ~128 (profiles/r01_ffn_sweep_prefill_gemm.txt)
+      if constexpr (NMAT == 2) {  // gated: 2 matrices -> (RG, NT) = (2,4) or (1,8)
+        if (nt <= 4) hipLaunchKernelGGL((ffn_gemm_kernel<T, 2, 2, 4, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
+        else hipLaunchKernelGGL((ffn_gemm_kernel<T, 2, 1, 8, 4>), grid, dim3(256), 0, st, s);
+      } else {                    // plain: (4,4) or (2,8)
+        if (nt <= 4) hipLaunchKernelGGL((ffn_gemm_kernel<T, 1, 4, 4, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+        else hipLaunchKernelGGL((ffn_gemm_kernel<T, 1, 2, 8, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
+      }
+    } else {
+      if (nw == 8) LAUNCH(8, 1, 4); else LAUNCH(4, 1, 4);
+    }
     return;
   }
   if (nw == 8) { if (u == 2) LAUNCH(8, 2, 1); else if (u == 8) LAUNCH(8, 8, 1); else LAUNCH(8, 4, 1); }
@@ -279,9 +438,9 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   // the 64-token variant runs at low occupancy (~240 VGPRs): it only pays once an expert needs >= 3 token tiles
   const bool many = env_nt ? env_nt > 1 : max_rows_per_expert > 32;
   if (s.dtype == DT_BF16) {
-    if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, st);
+    if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   } else {
-    if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, many, st); else launch_ffn_t<float, 1>(s, grid, nw, u, many, st);
+    if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<float, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   }
   return hipGetLastError();
 }
