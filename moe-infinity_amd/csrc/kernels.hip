@@ -393,6 +393,171 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ffn_gemm_lds: grouped GEMM for experts with many tokens, operands staged through LDS by the
+// asynchronous global->LDS DMA (global_load_lds, 16 B per lane) in a two-buffer ring.
+//   block = 4 waves as 2 (row halves) x 2 (token halves); block tile = RGB row groups x 8 token groups
+//   (gated: 64 rows of BOTH matrices x 128 tokens; plain: 128 rows x 128 tokens); every wave owns 16
+//   accumulator tiles; a stage = 2 k-tiles = 32 one-KiB tiles.
+//   Both operand images in LDS are in MFMA FRAGMENT ORDER (bytes [16*lane, +16) of a 1-KiB tile belong
+//   to lane `lane`): the weight tiles already are (tiled HBM layout, a contiguous 1-KiB DMA), and an
+//   activation tile becomes one DMA whose per-lane SOURCE address is x[token lane%16][k + (lane/16)*8]
+//   — the DMA writes base + lane*16, which is exactly the fragment slot.  Fragment reads are therefore
+//   linear ds_read_b128 at lane*16: conflict-free, no swizzle, no transpose.
+//   Loop: barrier (stage s landed, stage s-1 fully consumed) -> issue DMA of stage s+1 -> 32 MFMAs per
+//   wave on stage s.  Requires K % (k-tile) == 0 (no zero-fill path for the activations).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NMAT, int RGB>
+__global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int EPT = 4 * EPV;
+  constexpr int RGW = RGB / 2;
+  constexpr int NTB = 8, NTW = 4;
+  constexpr int KK = 2;
+  constexpr int A_TILES = KK * NMAT * RGB;
+  constexpr int B_TILES = KK * NTB;
+  constexpr int STAGE = (A_TILES + B_TILES) * 1024;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int u = blockIdx.y;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int rg0 = blockIdx.x * RGB;
+  const int nrg_total = (R + 15) / 16;
+  if (rg0 >= nrg_total) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int n = lane & 15, q = lane >> 4;
+  const int KB = K / EPT;  // K % EPT == 0 (checked by the launcher)
+  const int KS = (KB + KK - 1) / KK;
+  const size_t rg_stride = (size_t)KB * 1024;
+  const char* am[NMAT];
+  am[0] = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg0 * rg_stride + lane * 16;
+  if (NMAT == 2) am[NMAT - 1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg0 * rg_stride + lane * 16;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
+    const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);
+    // activation rows this wave DMA-loads: token groups `wave` and `wave + 4`
+    const T* xrp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int srow = off + min((tile0 + wave + 4 * i) * 16 + n, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + q * EPV;
+    }
+    f32x4 acc[RGW][NTW][NMAT];
+#pragma unroll
+    for (int a = 0; a < RGW; ++a)
+#pragma unroll
+      for (int b = 0; b < NTW; ++b)
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) acc[a][b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int ks, int buf) {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int kb = ks * KK + kk;
+        if (kb < KB) {
+#pragma unroll
+          for (int i = 0; i < RGB / 4; ++i) {
+            const int rg_l = wave + 4 * i;
+            if (rg0 + rg_l < nrg_total) {
+#pragma unroll
+              for (int m = 0; m < NMAT; ++m)
+                __builtin_amdgcn_global_load_lds((gptr_t)(am[m] + rg_l * rg_stride + (size_t)kb * 1024),
+                                                 (lptr_t)(base + ((kk * NMAT + m) * RGB + rg_l) * 1024), 16, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int tg_l = wave + 4 * i;
+            if (tg_l < ntl)
+              __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT),
+                                               (lptr_t)(base + (A_TILES + kk * NTB + tg_l) * 1024), 16, 0, 0);
+          }
+        }
+      }
+    };
+
+    issue(0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
+      __syncthreads();                                   // ... everybody's has, and stage ks-1 is fully consumed
+      if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);
+      const char* base = smem + (ks & 1) * STAGE + lane * 16;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        if (ks * KK + kk < KB) {
+          u32x4 af[RGW][NMAT], bf[NTW];
+#pragma unroll
+          for (int a = 0; a < RGW; ++a) {
+            const int rg_l = wr * RGW + a;
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) af[a][m] = *reinterpret_cast<const u32x4*>(base + ((kk * NMAT + m) * RGB + rg_l) * 1024);
+          }
+#pragma unroll
+          for (int b = 0; b < NTW; ++b) bf[b] = *reinterpret_cast<const u32x4*>(base + (A_TILES + kk * NTB + wc * NTW + b) * 1024);
+#pragma unroll
+          for (int a = 0; a < RGW; ++a) {
+            if (rg0 + wr * RGW + a < nrg_total) {
+#pragma unroll
+              for (int b = 0; b < NTW; ++b) {
+                if (wc * NTW + b < ntl) {
+                  mma16<T>(acc[a][b][0], af[a][0], bf[b]);
+                  if (NMAT == 2) mma16<T>(acc[a][b][NMAT - 1], af[a][NMAT - 1], bf[b]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // epilogue straight from the accumulators (no K split): lane holds 4 consecutive rows of one token
+#pragma unroll
+    for (int a = 0; a < RGW; ++a) {
+      const int r0 = (rg0 + wr * RGW + a) * 16 + q * 4;
+#pragma unroll
+      for (int b = 0; b < NTW; ++b) {
+        const int tok = (tile0 + wc * NTW + b) * 16 + n;
+        if (tok < cnt && rg0 + wr * RGW + a < nrg_total) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int orow = r0 + j;
+            if (orow < R) {
+              float v = DT<T>::round(acc[a][b][0][j]);
+              if (s.epi == EPI_GATED_SILU) {
+                const float bb = DT<T>::round(acc[a][b][NMAT - 1][j]);
+                const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+                v = DT<T>::round(sl * bb);
+              } else {
+                if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
+                  v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+              }
+              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tok) * s.ld_out + orow, v);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next pass re-uses buffer 0
+  }
+}
+
 // tuning knobs (overridable for sweeps: MOEINF_FFN_NW=4|8, MOEINF_FFN_U=2|4|8)
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -403,9 +568,21 @@ template <typename T, int NMAT>
 static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, int max_rows, hipStream_t st) {
 #define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
   if (many_tokens) {  // register-tiled grouped GEMM; 16 accumulator tiles per wave in every shape
-    static const int use_gemm = env_int("MOEINF_FFN_GEMM", 1);
+    static const int use_gemm = env_int("MOEINF_FFN_GEMM", 2);
     static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
-    if (use_gemm) {
+    const int ept = sizeof(T) == 2 ? 32 : 16;
+    const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
+    if (use_gemm == 2 && k_ok) {  // LDS-staged grouped GEMM
+      static const int rgb_plain = env_int("MOEINF_FFN_GEMM_RGB", 0);
+      if constexpr (NMAT == 2) {
+        hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 2, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+      } else {
+        // 128-row blocks need >= 2 blocks per CU to hide the DMA latency; fall back to 64-row blocks otherwise
+        const bool big = rgb_plain ? rgb_plain == 8 : ((grid.x + 7) / 8) * grid.y >= 512;
+        if (big) hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 1, 8>), dim3((grid.x + 7) / 8, grid.y), dim3(256), 0, st, s);
+        else hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 1, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+      }
+    } else if (use_gemm) {
       const int nt = force_nt ? force_nt : 4;  // measured: (RG,NT)=(2,4)/(4,4) beats (1,8)/(2,8) at t_e ~128 (profiles/r01_ffn_sweep_prefill_gemm.txt)
       if constexpr (NMAT == 2) {  // gated: 2 matrices -> (RG, NT) = (2,4) or (1,8)
         if (nt <= 4) hipLaunchKernelGGL((ffn_gemm_kernel<T, 2, 2, 4, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
