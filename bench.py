@@ -100,6 +100,11 @@ def host_expert_tensors(eng, cfg, layer, expert):
 
 
 def main():
+    # Native libraries (RCCL prints a version banner, HIP/driver warnings) write to the C stdout; keep the
+    # process's real stdout for the ONE JSON line only.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -359,7 +364,8 @@ def main():
             "cache": {k: st[k] for k in ("expert_hits", "expert_misses", "evictions", "h2d_bytes", "slots_total", "slots_used", "slot_bytes", "host_arena_bytes")},
             "parity": parity,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     eng.close()
     if use_ep:
         dist.destroy_process_group()

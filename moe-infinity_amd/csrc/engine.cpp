@@ -1282,14 +1282,13 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   hipStream_t st = (hipStream_t)stream;
   CHK(ep_alloc(g, cap_rows));
   const int np = g->last_T * g->K, ep = g->cfg.ep_size;
-  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, np, ep, st));
+  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
   ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
   ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
   ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
   HIPCHK(launch_dispatch_index(ia, st));
-  HIPCHK(hipMemsetAsync(g->d_ep_pair_pos, 0xFF, (size_t)np * 4, st));
   EpPackArgs pa;
   memset(&pa, 0, sizeof pa);
   pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;

@@ -115,9 +115,10 @@ struct PokeArgs {
 hipError_t launch_poke(const PokeArgs& a, hipStream_t st);
 
 // expert-parallel helpers
-// key[p] = valid pair ? topk_idx[p] % ep_size : -1   (destination rank of every (token,k) pair)
-hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n_pairs,
-                              int ep_size, hipStream_t st);
+// key[p] = valid pair ? topk_idx[p] % ep_size : -1   (destination rank of every (token,k) pair);
+// also resets pair_pos[p] = -1 when pair_pos != nullptr
+hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int32_t* pair_pos,
+                              int n_pairs, int ep_size, hipStream_t st);
 struct EpPackArgs {
   const void* x;              // [T,H]
   void* send;                 // [ep_size*cap_rows, ld_send]: H activations + a 16-byte tail whose first int32 is

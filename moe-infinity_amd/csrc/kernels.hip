@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
       for (int rg = 0; rg < RG; ++rg) {
         if (rg < nrg) {
           fa[rg][0] = ld16(a0 + rg * rg_stride + (size_t)kb * 1024);
-          if (NMAT == 2) fa[rg][1] = ld16(a1 + rg * rg_stride + (size_t)kb * 1024);
+          if (NMAT == 2) fa[rg][NMAT - 1] = ld16(a1 + rg * rg_stride + (size_t)kb * 1024);
         }
       }
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
           for (int tt = 0; tt < NT; ++tt) {
             if (tt < ntl) {
               mma16<T>(acc[rg][tt][0], fa[rg][0], fx[tt]);
-              if (NMAT == 2) mma16<T>(acc[rg][tt][1], fa[rg][1], fx[tt]);
+              if (NMAT == 2) mma16<T>(acc[rg][tt][NMAT - 1], fa[rg][NMAT - 1], fx[tt]);
             }
           }
         }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           red[wave][0][lane * 4 + j] = acc[rg][tt][0][j];
-          if (NMAT == 2) red[wave][1][lane * 4 + j] = acc[rg][tt][1][j];
+          if (NMAT == 2) red[wave][NMAT - 1][lane * 4 + j] = acc[rg][tt][NMAT - 1][j];
         }
         __syncthreads();
         for (int i = tid; i < 256; i += NW * 64) {
@@ -986,6 +986,8 @@ __device__ __forceinline__ int chunk_rank(int key, bool counted, int* wave_cnt /
   return pos;
 }
 
+__device__ __forceinline__ void index_small(const IndexArgs& a, int* cnt, int* offs);
+
 __device__ __forceinline__ void index_body(const IndexArgs& a, int* wave_cnt, int* running, int* offs, int* scan_tmp) {
   const int tid = threadIdx.x;
   const int E = a.E, K = a.K, T = a.T;
@@ -1074,7 +1076,11 @@ __global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a
   __shared__ int running[IDX_MAXE];
   __shared__ int offs[IDX_MAXE + 1];
   __shared__ int scan_tmp[IDX_MAXE];
-  index_body(a, wave_cnt, running, offs, scan_tmp);
+  if (a.T * a.K <= 64 && !(a.capacity > 0 && a.T > a.rows)) {
+    if (threadIdx.x < 64) index_small(a, running, offs);  // decode-sized: one wave, no workgroup barriers
+  } else {
+    index_body(a, wave_cnt, running, offs, scan_tmp);
+  }
 }
 
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
@@ -1323,16 +1329,17 @@ hipError_t launch_poke(const PokeArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // expert-parallel helpers
 // ------------------------------------------------------------------------------------------------
-__global__ void ep_dest_key_kernel(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n, int ep) {
+__global__ void ep_dest_key_kernel(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int32_t* pair_pos, int n, int ep) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const int e = topk_idx[p];
   key[p] = (e >= 0 && (!pair_valid || pair_valid[p])) ? (e % ep) : -1;
+  if (pair_pos) pair_pos[p] = -1;  // ep_pack fills the dispatched ones
 }
-hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int n_pairs,
-                              int ep_size, hipStream_t st) {
+hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int32_t* pair_pos,
+                              int n_pairs, int ep_size, hipStream_t st) {
   hipLaunchKernelGGL(ep_dest_key_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, topk_idx, pair_valid, key,
-                     n_pairs, ep_size);
+                     pair_pos, n_pairs, ep_size);
   return hipGetLastError();
 }
 

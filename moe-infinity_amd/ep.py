@@ -63,7 +63,6 @@ class ExpertParallelMoE:
         ld = ops.row_elems()  # H + 16-byte tail (expert id)
         self.send, self.recv = mk(n, ld), mk(n, ld)
         self.y, self.ret = mk(n, hidden), mk(n, hidden)
-        self.send_counts = mk(self.world, dt=torch.int32)
 
     def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, out: Optional[torch.Tensor] = None):
         shape = x.shape
@@ -73,7 +72,7 @@ class ExpertParallelMoE:
         if out is None:
             out = torch.empty_like(x2)
         self.ops.route(layer, x2, gate_w)
-        self.ops.pack(x2, self.send, self.send_counts, self.cap_rows)
+        self.ops.pack(x2, self.send, None, self.cap_rows)
         # dispatch all-to-all: rows with their expert ids in the tail, equal splits of cap_rows per peer
         dist.all_to_all_single(self.recv, self.send, group=self.group)
         self.ops.expert_ffn(layer, self.recv, self.y, self.cap_rows)
