@@ -314,7 +314,8 @@ int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_
  * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows zero). */
 int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream);
 /* Combine replies: ret_dev [ep_size*cap_rows, H] holds, in the order moeinf_ep_pack produced,
- * the expert outputs for this rank's routed rows; writes out_dev [tokens, H]. */
+ * the expert outputs for this rank's routed rows; writes out_dev [tokens, H].  With a shared expert
+ * (DeepSeek) registered, its FFN over x_dev runs here, on the token's home rank, and is added last. */
 int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows,
                       void* stream);
 

@@ -881,6 +881,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
     ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
     ca.router_prob = g->d_router_prob;
+    ca.y_shared = g->has_shared ? g->d_y : nullptr;
     ca.shared_offsets = g->has_shared ? g->d_offsets : nullptr;  // shared rows start at offsets[E]
     ca.shared_E = E;
     ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
@@ -1329,14 +1330,32 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
 extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream) {
   if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows");
-  if (g->has_shared) return fail(MOEINF_ERR_UNSUPPORTED, "EP combine with a shared expert: run the shared expert locally and add it (not built yet)");
   HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  if (g->has_shared) {
+    // the shared expert (always resident, replicated on every rank) runs on this rank's own tokens
+    const int T = g->last_T;
+    if (!g->shared_dev[g->last_layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", g->last_layer);
+    IndexArgs ia;
+    memset(&ia, 0, sizeof ia);
+    ia.T = T; ia.K = 1; ia.E = g->E;
+    ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
+    ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair;
+    HIPCHK(launch_shared_only_index(ia, st));
+    FfnStage s1, s2;
+    fill_stage(g, g->last_layer, 1, s1);
+    s1.in = x_dev;
+    fill_stage(g, g->last_layer, 2, s2);
+    s1.n_active_host = 1; s2.n_active_host = 1;
+    HIPCHK(launch_ffn_stage(s1, 1, T, st));
+    HIPCHK(launch_ffn_stage(s2, 1, T, st));
+  }
   CombineArgs ca;
   memset(&ca, 0, sizeof ca);
   ca.x = x_dev; ca.y = ret_dev; ca.out = out_dev;
   ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
-  ca.router_prob = g->d_router_prob; ca.shared_offsets = nullptr; ca.shared_E = g->E;
+  ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? g->d_y : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
   ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
-  HIPCHK(launch_combine(ca, (hipStream_t)stream));
+  HIPCHK(launch_combine(ca, st));
   return MOEINF_OK;
 }

@@ -97,13 +97,16 @@ struct CombineArgs {
   const int32_t* pair_slot; // [T,K]
   const int32_t* pair_order;// [T,K]
   const float* router_prob; // [T] Switch
-  const int32_t* shared_offsets;  // non-null: shared expert rows start at y[shared_offsets[shared_E]] (device)
+  const void* y_shared;           // non-null: DeepSeek shared-expert outputs, row t at y_shared[(row0 + t) * H]
+  const int32_t* shared_offsets;  // row0 = shared_offsets ? shared_offsets[shared_E] : 0 (device value)
   int shared_E;
   int T, H, K;
   int kind;                 // MOEINF_ROUTER_* (selects the reference block's combine semantics)
   int dtype;
 };
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+// index arrays for "only the shared pseudo-expert E is active, with T rows" (expert-parallel path)
+hipError_t launch_shared_only_index(const IndexArgs& a, hipStream_t st);
 
 // residency-table update: table[idx[i]] = val[i], i < n (n <= 16), stream-ordered
 struct PokeArgs {

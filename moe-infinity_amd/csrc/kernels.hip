@@ -1297,8 +1297,9 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
       }
     }
   }
-  if (a.kind == 1 && a.shared_offsets) {
-    const T* sr = y + (size_t)(a.shared_offsets[a.shared_E] + t) * a.H + h0;
+  if (a.kind == 1 && a.y_shared) {
+    const int row0 = a.shared_offsets ? a.shared_offsets[a.shared_E] : 0;
+    const T* sr = reinterpret_cast<const T*>(a.y_shared) + (size_t)(row0 + t) * a.H + h0;
     for (int j = 0; j < nh; ++j) acc[j] = DT<T>::round(acc[j] + DT<T>::load(sr + j));
   }
   if (a.kind == 3 /*NLLB: next_states[next_states == 0] = hidden_states[...] */) {
@@ -1307,6 +1308,17 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
       if (acc[j] == 0.f) acc[j] = DT<T>::load(xr + j);
   }
   for (int j = 0; j < nh; ++j) DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, acc[j]);
+}
+
+__global__ void shared_only_index_kernel(IndexArgs a) {
+  const int E = a.E, T = a.T;
+  for (int e = threadIdx.x; e <= E; e += blockDim.x) { a.counts[e] = (e == E) ? T : 0; a.offsets[e] = 0; }
+  if (threadIdx.x == 0) { a.offsets[E + 1] = T; a.active[0] = E; *a.n_active = 1; }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) { a.slot_token[t] = t; a.slot_pair[t] = -1; }
+}
+hipError_t launch_shared_only_index(const IndexArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(shared_only_index_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st) {

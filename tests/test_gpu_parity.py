@@ -380,3 +380,47 @@ def test_fp32_gated_experts():
     _check_routing_exact(eng, ref)
     assert_block_close(out, ref, torch.float32, "fp32 mixtral block")
     eng.close()
+
+
+def test_ep_two_ranks_with_shared_expert():
+    """Expert-parallel DeepSeek: routed experts sharded e % 2, the shared expert replicated and run on the
+    home rank inside ep_combine."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd.engine import FWD_ROUTE_ONLY
+
+    h, f, e, k, world, n_shared = 256, 192, 16, 4, 2, 2
+    ts = [4, 7]
+    cap = max(ts) * k
+    gate, experts, shared = make_weights("deepseek", h, f, e, 940, torch.bfloat16, n_shared=n_shared)
+    engs = []
+    for r in range(world):
+        eng = MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_DEEPSEEK, hidden=h, inter=f,
+                                        top_k=k, router_kind=Cf.ROUTER_DEEPSEEK, shared_inter=f * n_shared,
+                                        device_memory_ratio=0.25, ep_rank=r, ep_size=world, max_tokens=world * max(ts)))
+        for i in range(e):
+            if i % world == r:
+                eng.register_expert(0, i, experts[i])
+        eng.register_shared(0, shared)
+        engs.append(eng)
+    g = gate.to(DEV)
+    xs = [acts(t, h, torch.bfloat16, 950 + r).to(DEV) for r, t in enumerate(ts)]
+    ld = engs[0].ep_row_elems()
+    send = [torch.zeros(world * cap, ld, dtype=torch.bfloat16, device=DEV) for _ in range(world)]
+    for r in range(world):
+        engs[r].forward(0, xs[r], g, flags=FWD_ROUTE_ONLY)
+        engs[r].ep_pack(xs[r], send[r], None, cap)
+    torch.cuda.synchronize()
+    recv = [torch.cat([send[src][dst * cap:(dst + 1) * cap] for src in range(world)]).contiguous() for dst in range(world)]
+    ys = [torch.zeros(world * cap, h, dtype=torch.bfloat16, device=DEV) for _ in range(world)]
+    for r in range(world):
+        engs[r].ep_expert_ffn(0, recv[r], ys[r], cap)
+    torch.cuda.synchronize()
+    ret = [torch.cat([ys[src][dst * cap:(dst + 1) * cap] for src in range(world)]).contiguous() for dst in range(world)]
+    for r in range(world):
+        out = torch.empty_like(xs[r])
+        engs[r].ep_combine(xs[r], ret[r], out, cap)
+        ref = R.block_deepseek(xs[r].cpu()[None], gate, experts, k, shared=shared)
+        assert_block_close(out, ref, torch.bfloat16, f"EP rank {r} deepseek output")
+    for eng in engs:
+        eng.close()
