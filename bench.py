@@ -261,8 +261,12 @@ def main():
 
         kernels = {"ffn_stage1": kstat(p["ffn1_ms"], p["ffn1_launches"], p["ffn1_bytes"]),
                    "ffn_stage2": kstat(p["ffn2_ms"], p["ffn2_launches"], p["ffn2_bytes"]),
-                   "route(3 launches)": kstat(p["route_ms"], p["forwards"], p["route_bytes"]),
+                   "route(gate+topk+index)": kstat(p["route_ms"], p["forwards"], p["route_bytes"]),
                    "combine": kstat(p["combine_ms"], p["forwards"], p["combine_bytes"]),
+                   # decode-sized Mixtral/DeepSeek steps: the combine runs in the epilogue of FFN stage 2, the
+                   # "combine" interval above is then an empty event-to-event interval (= the events' own cost)
+                   "combine_fused_into_ffn_stage2": bool(B <= 16 and family in ("mixtral", "deepseek")
+                                                         and os.environ.get("MOEINF_FUSE_COMBINE", "1") != "0"),
                    "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)}
         k1 = kernels["ffn_stage1"]
         # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate

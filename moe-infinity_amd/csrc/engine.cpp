@@ -174,19 +174,20 @@ struct moeinf_engine {
   int32_t *d_topk_idx = nullptr, *d_pair_valid = nullptr, *d_pair_order = nullptr, *d_pair_slot = nullptr;
   float *d_topk_w = nullptr, *d_router_prob = nullptr;
   int32_t *d_counts = nullptr, *d_offsets = nullptr, *d_active = nullptr, *d_n_active = nullptr;
-  int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_mirror = nullptr, *d_miss = nullptr;
+  int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_miss = nullptr;
+  int32_t* d_arrive = nullptr;  // [ceil(H/16)] zeroed arrival counters of the fused combine's column tiles
   void *d_h = nullptr, *d_y = nullptr;
   int64_t ldh = 0;
-  int32_t* h_mirror = nullptr;  // pinned: {n_active, counts[E+1], active[E+1]}
+  int32_t* h_mirror = nullptr;  // pinned, written by the index kernels themselves: {n_active, counts[E+1], active[E+1]}
   int32_t* h_miss = nullptr;
   std::vector<PokeArgs> pending_pokes;
-  // sync-free forwards: their routing mirrors are copied to pinned buffers and applied to the
-  // counters/statistics lazily (no residency decision depends on them while every expert of the
-  // layer is resident)
-  struct PendingMirror { hipEvent_t ev; int32_t* buf; int layer; int T; bool prof; };
+  // sync-free forwards: the index kernel writes the routing mirror straight into a pooled pinned buffer
+  // (no copy command on the compute stream); it is applied to the counters/statistics lazily, once the
+  // forward's end-of-forward fence has passed (no residency decision depends on it while every expert of
+  // the layer is resident)
+  struct PendingMirror { uint64_t seq; int32_t* buf; int layer; int T; bool prof; };
   std::deque<PendingMirror> pend;
   std::vector<int32_t*> mirror_pool;
-  std::vector<hipEvent_t> mirror_events;
   int owned_experts = 0;
 
   // EP workspace (lazily allocated)
@@ -301,12 +302,11 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* bufs[] = {g->d_wptr, g->d_logits, g->d_topk_idx, g->d_pair_valid, g->d_pair_order, g->d_pair_slot, g->d_topk_w,
                   g->d_router_prob, g->d_counts, g->d_offsets, g->d_active, g->d_n_active, g->d_slot_token, g->d_slot_pair,
-                  g->d_mirror, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
-  for (auto& pm : g->pend) { hipHostFree(pm.buf); hipEventDestroy(pm.ev); }
+  for (auto& pm : g->pend) hipHostFree(pm.buf);
   for (auto b : g->mirror_pool) hipHostFree(b);
-  for (auto e : g->mirror_events) hipEventDestroy(e);
   if (g->stage_demand) hipFree(g->stage_demand);
   if (g->stage_prefetch) hipFree(g->stage_prefetch);
   if (g->h_mirror) hipHostFree(g->h_mirror);
@@ -379,7 +379,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRY(dmalloc(&g->d_pair_slot, T * K)); TRY(dmalloc(&g->d_topk_w, T * K)); TRY(dmalloc(&g->d_router_prob, T));
   TRY(dmalloc(&g->d_counts, E1)); TRY(dmalloc(&g->d_offsets, E1 + 1)); TRY(dmalloc(&g->d_active, E1)); TRY(dmalloc(&g->d_n_active, 1));
   TRY(dmalloc(&g->d_slot_token, rows)); TRY(dmalloc(&g->d_slot_pair, rows));
-  TRY(dmalloc(&g->d_mirror, 1 + 2 * E1)); TRY(dmalloc(&g->d_miss, 1));
+  TRY(dmalloc(&g->d_arrive, (g->H + 15) / 16)); TRY(dmalloc(&g->d_miss, 1));
+  TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
   TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
@@ -637,13 +638,17 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T) {
   if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
 }
 
-// apply the routing mirrors of finished sync-free forwards to counters / stats (all were hits)
-static void drain_mirrors(moeinf_engine* g, bool block) {
+// apply the routing mirrors of finished sync-free forwards to counters / stats (all were hits).
+// Entries beyond `max_pending` are waited for (oldest first), the rest are taken only if already complete.
+static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
   while (!g->pend.empty()) {
     auto& pm = g->pend.front();
-    if (block) {
-      hipEventSynchronize(pm.ev);
-    } else if (hipEventQuery(pm.ev) != hipSuccess) {
+    // the forward's fence; ring entries older than kFenceRing forwards have been re-recorded by a later forward
+    const uint64_t fs = (pm.seq + kFenceRing > g->seq) ? pm.seq : g->seq;
+    hipEvent_t ev = g->fence_ev[fs % kFenceRing];
+    if (g->pend.size() > max_pending) {
+      hipEventSynchronize(ev);
+    } else if (hipEventQuery(ev) != hipSuccess) {
       (void)hipGetLastError();
       break;
     }
@@ -663,9 +668,33 @@ static void drain_mirrors(moeinf_engine* g, bool block) {
     }
     if (pm.prof) account_profile(g, pm.buf, pm.T);
     g->mirror_pool.push_back(pm.buf);
-    g->mirror_events.push_back(pm.ev);
     g->pend.pop_front();
   }
+}
+static void drain_mirrors(moeinf_engine* g, bool block) { drain_mirrors(g, block ? (size_t)0 : (size_t)-1); }
+
+// Where the next index kernel writes its routing mirror, decided BEFORE that launch: a pooled pinned buffer when
+// the layer is fully resident (sync-free forward), the engine's h_mirror when the host has to look at it.
+struct MirrorPlan { bool fast = false; int32_t* target = nullptr; };
+static void settle_ready(moeinf_engine* g, int layer);
+static int plan_mirror(moeinf_engine* g, int layer, MirrorPlan& mp) {
+  settle_ready(g, layer);
+  mp.fast = g->resident_per_layer[layer] == g->owned_experts;
+  if (mp.fast) {
+    drain_mirrors(g, (size_t)(kFenceRing - 4));  // a mirror must be applied before its fence leaves the ring twice
+    if (!g->mirror_pool.empty()) { mp.target = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
+    else {
+      const size_t nb = (size_t)(1 + 2 * (g->E + 1)) * sizeof(int32_t);
+      HIPCHK(hipHostMalloc((void**)&mp.target, nb, hipHostMallocDefault));
+      memset(mp.target, 0, nb);
+    }
+  } else {
+    drain_mirrors(g, true);
+    mp.target = g->h_mirror;
+  }
+  // decode-sized index kernels report only the active experts: start from "no expert has rows"
+  memset(mp.target, 0, (size_t)(2 + g->E) * sizeof(int32_t));
+  return MOEINF_OK;
 }
 
 // experts whose copy has already landed need no stream wait any more: count them as ordered
@@ -735,7 +764,8 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 =
 // time, so it has no such limit): each chunk is made resident, launched, and fenced so the next
 // chunk may recycle its slots once its kernels have drained.
 static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_t st, hipEvent_t ev_before,
-                       hipEvent_t ev_mid, hipEvent_t ev_after, int64_t ld_x = 0) {
+                       hipEvent_t ev_mid, hipEvent_t ev_after, int64_t ld_x = 0, const CombineArgs* fuse = nullptr,
+                       bool* fused = nullptr) {
   const int E = g->E, E1 = E + 1;
   const int na = g->h_mirror[0];
   const int32_t* active = g->h_mirror + 1 + E1;
@@ -754,6 +784,10 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     CHK(flush_pokes(g, st));
     s1.active = g->d_active + a; s2.active = g->d_active + a;
     s1.n_active_host = b - a; s2.n_active_host = b - a;
+    if (fuse && a == 0 && b == na && na > 0) {  // one chunk: the last column-tile block of stage 2 combines
+      s2.fuse_combine = 1; s2.tile_done = g->d_arrive; s2.comb = *fuse;
+      if (fused) *fused = true;
+    }
     int max_rows = 0;
     for (int i = a; i < b; ++i) max_rows = std::max(max_rows, (int)g->h_mirror[1 + active[i]]);
     HIPCHK(launch_ffn_stage(s1, b - a, max_rows, st));
@@ -778,21 +812,13 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
 //   expert_executor.py:34-43).  The mirror is applied to the counters lazily.
 //   Decision path: some expert may be missing: small pinned D2H + event wait, then fetch/evict.
 static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
-                            hipStream_t st, bool prof, moeinf_engine::ProfRec* pr) {
+                            hipStream_t st, bool prof, moeinf_engine::ProfRec* pr, const MirrorPlan& mp,
+                            const CombineArgs* fuse, bool* fused) {
   const int E = g->E, E1 = E + 1;
-  const size_t mirror_bytes = (size_t)(1 + 2 * E1) * sizeof(int32_t);
-  settle_ready(g, layer);
-  const bool fast = g->resident_per_layer[layer] == g->owned_experts;
-  if (fast) {
-    drain_mirrors(g, g->pend.size() > 256);
+  if (fused) *fused = false;
+  if (mp.fast) {
     moeinf_engine::PendingMirror pm;
-    if (!g->mirror_pool.empty()) { pm.buf = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
-    else HIPCHK(hipHostMalloc((void**)&pm.buf, mirror_bytes, hipHostMallocDefault));
-    if (!g->mirror_events.empty()) { pm.ev = g->mirror_events.back(); g->mirror_events.pop_back(); }
-    else HIPCHK(hipEventCreateWithFlags(&pm.ev, hipEventDisableTiming));
-    pm.layer = layer; pm.T = T; pm.prof = prof;
-    HIPCHK(hipMemcpyAsync(pm.buf, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(pm.ev, st));
+    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = T; pm.prof = prof;
     g->pend.push_back(pm);
     for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
       const Node& n = g->nodes[node_index(g, layer, e)];
@@ -803,14 +829,14 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     fill_stage(g, layer, 1, s1, ld_x);
     s1.in = x_in;
     fill_stage(g, layer, 2, s2);
+    if (fuse) { s2.fuse_combine = 1; s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
     HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
     HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[4], st));
   } else {
-    drain_mirrors(g, true);
-    HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, mirror_bytes, hipMemcpyDeviceToHost, st));
+    // the index kernel wrote h_mirror itself (pinned, device-visible): wait for it, no copy
     HIPCHK(hipEventRecord(g->route_ev, st));
     const auto tw0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventSynchronize(g->route_ev));
@@ -820,7 +846,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
       if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d was handed rows for expert %d it does not own", g->cfg.ep_rank, e);
     }
     if (prof) account_profile(g, g->h_mirror, T);
-    CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x));
+    CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused));
   }
   return MOEINF_OK;
 }
@@ -852,7 +878,8 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   moeinf_engine::ProfRec pr;
   const bool prof = g->profiling && !route_only;
   if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
-  HIPCHK(launch_gate_logits(ra, st));
+  MirrorPlan mp;
+  if (!route_only) CHK(plan_mirror(g, layer, mp));
 
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
@@ -861,7 +888,8 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   ia.capacity = g->cfg.router_kind == MOEINF_ROUTER_SWITCH ? g->cfg.expert_capacity : 0;
   ia.shared = g->has_shared ? 1 : 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
+  HIPCHK(launch_gate_logits(ra, st));
   if (T <= 64) {
     HIPCHK(launch_route_index(ra, ia, st));  // decode: top-k + dispatch index in one launch
   } else {
@@ -873,20 +901,26 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (route_only) return MOEINF_OK;
   if (prof) HIPCHK(hipEventRecord(pr.ev[1], st));
 
+  const bool want_combine = !(flags & MOEINF_FWD_NO_COMBINE);
+  CombineArgs ca;
+  memset(&ca, 0, sizeof ca);
+  ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
+  ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
+  ca.router_prob = g->d_router_prob;
+  ca.y_shared = g->has_shared ? g->d_y : nullptr;
+  ca.shared_offsets = g->has_shared ? g->d_offsets : nullptr;  // shared rows start at offsets[E]
+  ca.shared_E = E;
+  ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
+  // decode-sized Mixtral/DeepSeek forwards (every token keeps K experts, so stage 2 always runs): the combine
+  // rides in the epilogue of FFN stage 2
+  static const bool fuse_combine = getenv("MOEINF_FUSE_COMBINE") ? atoi(getenv("MOEINF_FUSE_COMBINE")) != 0 : true;
+  const bool can_fuse = fuse_combine && want_combine && T <= 16 &&
+                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK);
+  bool fused = false;
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + (g->has_shared ? 1 : 0),
-                       (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr));
-  if (!(flags & MOEINF_FWD_NO_COMBINE)) {
-    CombineArgs ca;
-    memset(&ca, 0, sizeof ca);
-    ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
-    ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
-    ca.router_prob = g->d_router_prob;
-    ca.y_shared = g->has_shared ? g->d_y : nullptr;
-    ca.shared_offsets = g->has_shared ? g->d_offsets : nullptr;  // shared rows start at offsets[E]
-    ca.shared_E = E;
-    ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
-    HIPCHK(launch_combine(ca, st));
-  }
+                       (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr,
+                       mp, can_fuse ? &ca : nullptr, &fused));
+  if (want_combine && !fused) HIPCHK(launch_combine(ca, st));
   if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
   // fence: slots used by this forward may be recycled only after this point of the stream
   g->seq += 1;
@@ -910,9 +944,8 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   memset(&ia, 0, sizeof ia);
   ia.T = tokens; ia.K = 1; ia.E = E;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->h_mirror;
   HIPCHK(launch_mask_index(mask_dev, mask_elem_bytes, tokens, E, ia, st));
-  HIPCHK(hipMemcpyAsync(g->h_mirror, g->d_mirror, (size_t)(1 + 2 * E1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(g->route_ev, st));
   HIPCHK(hipEventSynchronize(g->route_ev));
   int64_t rows = 0;
@@ -1315,11 +1348,13 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
   ia.idx_stride = (int)(ld * g->es / 4);
   ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->d_mirror;
+  MirrorPlan mp;
+  CHK(plan_mirror(g, layer, mp));
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
   HIPCHK(launch_dispatch_index(ia, st));
   const int owned = std::max(1, g->owned_experts);
   CHK(dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
-                       (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr));
+                       (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr, mp, nullptr, nullptr));
   HIPCHK(launch_ep_unsort(g->d_y, y_dev, g->d_pair_slot, nrows, g->H, g->dt, st));
   g->st.forwards += 1;
   g->seq += 1;

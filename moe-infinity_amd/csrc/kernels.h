@@ -17,6 +17,23 @@ enum {
   EPI_GATED_SILU = 4  // out = Tr(Tr(silu(Tr(acc0))) * Tr(acc1))   (Mixtral w1/w3, DeepSeek gate/up)
 };
 
+struct CombineArgs {
+  const void* x;            // [T,H] (Switch/NLLB passthrough)
+  const void* y;            // [rows,H] expert outputs, expert-sorted
+  void* out;                // [T,H]
+  const int32_t* topk_idx;  // [T,K]
+  const float* topk_w;      // [T,K]
+  const int32_t* pair_slot; // [T,K]
+  const int32_t* pair_order;// [T,K]
+  const float* router_prob; // [T] Switch
+  const void* y_shared;           // non-null: DeepSeek shared-expert outputs, row t at y_shared[(row0 + t) * H]
+  const int32_t* shared_offsets;  // row0 = shared_offsets ? shared_offsets[shared_E] : 0 (device value)
+  int shared_E;
+  int T, H, K;
+  int kind;                 // MOEINF_ROUTER_* (selects the reference block's combine semantics)
+  int dtype;
+};
+
 // One stage (x -> h, or h -> y) of the grouped expert FFN for every active expert of a layer.
 struct FfnStage {
   const void* in;          // B-operand rows: x [tokens, ld_in] (stage 1) or h [rows, ld_in] (stage 2)
@@ -39,6 +56,12 @@ struct FfnStage {
   int64_t off_a_sh, off_b_sh;               // inside the shared blob
   int epi;
   int dtype;
+  // decode-sized fused combine (stage 2 of a forward with <= 16 tokens, Mixtral/DeepSeek combine semantics): the
+  // LAST block to finish a 16-column tile of y (over all active experts; arrival counter + agent-scope fences)
+  // combines those 16 columns for every token, so the combine needs no launch of its own and stays deterministic
+  int fuse_combine;
+  int32_t* tile_done;      // [ceil(R/16)] arrival counters, zero between launches (the last block resets its own)
+  CombineArgs comb;
 };
 // max_rows_per_expert: upper bound of rows any one expert receives (selects the multi-token-tile variant)
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
@@ -80,7 +103,8 @@ struct IndexArgs {
   int32_t* pair_slot;       // [T,K]
   int32_t* slot_token;      // [T*K + T] expert-sorted row -> token id
   int32_t* slot_pair;       // [T*K + T] expert-sorted row -> pair id t*K+k (shared rows: -1)
-  int32_t* mirror;          // device staging of {n_active, counts[E+1], active[E+1]} for one D2H copy
+  int32_t* mirror;          // pinned HOST buffer {n_active, counts[E+1], active[E+1]} written by the kernel itself
+                            // (counts pre-zeroed by the host; only active experts' counts are guaranteed written)
 };
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
 // dispatch index from a dense router_mask[T,E] (element size 1, 4 or 8 bytes, non-zero = routed)
@@ -88,22 +112,6 @@ hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
 
-struct CombineArgs {
-  const void* x;            // [T,H] (Switch/NLLB passthrough)
-  const void* y;            // [rows,H] expert outputs, expert-sorted
-  void* out;                // [T,H]
-  const int32_t* topk_idx;  // [T,K]
-  const float* topk_w;      // [T,K]
-  const int32_t* pair_slot; // [T,K]
-  const int32_t* pair_order;// [T,K]
-  const float* router_prob; // [T] Switch
-  const void* y_shared;           // non-null: DeepSeek shared-expert outputs, row t at y_shared[(row0 + t) * H]
-  const int32_t* shared_offsets;  // row0 = shared_offsets ? shared_offsets[shared_E] : 0 (device value)
-  int shared_E;
-  int T, H, K;
-  int kind;                 // MOEINF_ROUTER_* (selects the reference block's combine semantics)
-  int dtype;
-};
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
 // index arrays for "only the shared pseudo-expert E is active, with T rows" (expert-parallel path)
 hipError_t launch_shared_only_index(const IndexArgs& a, hipStream_t st);

@@ -35,6 +35,16 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, N
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// Device-coherent accessors for data handed between workgroups INSIDE one launch (fused combine / fused router):
+// relaxed agent-scope atomics compile to sc1 loads/stores that write through / miss the per-XCD L2 for lines it
+// does not own, so no agent-scope fence (= a full L2 write-back + invalidate, tens of us on 8 XCDs) is needed;
+// the producer only waits for its stores to be acknowledged (s_waitcnt) before it bumps the arrival counter.
+template <typename V>
+__device__ __forceinline__ V ld_coherent(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V>
+__device__ __forceinline__ void st_coherent(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_stores_acked() { __builtin_amdgcn_s_waitcnt(0); }
+
 template <typename T>
 struct DT;
 template <>
@@ -43,6 +53,32 @@ struct DT<uint16_t> {  // bf16 storage
   __device__ static __forceinline__ float round(float f) { return bf2f(f2bf(f)); }
   __device__ static __forceinline__ float load(const uint16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void store(uint16_t* p, float f) { *p = f2bf(f); }
+  // 4 consecutive elements, 8-byte aligned
+  __device__ static __forceinline__ void load4(const uint16_t* p, float o[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  // raw 4-element fetch (issue many, unpack later: keeps independent loads back to back)
+  struct Raw4 { unsigned long long v; };
+  template <bool COH>
+  __device__ static __forceinline__ Raw4 fetch4(const uint16_t* p) {
+    Raw4 r;
+    r.v = COH ? ld_coherent(reinterpret_cast<const unsigned long long*>(p)) : *reinterpret_cast<const unsigned long long*>(p);
+    return r;
+  }
+  __device__ static __forceinline__ void unpack4(const Raw4& r, float o[4]) {
+    const uint32_t x = (uint32_t)r.v, y = (uint32_t)(r.v >> 32);
+    o[0] = __uint_as_float(x << 16); o[1] = __uint_as_float(x & 0xffff0000u);
+    o[2] = __uint_as_float(y << 16); o[3] = __uint_as_float(y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store_coherent(uint16_t* p, float f) { st_coherent(p, f2bf(f)); }
+  __device__ static __forceinline__ void store4(uint16_t* p, const float f[4]) {
+    uint2 v;
+    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
 };
 template <>
 struct DT<float> {
@@ -50,6 +86,27 @@ struct DT<float> {
   __device__ static __forceinline__ float round(float f) { return f; }
   __device__ static __forceinline__ float load(const float* p) { return *p; }
   __device__ static __forceinline__ void store(float* p, float f) { *p = f; }
+  __device__ static __forceinline__ void load4(const float* p, float o[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  struct Raw4 { unsigned long long a, b; };
+  template <bool COH>
+  __device__ static __forceinline__ Raw4 fetch4(const float* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    Raw4 r;
+    r.a = COH ? ld_coherent(q) : q[0];
+    r.b = COH ? ld_coherent(q + 1) : q[1];
+    return r;
+  }
+  __device__ static __forceinline__ void unpack4(const Raw4& r, float o[4]) {
+    o[0] = __uint_as_float((uint32_t)r.a); o[1] = __uint_as_float((uint32_t)(r.a >> 32));
+    o[2] = __uint_as_float((uint32_t)r.b); o[3] = __uint_as_float((uint32_t)(r.b >> 32));
+  }
+  __device__ static __forceinline__ void store_coherent(float* p, float f) { st_coherent(p, f); }
+  __device__ static __forceinline__ void store4(float* p, const float f[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
 };
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -113,6 +170,79 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// combine: out[t] = sum over the token's experts in ASCENDING expert id of w * y, with the
+// reference block's dtype rounding points (mixtral.py:96-101, deepseek.py:123-136,
+// switch_transformers.py:99-109, nllb_moe.py:84-104).  Used by combine_kernel (grid =
+// (ceil(H/(256*4)), T)) and by the fused epilogue of the decode-sized FFN stage 2.
+// ------------------------------------------------------------------------------------------------
+// columns [h0, h0+4) of token t; H % 4 == 0 (moeinf_create checks), rows 8/16-byte aligned
+template <typename T, bool COH = false>  // COH: y / y_shared were written by other workgroups of THIS launch
+__device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, const int h0) {
+  const int K = a.K;
+  const T* y = reinterpret_cast<const T*>(a.y);
+  T* out = reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.kind == 2 /*SWITCH*/) {
+    const int slot = a.pair_slot[t];
+    const T* src = (slot >= 0) ? y + (size_t)slot * a.H : reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
+    const float pr = a.router_prob[t];
+    float v[4];
+    DT<T>::load4(src + h0, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = DT<T>::round(pr * v[j]);
+    DT<T>::store4(out, acc);
+    return;
+  }
+  // Three dependent rounds of loads (order -> slot/weight -> rows), each round issued back to back: entries
+  // kk >= K repeat entry K-1 and absent slots fetch row 0 (both ignored below) so the rounds stay branch-free.
+  int ko[8], slot[8];
+  float w[8];
+  const size_t p0 = (size_t)t * K;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ko[kk] = a.pair_order[p0 + min(kk, K - 1)];
+  const bool has_sh = (a.kind == 1 && a.y_shared);
+  const int row0 = (has_sh && a.shared_offsets) ? a.shared_offsets[a.shared_E] : 0;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    slot[kk] = a.pair_slot[p0 + ko[kk]];
+    w[kk] = a.topk_w[p0 + ko[kk]];
+  }
+  typename DT<T>::Raw4 rsh, ry[8];
+  rsh = DT<T>::template fetch4<COH>(reinterpret_cast<const T*>(has_sh ? a.y_shared : a.y) + (size_t)(row0 + (has_sh ? t : 0)) * a.H + h0);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ry[kk] = DT<T>::template fetch4<COH>(y + (size_t)max(slot[kk], 0) * a.H + h0);
+  float sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_sh) DT<T>::unpack4(rsh, sh);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    if (kk < K && slot[kk] >= 0) {
+      float yv[4];
+      DT<T>::unpack4(ry[kk], yv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float prod = yv[j] * w[kk];
+        // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
+        // product in fp32 (fp32 gate weights promote the bf16 expert output)
+        if (a.kind != 1) prod = DT<T>::round(prod);
+        acc[j] = DT<T>::round(acc[j] + prod);
+      }
+    }
+  }
+  if (has_sh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = DT<T>::round(acc[j] + sh[j]);
+  }
+  if (a.kind == 3 /*NLLB: next_states[next_states == 0] = hidden_states[...] */) {
+    float xv[4];
+    DT<T>::load4(reinterpret_cast<const T*>(a.x) + (size_t)t * a.H + h0, xv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (acc[j] == 0.f) acc[j] = xv[j];
+  }
+  DT<T>::store4(out, acc);
+}
+
 template <typename T, int NMAT, int NW, int U, int NT>
 __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   constexpr int EPV = DT<T>::EPV;
@@ -120,20 +250,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   __shared__ float red[NW][NMAT][256];
 
   const int u = blockIdx.y;
-  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int nact = s.n_active_host >= 0 ? s.n_active_host : *s.n_active;
+  if (u >= nact) return;
   const int e = s.active[u];
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
   const int r0 = blockIdx.x * 16;
   if (r0 >= R) return;
-  const int cnt = s.counts[e];
   const int off = s.offsets[e];
   const char* W = reinterpret_cast<const char*>(s.wptr[e]);
-  if (W == nullptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
-    return;
-  }
+  // an absent expert (never on the sync-free path) computes nothing but still reports its arrival below
+  if (W == nullptr && threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+  const int cnt = W ? s.counts[e] : 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -239,10 +368,26 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
               v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
             if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
           }
-          DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
+          T* op = reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow;
+          if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v); else DT<T>::store(op, v);
         }
       }
       __syncthreads();
+    }
+  }
+  if constexpr (NMAT == 1 && NT == 1) {
+    if (s.fuse_combine) {
+      // this block's y columns [r0, r0+16) are written; the last of the layer's `nact` blocks to arrive for
+      // the column tile combines it for every token (fixed ascending-expert order -> deterministic)
+      __shared__ int is_last;
+      wait_stores_acked();  // this thread's (write-through) y stores have reached device-coherent memory
+      __syncthreads();
+      if (tid == 0) is_last = (__hip_atomic_fetch_add(&s.tile_done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nact - 1);
+      __syncthreads();
+      if (is_last) {
+        for (int i = tid; i < s.comb.T * 4; i += NW * 64) combine_cols<T, true>(s.comb, i >> 2, r0 + (i & 3) * 4);
+        if (tid == 0) s.tile_done[blockIdx.x] = 0;
+      }
     }
   }
 }
@@ -613,7 +758,7 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   const int u = env_u ? env_u : 4;
   static const int env_nt = env_int("MOEINF_FFN_NT", 0);
   // the 64-token variant runs at low occupancy (~240 VGPRs): it only pays once an expert needs >= 3 token tiles
-  const bool many = env_nt ? env_nt > 1 : max_rows_per_expert > 32;
+  const bool many = s.fuse_combine ? false : (env_nt ? env_nt > 1 : max_rows_per_expert > 32);
   if (s.dtype == DT_BF16) {
     if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   } else {
@@ -646,10 +791,8 @@ __device__ __forceinline__ void load8<float>(const float* p, float out[8]) {
 }
 
 template <typename XT, typename WT, int TT>
-__global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__ x, const WT* __restrict__ wg,
-                                                          float* __restrict__ logits, int T, int H, int E,
-                                                          int round_bf16) {
-  __shared__ double red[4][TT];
+__device__ __forceinline__ void gate_body(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
+                                          int T, int H, int E, int round_bf16, double (*red)[TT]) {
   const int e = blockIdx.x;
   const int t0 = blockIdx.y * TT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -686,12 +829,22 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__
   }
 }
 
+template <typename XT, typename WT, int TT>
+__global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__ x, const WT* __restrict__ wg,
+                                                          float* __restrict__ logits, int T, int H, int E,
+                                                          int round_bf16) {
+  __shared__ double red[4][TT];
+  gate_body<XT, WT, TT>(x, wg, logits, T, H, E, round_bf16, red);
+}
+
+// Mixtral's gate is an nn.Linear in the model dtype (mixtral.py:46): its output is rounded to
+// that dtype.  The other routers compute fp32 logits from (exactly) up-cast inputs.
+static inline int gate_rounds_bf16(const RouteArgs& a) { return (a.kind == 0 /*MIXTRAL*/ && a.x_dtype == DT_BF16) ? 1 : 0; }
+
 hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
   constexpr int TT = 4;
   dim3 grid(a.E, (a.T + TT - 1) / TT);
-  // Mixtral's gate is an nn.Linear in the model dtype (mixtral.py:46): its output is rounded to
-  // that dtype.  The other routers compute fp32 logits from (exactly) up-cast inputs.
-  const int rb = (a.kind == 0 /*MIXTRAL*/ && a.x_dtype == DT_BF16) ? 1 : 0;
+  const int rb = gate_rounds_bf16(a);
 #define GL(XT, WT) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
   if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
   else if (a.x_dtype == DT_BF16) GL(uint16_t, float);
@@ -771,6 +924,7 @@ __device__ __forceinline__ void pick_best(const float key[4], uint32_t taken, in
   bv = 0.f; bi = -1;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (64 * j >= E) break;  // wave-uniform: E <= 64 scans one entry per lane
     const int e = lane + 64 * j;
     if (e < E && !((taken >> j) & 1u)) {
       if (bi < 0 || key[j] > bv) { bv = key[j]; bi = e; }  // ascending e inside a lane: strict > keeps lowest
@@ -795,8 +949,11 @@ __device__ __forceinline__ void route_token(const RouteArgs& a, const int t, con
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = lane + 64 * j;
-    p[j] = (e < E) ? expf(l[j] - m) : 0.f;
-    ssum += p[j];
+    p[j] = 0.f;
+    if (64 * j < E) {  // wave-uniform skip of the expf for absent columns
+      p[j] = (e < E) ? expf(l[j] - m) : 0.f;
+      ssum += p[j];
+    }
   }
   ssum = wave_sum(ssum);
 #pragma unroll
@@ -908,24 +1065,23 @@ __device__ __forceinline__ void route_token(const RouteArgs& a, const int t, con
     valid[0] = (w[0] != 0.f); valid[1] = (w[1] != 0.f);  // router_mask = combining_weights.bool()
   }
 
-  if (lane == 0) {
-    // pair order: k indices by ascending expert id (deterministic combine order)
-    int ord[8];
-    for (int k = 0; k < K; ++k) ord[k] = k;
-    for (int i = 1; i < K; ++i) {
-      const int o = ord[i];
-      int j = i - 1;
-      while (j >= 0 && sel[ord[j]] > sel[o]) { ord[j + 1] = ord[j]; --j; }
-      ord[j + 1] = o;
-    }
-    for (int k = 0; k < K; ++k) {
-      a.topk_idx[(size_t)t * K + k] = sel[k];
-      a.topk_w[(size_t)t * K + k] = w[k];
-      a.pair_valid[(size_t)t * K + k] = (sel[k] >= 0) ? valid[k] : 0;
-      a.pair_order[(size_t)t * K + k] = ord[k];
-    }
-    if (a.router_prob) a.router_prob[t] = val[0];
+  // lane k (< K) owns entry k: its rank among the token's experts by ascending id is its place in the
+  // (deterministic) combine order.  Stable for repeated ids (-1 = nothing selected).
+  int my_sel = -1, my_valid = 0, rank = 0;
+  float my_w = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (lane == k) { my_sel = sel[k]; my_w = w[k]; my_valid = valid[k]; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < K) rank += (sel[j] < my_sel || (sel[j] == my_sel && j < lane)) ? 1 : 0;
+  if (lane < K) {
+    a.topk_idx[(size_t)t * K + lane] = my_sel;
+    a.topk_w[(size_t)t * K + lane] = my_w;
+    a.pair_valid[(size_t)t * K + lane] = (my_sel >= 0) ? my_valid : 0;
+    a.pair_order[(size_t)t * K + rank] = lane;
   }
+  if (lane == 0 && a.router_prob) a.router_prob[t] = val[0];
 }
 
 __global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
@@ -1132,8 +1288,13 @@ __device__ __forceinline__ void index_small(const IndexArgs& a, int* cnt /*LDS [
       offs[e] = pre;
       a.offsets[e] = pre;
       a.counts[e] = c[j];
-      if (a.mirror) a.mirror[1 + e] = c[j];
-      if (c[j] > 0) { a.active[pnz] = e; if (a.mirror) a.mirror[1 + ne + pnz] = e; ++pnz; }
+      // the mirror is pinned HOST memory (every store is a PCIe write): only the active experts are reported,
+      // the host zeroes the counts before it hands the buffer out and reads active[] up to n_active only
+      if (c[j] > 0) {
+        a.active[pnz] = e;
+        if (a.mirror) { a.mirror[1 + e] = c[j]; a.mirror[1 + ne + pnz] = e; }
+        ++pnz;
+      }
       pre += c[j];
     }
   }
@@ -1142,7 +1303,6 @@ __device__ __forceinline__ void index_small(const IndexArgs& a, int* cnt /*LDS [
     *a.n_active = total_nz;
     if (a.mirror) a.mirror[0] = total_nz;
   }
-  if (a.mirror) for (int i = total_nz + lane; i < ne; i += 64) a.mirror[1 + ne + i] = -1;
   __builtin_amdgcn_wave_barrier();
   if (in) {
     int slot = -1;
@@ -1247,67 +1407,11 @@ hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// combine: out[t] = sum over the token's experts in ASCENDING expert id of w * y, with the
-// reference block's dtype rounding points (mixtral.py:96-101, deepseek.py:123-136,
-// switch_transformers.py:99-109, nllb_moe.py:84-104).  grid = (ceil(H/(256*4)), T).
-// ------------------------------------------------------------------------------------------------
+// standalone combine launch (see combine_cols)
 template <typename T>
 __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
-  const int t = blockIdx.y;
   const int h0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (h0 >= a.H) return;
-  const int K = a.K;
-  const T* y = reinterpret_cast<const T*>(a.y);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int nh = min(4, a.H - h0);
-  if (a.kind == 2 /*SWITCH*/) {
-    const int slot = a.pair_slot[t];
-    const T* src = (slot >= 0) ? y + (size_t)slot * a.H : reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
-    const float pr = a.router_prob[t];
-    for (int j = 0; j < nh; ++j)
-      DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, DT<T>::round(pr * DT<T>::load(src + h0 + j)));
-    return;
-  }
-  int slot[8];
-  float w[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    slot[kk] = -1; w[kk] = 0.f;
-    if (kk < K) {
-      const int k = a.pair_order[(size_t)t * K + kk];
-      slot[kk] = a.pair_slot[(size_t)t * K + k];
-      w[kk] = a.topk_w[(size_t)t * K + k];
-    }
-  }
-  float yv[8][4];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk)
-    if (kk < K && slot[kk] >= 0)
-      for (int j = 0; j < nh; ++j) yv[kk][j] = DT<T>::load(y + (size_t)slot[kk] * a.H + h0 + j);
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    if (kk < K && slot[kk] >= 0) {
-      for (int j = 0; j < nh; ++j) {
-        float prod = yv[kk][j] * w[kk];
-        // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
-        // product in fp32 (fp32 gate weights promote the bf16 expert output)
-        if (a.kind != 1) prod = DT<T>::round(prod);
-        acc[j] = DT<T>::round(acc[j] + prod);
-      }
-    }
-  }
-  if (a.kind == 1 && a.y_shared) {
-    const int row0 = a.shared_offsets ? a.shared_offsets[a.shared_E] : 0;
-    const T* sr = reinterpret_cast<const T*>(a.y_shared) + (size_t)(row0 + t) * a.H + h0;
-    for (int j = 0; j < nh; ++j) acc[j] = DT<T>::round(acc[j] + DT<T>::load(sr + j));
-  }
-  if (a.kind == 3 /*NLLB: next_states[next_states == 0] = hidden_states[...] */) {
-    const T* xr = reinterpret_cast<const T*>(a.x) + (size_t)t * a.H + h0;
-    for (int j = 0; j < nh; ++j)
-      if (acc[j] == 0.f) acc[j] = DT<T>::load(xr + j);
-  }
-  for (int j = 0; j < nh; ++j) DT<T>::store(reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0 + j, acc[j]);
+  if (h0 < a.H) combine_cols<T>(a, blockIdx.y, h0);
 }
 
 __global__ void shared_only_index_kernel(IndexArgs a) {

@@ -424,3 +424,35 @@ def test_ep_two_ranks_with_shared_expert():
         assert_block_close(out, ref, torch.bfloat16, f"EP rank {r} deepseek output")
     for eng in engs:
         eng.close()
+
+
+@pytest.mark.parametrize("family", ["mixtral", "deepseek"])
+def test_fused_combine_is_stable_over_many_decode_steps(family):
+    """Decode-sized forwards combine inside FFN stage 2 (last-arriving block per column tile, device-coherent
+    loads of the other experts' rows).  Alternate two inputs for many steps: a stale row from the previous
+    step, or a combine that ran before a producer finished, would change some output bit."""
+    h, f, e, k, n_shared = 512, 384, 8, 2, 0
+    if family == "deepseek":
+        e, k, n_shared = 16, 6, 2
+    gate, experts, shared = make_weights(family, h, f, e, 960, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=8)
+    register_all(eng, experts, shared)
+    g = gate.to(DEV)
+    xs = [acts(t, h, torch.bfloat16, 970 + i).to(DEV) for i, t in enumerate((1, 3))]
+    refs = []
+    for x in xs:
+        if family == "mixtral":
+            refs.append(R.block_mixtral(x.cpu()[None], gate, experts, top_k=k))
+        else:
+            refs.append(R.block_deepseek(x.cpu()[None], gate, experts, k, shared=shared))
+    first = [None, None]
+    for step in range(400):
+        i = step & 1
+        out_t = eng.forward(0, xs[i], g)
+        if first[i] is None:
+            first[i] = out_t.clone()
+            assert_block_close(first[i], refs[i], torch.bfloat16, f"{family} decode step output")
+        elif step % 7 == 0 or step > 390:
+            assert torch.equal(out_t, first[i]), f"step {step}: output changed between identical forwards"
+    torch.cuda.synchronize()
+    eng.close()
