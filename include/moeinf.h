@@ -311,7 +311,7 @@ int moeinf_ep_row_elems(const moeinf_engine* eng, int32_t* elems);
 int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows,
                    void* stream);
 /* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, ep_row_elems];
- * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows zero). */
+ * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows are left untouched: nobody reads them). */
 int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream);
 /* Combine replies: ret_dev [ep_size*cap_rows, H] holds, in the order moeinf_ep_pack produced,
  * the expert outputs for this rank's routed rows; writes out_dev [tokens, H].  With a shared expert

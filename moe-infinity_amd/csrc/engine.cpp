@@ -196,6 +196,10 @@ struct moeinf_engine {
           *d_ep_pair_pos = nullptr;
   int ep_cap_rows = 0;
 
+  // stage-2 output override of the expert-parallel FFN: rows go straight to the reply buffer, in arrival order
+  void* ovr_out = nullptr;
+  const int32_t* ovr_map = nullptr;
+
   // last forward
   int last_T = 0, last_layer = -1;
   hipStream_t last_stream = nullptr;
@@ -614,6 +618,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   } else {
     s.K = g->F; s.R = g->H; s.K_sh = g->Fs; s.R_sh = g->H;
     s.in = g->d_h; s.ld_in = g->ldh; s.row_map = nullptr; s.out = g->d_y; s.ld_out = g->H;
+    if (g->ovr_out) { s.out = g->ovr_out; s.out_map = g->ovr_map; }
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[2]; s.off_a_sh = bs.off[2]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
@@ -1316,6 +1321,14 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   hipStream_t st = (hipStream_t)stream;
   CHK(ep_alloc(g, cap_rows));
   const int np = g->last_T * g->K, ep = g->cfg.ep_size;
+  if (np <= 64) {  // decode: one launch
+    EpPackArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
+    pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
+    HIPCHK(launch_ep_pack_small(pa, g->d_pair_valid, np, send_counts_dev, st));
+    return MOEINF_OK;
+  }
   HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
@@ -1353,9 +1366,13 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
   HIPCHK(launch_dispatch_index(ia, st));
   const int owned = std::max(1, g->owned_experts);
-  CHK(dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
-                       (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr, mp, nullptr, nullptr));
-  HIPCHK(launch_ep_unsort(g->d_y, y_dev, g->d_pair_slot, nrows, g->H, g->dt, st));
+  // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
+  // row), so the reply needs no un-sort pass
+  g->ovr_out = y_dev; g->ovr_map = g->d_slot_pair;
+  const int rc = dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
+                                  (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr, mp, nullptr, nullptr);
+  g->ovr_out = nullptr; g->ovr_map = nullptr;
+  if (rc != MOEINF_OK) return rc;
   g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));

@@ -41,6 +41,7 @@ struct FfnStage {
   const int32_t* row_map;  // stage 1: expert-sorted row -> token id (fused gather); nullptr: identity
   void* out;               // [rows, ld_out]
   int64_t ld_out;
+  const int32_t* out_map;  // expert-sorted row -> output row (scatter fused into the epilogue); nullptr: identity
   const uint64_t* wptr;    // [E+1] device base pointer of every expert blob of this layer (0 = absent);
                            // entry E is the shared expert (DeepSeek) or 0
   const int32_t* active;   // [<= E+1] ids of experts with tokens, ascending
@@ -143,6 +144,9 @@ struct EpPackArgs {
   int K, H, ep_size, cap_rows, dtype;
 };
 hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
+// n_pairs <= 64: dest keys + stable ranks + row copy in one launch (counts/offsets/slot_pair of `a` unused);
+// send_counts (optional, [ep_size]) receives the rows per destination
+hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st);
 // y_rows[r] = (row_slot[r] >= 0) ? y_sorted[row_slot[r]] : 0
 hipError_t launch_ep_unsort(const void* y_sorted, void* y_rows, const int32_t* row_slot, int n_rows, int H,
                             int dtype, hipStream_t st);

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
               v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
             if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
           }
-          T* op = reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow;
+          const int srow = off + tile * 16 + tn;
+          T* op = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[srow] : srow) * s.ld_out + orow;
           if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v); else DT<T>::store(op, v);
         }
       }
@@ -529,7 +530,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
                 v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
               if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
             }
-            DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tile * 16 + tn) * s.ld_out + orow, v);
+            const int srow = off + tile * 16 + tn;
+            DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[srow] : srow) * s.ld_out + orow, v);
           }
         }
         __syncthreads();
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
                   v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
                 if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
               }
-              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(off + tok) * s.ld_out + orow, v);
+              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out + orow, v);
             }
           }
         }
@@ -1481,6 +1483,50 @@ __global__ __launch_bounds__(256) void ep_pack_kernel(EpPackArgs a) {
   constexpr int EPV = DT<T>::EPV;
   for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
 }
+// <= 64 (token,k) pairs (decode): destination keys, stable ranks and the row copy in ONE launch.  Every block
+// (= one send row (d, pos)) re-derives "which pair is the pos-th one bound for rank d" with two ballots over the
+// pairs — the same stable order the dest-key + dispatch_index + pack sequence produces.
+template <typename T>
+__global__ __launch_bounds__(256) void ep_pack_small_kernel(EpPackArgs a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts) {
+  __shared__ int s_pair, s_cnt;
+  const int row = blockIdx.x;
+  const int d = row / a.cap_rows, pos = row % a.cap_rows;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int key = -1;
+    if (lane < n_pairs) {
+      const int e = a.topk_idx[lane];
+      if (e >= 0 && (!pair_valid || pair_valid[lane])) key = e % a.ep_size;
+    }
+    const uint64_t mine = __ballot(key == d);
+    const int rank = __popcll(mine & lanes_below(lane));
+    const uint64_t hit = __ballot(key == d && rank == pos);
+    if (lane == 0) { s_pair = hit ? (__ffsll((unsigned long long)hit) - 1) : -1; s_cnt = __popcll(mine); }
+    if (row == 0 && lane < n_pairs && key < 0) a.pair_pos[lane] = -1;  // never dispatched
+  }
+  __syncthreads();
+  const int pair = s_pair;
+  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
+  int32_t* tail = reinterpret_cast<int32_t*>(dst + a.H);
+  if (threadIdx.x == 0 && pos == 0 && send_counts) send_counts[d] = s_cnt;
+  if (pair < 0) {
+    if (threadIdx.x == 0) tail[0] = -1;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    tail[0] = a.topk_idx[pair];
+    a.pair_pos[pair] = row;
+  }
+  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)(pair / a.K) * a.H;
+  constexpr int EPV = DT<T>::EPV;
+  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
+}
+hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st) {
+  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_small_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);
+  else hipLaunchKernelGGL(ep_pack_small_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);
+  return hipGetLastError();
+}
+
 __global__ void ep_fill_kernel(int32_t* p, int n, int v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -264,16 +264,16 @@ def test_error_paths_do_not_abort():
     eng.close()
 
 
-def test_ep_two_ranks_emulated_on_one_gpu():
-    """Expert-parallel kernels (pack / grouped FFN on received rows / unsort / combine) with
+@pytest.mark.parametrize("ts", [[5, 3], [40, 33]], ids=["decode_sized_one_launch_pack", "many_pairs_indexed_pack"])
+def test_ep_two_ranks_emulated_on_one_gpu(ts):
+    """Expert-parallel kernels (pack / grouped FFN on received rows, replies scattered in place / combine) with
     ep_size=2: two engines on the same GPU play rank 0 and rank 1, the test performs the two
     all-to-alls by swapping buffer halves.  Result per rank must equal the oracle block."""
     from moe_infinity_amd import MoEEngine
     from moe_infinity_amd import config as Cf
     from moe_infinity_amd.engine import FWD_ROUTE_ONLY
 
-    h, f, e, k, world = 256, 512, 8, 2, 2
-    ts = [5, 3]  # ragged token counts per rank
+    h, f, e, k, world = 256, 512, 8, 2, 2  # ts: ragged token counts per rank
     cap = max(ts) * k
     gate, experts, _ = make_weights("mixtral", h, f, e, 400, torch.bfloat16)
     engs = []
