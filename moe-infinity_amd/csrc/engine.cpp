@@ -188,6 +188,7 @@ struct moeinf_engine {
   struct PendingMirror { uint64_t seq; int32_t* buf; int layer; int T; bool prof; };
   std::deque<PendingMirror> pend;
   std::vector<int32_t*> mirror_pool;
+  int32_t* mirror_slab = nullptr;  // one pinned allocation holding every pooled mirror
   int owned_experts = 0;
 
   // EP workspace (lazily allocated)
@@ -309,8 +310,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
                   g->d_arrive, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
-  for (auto& pm : g->pend) hipHostFree(pm.buf);
-  for (auto b : g->mirror_pool) hipHostFree(b);
+  if (g->mirror_slab) hipHostFree(g->mirror_slab);
   if (g->stage_demand) hipFree(g->stage_demand);
   if (g->stage_prefetch) hipFree(g->stage_prefetch);
   if (g->h_mirror) hipHostFree(g->h_mirror);
@@ -391,6 +391,12 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMalloc(&g->stage_demand, (size_t)std::max(g->lay.total, g->lay_sh.total)));
   TRYHIP(hipMalloc(&g->stage_prefetch, (size_t)g->lay.total));
   TRYHIP(hipHostMalloc((void**)&g->h_mirror, (1 + 2 * E1) * sizeof(int32_t), hipHostMallocDefault));
+  {
+    const size_t per = ((size_t)(1 + 2 * E1) + 15) / 16 * 16;  // ints per mirror, 64-byte aligned
+    TRYHIP(hipHostMalloc((void**)&g->mirror_slab, per * kFenceRing * sizeof(int32_t), hipHostMallocDefault));
+    memset(g->mirror_slab, 0, per * kFenceRing * sizeof(int32_t));
+    for (int i = 0; i < kFenceRing; ++i) g->mirror_pool.push_back(g->mirror_slab + per * i);
+  }
   TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
   *out = g;
   return MOEINF_OK;
@@ -687,12 +693,11 @@ static int plan_mirror(moeinf_engine* g, int layer, MirrorPlan& mp) {
   mp.fast = g->resident_per_layer[layer] == g->owned_experts;
   if (mp.fast) {
     drain_mirrors(g, (size_t)(kFenceRing - 4));  // a mirror must be applied before its fence leaves the ring twice
-    if (!g->mirror_pool.empty()) { mp.target = g->mirror_pool.back(); g->mirror_pool.pop_back(); }
-    else {
-      const size_t nb = (size_t)(1 + 2 * (g->E + 1)) * sizeof(int32_t);
-      HIPCHK(hipHostMalloc((void**)&mp.target, nb, hipHostMallocDefault));
-      memset(mp.target, 0, nb);
-    }
+    // at most kFenceRing - 4 mirrors are pending, and the pool was carved out of one pinned slab at creation
+    // (hipHostMalloc on the forward path stalls the device for milliseconds)
+    if (g->mirror_pool.empty()) return fail(MOEINF_ERR_STATE, "routing-mirror pool exhausted");
+    mp.target = g->mirror_pool.back();
+    g->mirror_pool.pop_back();
   } else {
     drain_mirrors(g, true);
     mp.target = g->h_mirror;

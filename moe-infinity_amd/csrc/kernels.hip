@@ -554,37 +554,47 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
 //   Loop: barrier (stage s landed, stage s-1 fully consumed) -> issue DMA of stage s+1 -> 32 MFMAs per
 //   wave on stage s.  Requires K % (k-tile) == 0 (no zero-fill path for the activations).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NMAT, int RGB>
-__global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
+// NWV waves per block in a 2 x (NWV/2) grid: 4 waves cover 128 tokens per pass over the weights, 8 waves 256
+// (experts with more than 128 rows would otherwise stream their weights from HBM twice).
+// XL (needs K % (2 k-tiles) == 0): the activation image of a stage is filled in FULL 128-byte lines — one DMA =
+// 8 token rows x 128 B (both k-tiles of the stage) instead of 16 rows x 64 B: half the cache lines per
+// instruction on the texture-addresser path, which is what bounds this kernel at 128-256 tokens per expert.  The
+// DMA writes LDS linearly (base + lane*16), so the bank swizzle is applied to the SOURCE: lane (r = lane/8,
+// c = lane%8) fetches 16-byte chunk (c ^ r) of row r; a fragment read of (token n, chunk ch) then goes to piece
+// n/8, byte r*128 + ((ch ^ r) << 4), r = n%8 — conflict-free for ds_read_b128.
+template <typename T, int NMAT, int RGB, int NWV, bool XL>
+__global__ __launch_bounds__(NWV * 64) void ffn_gemm_lds_kernel(FfnStage s) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;
   constexpr int RGW = RGB / 2;
-  constexpr int NTB = 8, NTW = 4;
+  constexpr int WC = NWV / 2;          // wave columns
+  constexpr int NTW = 4, NTB = WC * NTW;
+  constexpr int XPW = XL ? 2 * NTB / NWV : NTB / NWV;  // activation DMA pieces per wave and k-tile pair
   constexpr int KK = 2;
   constexpr int A_TILES = KK * NMAT * RGB;
   constexpr int B_TILES = KK * NTB;
   constexpr int STAGE = (A_TILES + B_TILES) * 1024;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-  const int u = blockIdx.y;
+  const int u = blockIdx.y, bx = blockIdx.x;
   if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
   const int e = s.active[u];
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
-  const int rg0 = blockIdx.x * RGB;
+  const int rg0 = bx * RGB;
   const int nrg_total = (R + 15) / 16;
   if (rg0 >= nrg_total) return;
   const int cnt = s.counts[e];
   const int off = s.offsets[e];
   const char* W = reinterpret_cast<const char*>(s.wptr[e]);
   if (W == nullptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    if (threadIdx.x == 0 && bx == 0) atomicExch(s.miss_flag, 1);
     return;
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int n = lane & 15, q = lane >> 4;
   const int KB = K / EPT;  // K % EPT == 0 (checked by the launcher)
   const int KS = (KB + KK - 1) / KK;
@@ -597,13 +607,15 @@ __global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
 
   for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
     const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);
-    // activation rows this wave DMA-loads: token groups `wave` and `wave + 4`
-    const T* xrp[2];
+    // activation rows this wave DMA-loads: token groups `wave`, `wave + NWV` (16 rows x 64 B each), or with XL the
+    // 8-row pieces `wave + NWV*i` (8 rows x 128 B, source chunk swizzled)
+    const T* xrp[XPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int srow = off + min((tile0 + wave + 4 * i) * 16 + n, cnt - 1);
+    for (int i = 0; i < XPW; ++i) {
+      const int trow = XL ? (tile0 * 16 + (wave + NWV * i) * 8 + (lane >> 3)) : ((tile0 + wave + NWV * i) * 16 + n);
+      const int srow = off + min(trow, cnt - 1);
       const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + q * EPV;
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (XL ? (((lane & 7) ^ (lane >> 3)) * EPV) : q * EPV);
     }
     f32x4 acc[RGW][NTW][NMAT];
 #pragma unroll
@@ -620,22 +632,32 @@ __global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
         const int kb = ks * KK + kk;
         if (kb < KB) {
 #pragma unroll
-          for (int i = 0; i < RGB / 4; ++i) {
-            const int rg_l = wave + 4 * i;
-            if (rg0 + rg_l < nrg_total) {
+          for (int i = 0; i < (RGB + NWV - 1) / NWV; ++i) {
+            const int rg_l = wave + NWV * i;
+            if (rg_l < RGB && rg0 + rg_l < nrg_total) {
 #pragma unroll
               for (int m = 0; m < NMAT; ++m)
                 __builtin_amdgcn_global_load_lds((gptr_t)(am[m] + rg_l * rg_stride + (size_t)kb * 1024),
                                                  (lptr_t)(base + ((kk * NMAT + m) * RGB + rg_l) * 1024), 16, 0, 0);
             }
           }
+          if constexpr (!XL) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int tg_l = wave + 4 * i;
-            if (tg_l < ntl)
-              __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT),
-                                               (lptr_t)(base + (A_TILES + kk * NTB + tg_l) * 1024), 16, 0, 0);
+            for (int i = 0; i < XPW; ++i) {
+              const int tg_l = wave + NWV * i;
+              if (tg_l < ntl)
+                __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT),
+                                                 (lptr_t)(base + (A_TILES + kk * NTB + tg_l) * 1024), 16, 0, 0);
+            }
           }
+        }
+      }
+      if constexpr (XL) {
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+          const int pc = wave + NWV * i;  // 8-row piece; token group pc/2
+          if (pc < 2 * ntl)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + (A_TILES + pc) * 1024), 16, 0, 0);
         }
       }
     };
@@ -657,7 +679,14 @@ __global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
             for (int m = 0; m < NMAT; ++m) af[a][m] = *reinterpret_cast<const u32x4*>(base + ((kk * NMAT + m) * RGB + rg_l) * 1024);
           }
 #pragma unroll
-          for (int b = 0; b < NTW; ++b) bf[b] = *reinterpret_cast<const u32x4*>(base + (A_TILES + kk * NTB + wc * NTW + b) * 1024);
+          for (int b = 0; b < NTW; ++b) {
+            if constexpr (XL) {
+              const int r = n & 7, ch = kk * 4 + q;
+              bf[b] = *reinterpret_cast<const u32x4*>(smem + (ks & 1) * STAGE + (A_TILES + (wc * NTW + b) * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4));
+            } else {
+              bf[b] = *reinterpret_cast<const u32x4*>(base + (A_TILES + kk * NTB + wc * NTW + b) * 1024);
+            }
+          }
 #pragma unroll
           for (int a = 0; a < RGW; ++a) {
             if (rg0 + wr * RGW + a < nrg_total) {
@@ -705,6 +734,161 @@ __global__ __launch_bounds__(256) void ffn_gemm_lds_kernel(FfnStage s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ffn_gemm_hyb: grouped GEMM for experts with up to a few hundred tokens, where the stage is still bound
+// by streaming the weights from HBM (ridge: ~300 tokens per expert).  What limits ffn_gemm_lds there is
+// BYTES IN FLIGHT: a CU has to keep latency x bandwidth (~2 us x 25 B/ns) of weight bytes outstanding, and
+// with both operands staged in LDS the 160 KiB cap that at 2 blocks x one 16-KiB weight stage.
+// Here only the ACTIVATIONS go through LDS (they are shared by all waves of the block); every wave owns
+// private weight rows and streams its tiles straight into registers, like the decode kernel (the tiled HBM
+// layout is the MFMA A fragment).  LDS per block drops to 2 x KK x 8 KiB, so 3-4 blocks fit a CU and the
+// weight bytes in flight no longer depend on LDS.
+//   block = 4 waves; wave w owns RW row groups (16 rows each) of NMAT matrices (RW*NMAT = 2) against 8 token
+//   groups (128 tokens): 16 accumulator tiles.  Stage = KK k-tiles: A fragments of stage s+1 are loaded into a
+//   second register set and B tiles of stage s+1 are DMA'd into the other LDS buffer while stage s computes.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NMAT, int RW, int KK>
+__global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int EPT = 4 * EPV;
+  constexpr int NTB = 8;
+  constexpr int RGB = 4 * RW;            // row groups per block
+  constexpr int STAGE = KK * NTB * 1024;  // activation bytes per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int u = blockIdx.y;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int nrg_total = (R + 15) / 16;
+  if ((int)blockIdx.x * RGB >= nrg_total) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int KB = K / EPT;  // K % EPT == 0 (checked by the launcher)
+  const int KS = (KB + KK - 1) / KK;
+  const size_t rg_stride = (size_t)KB * 1024;
+  const int rgw0 = blockIdx.x * RGB + wave * RW;  // first row group of this wave
+  // row groups past the end (R not a multiple of the block's rows) re-read the last one; their results are dropped
+  const char* ap[RW][NMAT];
+#pragma unroll
+  for (int a = 0; a < RW; ++a) {
+    const int rg = min(rgw0 + a, nrg_total - 1);
+    ap[a][0] = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg * rg_stride + lane * 16;
+    if (NMAT == 2) ap[a][NMAT - 1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg * rg_stride + lane * 16;
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
+    const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);
+    const T* xrp[2];  // activation rows this wave DMA-loads: token groups `wave` and `wave + 4`
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int srow = off + min((tile0 + wave + 4 * i) * 16 + n, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + q * EPV;
+    }
+    f32x4 acc[RW][NTB][NMAT];
+#pragma unroll
+    for (int a = 0; a < RW; ++a)
+#pragma unroll
+      for (int b = 0; b < NTB; ++b)
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) acc[a][b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 af[2][KK][RW][NMAT];  // two register sets of weight fragments (current / next stage)
+    auto issue = [&](int ks, int buf, u32x4 (&dst)[KK][RW][NMAT]) {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int kb = min(ks * KK + kk, KB - 1);  // a short last stage re-reads tile KB-1 (never multiplied)
+#pragma unroll
+        for (int a = 0; a < RW; ++a)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) dst[kk][a][m] = ld16_nt(ap[a][m] + (size_t)kb * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int tg_l = wave + 4 * i;
+          if (tg_l < ntl)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT), (lptr_t)(base + (kk * NTB + tg_l) * 1024), 16, 0, 0);
+        }
+      }
+    };
+    auto compute = [&](int ks, int buf, const u32x4 (&cur)[KK][RW][NMAT]) {
+      const char* base = smem + buf * STAGE + lane * 16;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        if (ks * KK + kk < KB) {
+#pragma unroll
+          for (int b = 0; b < NTB; ++b) {
+            if (b < ntl) {
+              const u32x4 bf = *reinterpret_cast<const u32x4*>(base + (kk * NTB + b) * 1024);
+#pragma unroll
+              for (int a = 0; a < RW; ++a) {
+                mma16<T>(acc[a][b][0], cur[kk][a][0], bf);
+                if (NMAT == 2) mma16<T>(acc[a][b][NMAT - 1], cur[kk][a][NMAT - 1], bf);
+              }
+            }
+          }
+        }
+      }
+    };
+
+    issue(0, 0, af[0]);
+    for (int ks = 0; ks < KS; ks += 2) {  // unrolled by two so both register sets are indexed statically
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage ks: this wave's fragments and activation DMA landed
+      __syncthreads();                                   // ... everybody's DMA has, and stage ks-1 is fully consumed
+      if (ks + 1 < KS) issue(ks + 1, 1, af[1]);
+      compute(ks, 0, af[0]);
+      if (ks + 1 < KS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 2 < KS) issue(ks + 2, 0, af[0]);
+        compute(ks + 1, 1, af[1]);
+      }
+    }
+    // epilogue straight from the accumulators (no K split): lane holds 4 consecutive rows of one token
+#pragma unroll
+    for (int a = 0; a < RW; ++a) {
+      const int r0 = (rgw0 + a) * 16 + q * 4;
+#pragma unroll
+      for (int b = 0; b < NTB; ++b) {
+        const int tok = (tile0 + b) * 16 + n;
+        if (tok < cnt && rgw0 + a < nrg_total) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int orow = r0 + j;
+            if (orow < R) {
+              float v = DT<T>::round(acc[a][b][0][j]);
+              if (s.epi == EPI_GATED_SILU) {
+                const float bb = DT<T>::round(acc[a][b][NMAT - 1][j]);
+                const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+                v = DT<T>::round(sl * bb);
+              } else {
+                if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
+                  v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+              }
+              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out + orow, v);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next pass re-uses LDS buffer 0
+  }
+}
+
 // tuning knobs (overridable for sweeps: MOEINF_FFN_NW=4|8, MOEINF_FFN_U=2|4|8)
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -719,16 +903,42 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
     static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
     const int ept = sizeof(T) == 2 ? 32 : 16;
     const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
-    if (use_gemm == 2 && k_ok) {  // LDS-staged grouped GEMM
-      static const int rgb_plain = env_int("MOEINF_FFN_GEMM_RGB", 0);
+    // 33-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
+    // amortise staging the weights in LDS -> the hybrid kernel (measured -15 % on that shape, sweep in profiles/)
+    static const int hyb_rows = env_int("MOEINF_GEMM_HYB_ROWS", 64);
+    if ((use_gemm == 3 || (use_gemm == 2 && max_rows <= hyb_rows)) && k_ok) {  // weights -> registers, activations -> LDS
+      static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
+      static const int rwx = env_int("MOEINF_GEMM_HYB_RW", 1);  // 2: twice the rows per wave (4 MFMAs per activation fragment read)
+#define HYB(NM, RWV, KKV) hipLaunchKernelGGL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
       if constexpr (NMAT == 2) {
-        hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 2, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+        if (rwx == 2) { if (kk == 1) HYB(2, 2, 1); else HYB(2, 2, 2); }
+        else { if (kk == 4) HYB(2, 1, 4); else if (kk == 1) HYB(2, 1, 1); else HYB(2, 1, 2); }
+      } else {
+        if (rwx == 2) { if (kk == 1) HYB(1, 4, 1); else HYB(1, 4, 2); }
+        else { if (kk == 4) HYB(1, 2, 4); else if (kk == 1) HYB(1, 2, 1); else HYB(1, 2, 2); }
+      }
+#undef HYB
+    } else if (use_gemm == 2 && k_ok) {  // LDS-staged grouped GEMM
+      static const int rgb_plain = env_int("MOEINF_FFN_GEMM_RGB", 0);
+      static const int wide_env = env_int("MOEINF_GEMM_WIDE", -1);
+      const bool wide = wide_env >= 0 ? wide_env != 0 : max_rows > 128;  // 8 waves: 256 tokens per pass over the weights
+      static const int xl_env = env_int("MOEINF_GEMM_XL", 1);
+      const bool xl = xl_env && (s.K % (2 * ept)) == 0 && (s.K_sh % (2 * ept)) == 0;  // full-line activation staging
+      auto go = [&](auto kern, int rgb, int nwv) {
+        hipLaunchKernelGGL(kern, dim3((grid.x + rgb - 1) / rgb, grid.y), dim3(nwv * 64), 0, st, s);
+      };
+#define GO(NM, RG, NW) do { if (xl) go(ffn_gemm_lds_kernel<T, NM, RG, NW, true>, RG, NW); else go(ffn_gemm_lds_kernel<T, NM, RG, NW, false>, RG, NW); } while (0)
+      if constexpr (NMAT == 2) {
+        static const int rgb_gated = env_int("MOEINF_FFN_GEMM_RGB2", 4);
+        if (rgb_gated == 8) { if (wide) GO(2, 8, 8); else GO(2, 8, 4); }
+        else { if (wide) GO(2, 4, 8); else GO(2, 4, 4); }
       } else {
         // 128-row blocks need >= 2 blocks per CU to hide the DMA latency; fall back to 64-row blocks otherwise
-        const bool big = rgb_plain ? rgb_plain == 8 : ((grid.x + 7) / 8) * grid.y >= 512;
-        if (big) hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 1, 8>), dim3((grid.x + 7) / 8, grid.y), dim3(256), 0, st, s);
-        else hipLaunchKernelGGL((ffn_gemm_lds_kernel<T, 1, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+        const bool big = rgb_plain ? rgb_plain == 8 : (((grid.x + 7) / 8) * grid.y >= 512 && s.K >= 4096);
+        if (big) { if (wide) GO(1, 8, 8); else GO(1, 8, 4); }
+        else     { if (wide) GO(1, 4, 8); else GO(1, 4, 4); }
       }
+#undef GO
     } else if (use_gemm) {
       const int nt = force_nt ? force_nt : 4;  // measured: (RG,NT)=(2,4)/(4,4) beats (1,8)/(2,8) at t_e ~128 (profiles/r01_ffn_sweep_prefill_gemm.txt)
       if constexpr (NMAT == 2) {  // gated: 2 matrices -> (RG, NT) = (2,4) or (1,8)

@@ -456,3 +456,19 @@ def test_fused_combine_is_stable_over_many_decode_steps(family):
             assert torch.equal(out_t, first[i]), f"step {step}: output changed between identical forwards"
     torch.cuda.synchronize()
     eng.close()
+
+
+@pytest.mark.parametrize("family", ["mixtral", "nllb"])
+def test_mid_sized_batch_33_to_64_rows_per_expert(family):
+    """Between the decode kernel (<= 32 rows per expert) and the LDS-staged GEMM: the hybrid kernel (weights
+    straight to registers, activations through LDS).  Two passes: decision path, then the sync-free path."""
+    t, h, f, e, k = 160, 256, 512, 8, 2
+    gate, experts, _ = make_weights(family, h, f, e, 980, torch.bfloat16, **({"gate_std": 0.5} if family == "nllb" else {}))
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 981)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k) if family == "mixtral" else R.block_nllb(x[None], gate, experts)
+    assert_block_close(out, ref, torch.bfloat16, f"{family} 160-token block")
+    eng.close()
