@@ -747,8 +747,11 @@ __global__ __launch_bounds__(NWV * 64) void ffn_gemm_lds_kernel(FfnStage s) {
 //   groups (128 tokens): 16 accumulator tiles.  Stage = KK k-tiles: A fragments of stage s+1 are loaded into a
 //   second register set and B tiles of stage s+1 are DMA'd into the other LDS buffer while stage s computes.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NMAT, int RW, int KK>
+//   XL: activation image in full 128-byte lines with the source-side swizzle of ffn_gemm_lds (needs KK even and
+//   an even number of k-tiles).
+template <typename T, int NMAT, int RW, int KK, bool XL>
 __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
+  static_assert(!XL || KK % 2 == 0, "full-line staging moves k-tiles in pairs");
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;
   constexpr int NTB = 8;
@@ -791,12 +794,14 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
 
   for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
     const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);
-    const T* xrp[2];  // activation rows this wave DMA-loads: token groups `wave` and `wave + 4`
+    constexpr int XPW = XL ? 4 : 2;
+    const T* xrp[XPW];  // activation rows this wave DMA-loads: token groups `wave`, `wave + 4` / 8-row pieces `wave + 4i`
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int srow = off + min((tile0 + wave + 4 * i) * 16 + n, cnt - 1);
+    for (int i = 0; i < XPW; ++i) {
+      const int trow = XL ? (tile0 * 16 + (wave + 4 * i) * 8 + (lane >> 3)) : ((tile0 + wave + 4 * i) * 16 + n);
+      const int srow = off + min(trow, cnt - 1);
       const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + q * EPV;
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (XL ? (((lane & 7) ^ (lane >> 3)) * EPV) : q * EPV);
     }
     f32x4 acc[RW][NTB][NMAT];
 #pragma unroll
@@ -816,11 +821,25 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
         for (int a = 0; a < RW; ++a)
 #pragma unroll
           for (int m = 0; m < NMAT; ++m) dst[kk][a][m] = ld16_nt(ap[a][m] + (size_t)kb * 1024);
+        if constexpr (!XL) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int tg_l = wave + 4 * i;
-          if (tg_l < ntl)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT), (lptr_t)(base + (kk * NTB + tg_l) * 1024), 16, 0, 0);
+          for (int i = 0; i < 2; ++i) {
+            const int tg_l = wave + 4 * i;
+            if (tg_l < ntl)
+              __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kb * EPT), (lptr_t)(base + (kk * NTB + tg_l) * 1024), 16, 0, 0);
+          }
+        }
+      }
+      if constexpr (XL) {
+#pragma unroll
+        for (int j = 0; j < KK / 2; ++j) {
+          const int pr = min(ks * (KK / 2) + j, KB / 2 - 1);  // k-tile pair (a short last stage re-reads the last pair)
+#pragma unroll
+          for (int i = 0; i < XPW; ++i) {
+            const int pc = wave + 4 * i;
+            if (pc < 2 * ntl)
+              __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)pr * 2 * EPT), (lptr_t)(base + (j * 2 * NTB + pc) * 1024), 16, 0, 0);
+          }
         }
       }
     };
@@ -832,7 +851,9 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
 #pragma unroll
           for (int b = 0; b < NTB; ++b) {
             if (b < ntl) {
-              const u32x4 bf = *reinterpret_cast<const u32x4*>(base + (kk * NTB + b) * 1024);
+              const int r = n & 7, ch = (kk & 1) * 4 + q;
+              const u32x4 bf = XL ? *reinterpret_cast<const u32x4*>(smem + buf * STAGE + ((kk >> 1) * 2 * NTB + b * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4))
+                                  : *reinterpret_cast<const u32x4*>(base + (kk * NTB + b) * 1024);
 #pragma unroll
               for (int a = 0; a < RW; ++a) {
                 mma16<T>(acc[a][b][0], cur[kk][a][0], bf);
@@ -903,19 +924,22 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
     static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
     const int ept = sizeof(T) == 2 ? 32 : 16;
     const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
-    // 33-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
+    // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
     // amortise staging the weights in LDS -> the hybrid kernel (measured -15 % on that shape, sweep in profiles/)
     static const int hyb_rows = env_int("MOEINF_GEMM_HYB_ROWS", 64);
     if ((use_gemm == 3 || (use_gemm == 2 && max_rows <= hyb_rows)) && k_ok) {  // weights -> registers, activations -> LDS
       static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
-      static const int rwx = env_int("MOEINF_GEMM_HYB_RW", 1);  // 2: twice the rows per wave (4 MFMAs per activation fragment read)
-#define HYB(NM, RWV, KKV) hipLaunchKernelGGL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
+      static const int rwx = 1;
+      static const int hxl_env = env_int("MOEINF_GEMM_XL", 1);
+      const bool hxl = hxl_env && (s.K % (2 * ept)) == 0 && (s.K_sh % (2 * ept)) == 0;
+#define HYB(NM, RWV, KKV, XLV) hipLaunchKernelGGL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV, XLV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
+      (void)rwx;
       if constexpr (NMAT == 2) {
-        if (rwx == 2) { if (kk == 1) HYB(2, 2, 1); else HYB(2, 2, 2); }
-        else { if (kk == 4) HYB(2, 1, 4); else if (kk == 1) HYB(2, 1, 1); else HYB(2, 1, 2); }
+        if (kk == 2) { if (hxl) HYB(2, 1, 2, true); else HYB(2, 1, 2, false); }
+        else { if (hxl) HYB(2, 1, 4, true); else HYB(2, 1, 4, false); }
       } else {
-        if (rwx == 2) { if (kk == 1) HYB(1, 4, 1); else HYB(1, 4, 2); }
-        else { if (kk == 4) HYB(1, 2, 4); else if (kk == 1) HYB(1, 2, 1); else HYB(1, 2, 2); }
+        if (kk == 2) { if (hxl) HYB(1, 2, 2, true); else HYB(1, 2, 2, false); }
+        else { if (hxl) HYB(1, 2, 4, true); else HYB(1, 2, 4, false); }
       }
 #undef HYB
     } else if (use_gemm == 2 && k_ok) {  // LDS-staged grouped GEMM
@@ -969,8 +993,10 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   const int nw = env_nw ? env_nw : (kbytes >= 16384 ? 8 : 4);
   const int u = env_u ? env_u : 4;
   static const int env_nt = env_int("MOEINF_FFN_NT", 0);
-  // the 64-token variant runs at low occupancy (~240 VGPRs): it only pays once an expert needs >= 3 token tiles
-  const bool many = s.fuse_combine ? false : (env_nt ? env_nt > 1 : max_rows_per_expert > 32);
+  // the decode kernel re-streams an expert's weights for every 16 rows: from 17 rows on, the GEMM kernels (one pass
+  // per 128/256 rows) win — Mixtral at 64 tokens: 761 -> 549 us per layer (profiles/r01_ffn_sweep_midsize.txt)
+  static const int many_rows = env_int("MOEINF_FFN_MANY_ROWS", 16);
+  const bool many = s.fuse_combine ? false : (env_nt ? env_nt > 1 : max_rows_per_expert > many_rows);
   if (s.dtype == DT_BF16) {
     if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   } else {

@@ -459,8 +459,8 @@ def test_fused_combine_is_stable_over_many_decode_steps(family):
 
 
 @pytest.mark.parametrize("family", ["mixtral", "nllb"])
-def test_mid_sized_batch_33_to_64_rows_per_expert(family):
-    """Between the decode kernel (<= 32 rows per expert) and the LDS-staged GEMM: the hybrid kernel (weights
+def test_mid_sized_batch_17_to_64_rows_per_expert(family):
+    """Between the decode kernel (<= 16 rows per expert) and the LDS-staged GEMM: the hybrid kernel (weights
     straight to registers, activations through LDS).  Two passes: decision path, then the sync-free path."""
     t, h, f, e, k = 160, 256, 512, 8, 2
     gate, experts, _ = make_weights(family, h, f, e, 980, torch.bfloat16, **({"gate_std": 0.5} if family == "nllb" else {}))

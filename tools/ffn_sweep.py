@@ -66,7 +66,7 @@ if __name__ == "__main__":
     wls = sys.argv[1:] or ["mixtral_8x7b:1:4", "deepseek_v2_lite:1:4"]
     for spec in wls:
         wl, B, L = spec.split(":")
-        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_HYB_ROWS": 0}]
+        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_XL": 0}, {"MOEINF_FFN_MANY_ROWS": 16}]
         for env in envs:
             r = run(wl, int(B), int(L), 200 if int(B) <= 16 else 20, env)
             if "error" in r:
