@@ -386,6 +386,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRY(dmalloc(&g->d_arrive, (g->H + 15) / 16)); TRY(dmalloc(&g->d_miss, 1));
   TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
+  TRYHIP(hipMemset(g->d_active, 0, (size_t)E1 * sizeof(int32_t)));  // the FFN kernels read active[u] before they know n_active
+  TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
   TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
   TRYHIP(hipMalloc(&g->stage_demand, (size_t)std::max(g->lay.total, g->lay_sh.total)));

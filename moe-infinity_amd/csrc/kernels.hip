@@ -249,20 +249,25 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
   __shared__ float red[NW][NMAT][256];
 
+  // Prologue loads in two dependent rounds instead of three: active[u] is fetched together with n_active (entries
+  // past n_active hold stale but valid expert ids — the array is zero-initialised and only ever written with ids).
   const int u = blockIdx.y;
-  const int nact = s.n_active_host >= 0 ? s.n_active_host : *s.n_active;
-  if (u >= nact) return;
   const int e = s.active[u];
+  const int nact_dev = *s.n_active;
+  asm volatile("" ::"s"(e), "s"(nact_dev));  // keep both loads ahead of the exit branch (the compiler would sink active[u] below it)
+  const int nact = s.n_active_host >= 0 ? s.n_active_host : nact_dev;
+  if (u >= nact) return;
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
   const int r0 = blockIdx.x * 16;
   if (r0 >= R) return;
   const int off = s.offsets[e];
+  const int cnt_e = s.counts[e];  // loaded alongside wptr[e], not after it: one dependent round trip less per block
   const char* W = reinterpret_cast<const char*>(s.wptr[e]);
   // an absent expert (never on the sync-free path) computes nothing but still reports its arrival below
   if (W == nullptr && threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
-  const int cnt = W ? s.counts[e] : 0;
+  const int cnt = W ? cnt_e : 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
