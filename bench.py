@@ -242,8 +242,10 @@ def main():
     st = eng.stats()
 
     # ---- same K steps again with per-kernel HIP events on the launch stream (roofline leg)
+    # Expert-parallel runs: every rank repeats the steps (the collectives need all of them); the events bracket the
+    # owner-side FFN launches of THIS rank, and rank 0 reports its own kernels.
     roof, kernels = None, {}
-    if world == 1 and not use_ep:
+    if True:
         eng.set_profiling(True)
         fence()
         run_steps(args.warmup, args.steps)
@@ -260,25 +262,30 @@ def main():
                     "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
         kernels = {"ffn_stage1": kstat(p["ffn1_ms"], p["ffn1_launches"], p["ffn1_bytes"]),
-                   "ffn_stage2": kstat(p["ffn2_ms"], p["ffn2_launches"], p["ffn2_bytes"]),
+                   "ffn_stage2": kstat(p["ffn2_ms"], p["ffn2_launches"], p["ffn2_bytes"])}
+        if use_ep:
+            kernels["note"] = f"rank 0's owner-side FFN over the rows it received (experts e % {world} == 0)"
+        else:
+            kernels.update({
                    "route(gate+topk+index)": kstat(p["route_ms"], p["forwards"], p["route_bytes"]),
                    "combine": kstat(p["combine_ms"], p["forwards"], p["combine_bytes"]),
                    # decode-sized Mixtral/DeepSeek steps: the combine runs in the epilogue of FFN stage 2, the
                    # "combine" interval above is then an empty event-to-event interval (= the events' own cost)
                    "combine_fused_into_ffn_stage2": bool(B <= 16 and family in ("mixtral", "deepseek")
                                                          and os.environ.get("MOEINF_FUSE_COMBINE", "1") != "0"),
-                   "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)}
+                   "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)})
         k1 = kernels["ffn_stage1"]
         # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; tools/pmc_summary.py)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_mixtral8x7b.json")
-        if args.workload == "mixtral-8x7b" and B == 1 and os.path.exists(pmc):
+        if args.workload == "mixtral-8x7b" and B == 1 and not use_ep and os.path.exists(pmc):
             for name, v in json.load(open(pmc))["kernels"].items():
                 if "ffn_rows_kernel<unsigned short, 2" in name:
                     traffic = v["hbm_bytes"]
         if k1:
-            roof = {"bound": "hbm", "kernel": "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)",
+            roof = {"bound": "hbm", "kernel": "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)"
+                                              + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
                     "traffic": traffic, "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"]}
 

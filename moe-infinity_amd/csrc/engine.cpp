@@ -185,7 +185,7 @@ struct moeinf_engine {
   // (no copy command on the compute stream); it is applied to the counters/statistics lazily, once the
   // forward's end-of-forward fence has passed (no residency decision depends on it while every expert of
   // the layer is resident)
-  struct PendingMirror { uint64_t seq; int32_t* buf; int layer; int T; bool prof; };
+  struct PendingMirror { uint64_t seq; int32_t* buf; int layer; int T; bool prof; bool local; };
   std::deque<PendingMirror> pend;
   std::vector<int32_t*> mirror_pool;
   int32_t* mirror_slab = nullptr;  // one pinned allocation holding every pooled mirror
@@ -635,18 +635,22 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
 }
 
 // algorithmic bytes of one forward (profiling), from its routing mirror
-static void account_profile(moeinf_engine* g, const int32_t* mirror, int T) {
+// local = a whole local forward (router, shared expert and combine included); false = the expert-parallel owner-side
+// FFN over received rows only
+static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool local = true) {
   const int E = g->E, K = g->K;
   int64_t U = 0, rows = 0;
   for (int e = 0; e < E; ++e) { if (mirror[1 + e] > 0) { ++U; rows += mirror[1 + e]; } }
-  const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = g->has_shared ? T : 0;
+  const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = (g->has_shared && local) ? T : 0;
   const int et = g->cfg.expert_type;
   const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
   const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
   g->prof.ffn1_bytes += U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
   g->prof.ffn2_bytes += U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
-  g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
-  g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
+  if (local) {
+    g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
+    g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
+  }
   g->prof.forwards += 1;
   if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
 }
@@ -679,7 +683,7 @@ static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
       g->pol[idx].incache += 1;
       g->pol[idx].last_access = ++g->clock;
     }
-    if (pm.prof) account_profile(g, pm.buf, pm.T);
+    if (pm.prof) account_profile(g, pm.buf, pm.T, pm.local);
     g->mirror_pool.push_back(pm.buf);
     g->pend.pop_front();
   }
@@ -830,7 +834,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
   if (fused) *fused = false;
   if (mp.fast) {
     moeinf_engine::PendingMirror pm;
-    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = T; pm.prof = prof;
+    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = T; pm.prof = prof; pm.local = !g->ovr_out;
     g->pend.push_back(pm);
     for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
       const Node& n = g->nodes[node_index(g, layer, e)];
@@ -857,7 +861,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
       const int e = g->h_mirror[1 + E1 + i];
       if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d was handed rows for expert %d it does not own", g->cfg.ep_rank, e);
     }
-    if (prof) account_profile(g, g->h_mirror, T);
+    if (prof) account_profile(g, g->h_mirror, T, !g->ovr_out);
     CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused));
   }
   return MOEINF_OK;
@@ -1376,10 +1380,18 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
   // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
   // row), so the reply needs no un-sort pass
   g->ovr_out = y_dev; g->ovr_map = g->d_slot_pair;
+  // profiling: only the two FFN stages are bracketed here (events 2..4); the other intervals are empty
+  moeinf_engine::ProfRec pr;
+  const bool prof = g->profiling;
+  if (prof) {
+    for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) { g->ovr_out = nullptr; g->ovr_map = nullptr; return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } }
+    hipEventRecord(pr.ev[0], st); hipEventRecord(pr.ev[1], st);
+  }
   const int rc = dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
-                                  (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, false, nullptr, mp, nullptr, nullptr);
+                                  (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, prof, prof ? &pr : nullptr, mp, nullptr, nullptr);
   g->ovr_out = nullptr; g->ovr_map = nullptr;
   if (rc != MOEINF_OK) return rc;
+  if (prof) { hipEventRecord(pr.ev[5], st); g->prof_pending.push_back(pr); }
   g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));

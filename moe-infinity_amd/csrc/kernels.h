@@ -147,8 +147,5 @@ hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
 // n_pairs <= 64: dest keys + stable ranks + row copy in one launch (counts/offsets/slot_pair of `a` unused);
 // send_counts (optional, [ep_size]) receives the rows per destination
 hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st);
-// y_rows[r] = (row_slot[r] >= 0) ? y_sorted[row_slot[r]] : 0
-hipError_t launch_ep_unsort(const void* y_sorted, void* y_rows, const int32_t* row_slot, int n_rows, int H,
-                            int dtype, hipStream_t st);
 
 }  // namespace moeinf

@@ -934,11 +934,9 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
     static const int hyb_rows = env_int("MOEINF_GEMM_HYB_ROWS", 64);
     if ((use_gemm == 3 || (use_gemm == 2 && max_rows <= hyb_rows)) && k_ok) {  // weights -> registers, activations -> LDS
       static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
-      static const int rwx = 1;
       static const int hxl_env = env_int("MOEINF_GEMM_XL", 1);
       const bool hxl = hxl_env && (s.K % (2 * ept)) == 0 && (s.K_sh % (2 * ept)) == 0;
 #define HYB(NM, RWV, KKV, XLV) hipLaunchKernelGGL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV, XLV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
-      (void)rwx;
       if constexpr (NMAT == 2) {
         if (kk == 2) { if (hxl) HYB(2, 1, 2, true); else HYB(2, 1, 2, false); }
         else { if (hxl) HYB(2, 1, 4, true); else HYB(2, 1, 4, false); }
@@ -1768,34 +1766,9 @@ hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, 
   return hipGetLastError();
 }
 
-__global__ void ep_fill_kernel(int32_t* p, int n, int v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st) {
   if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(ep_pack_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void ep_unsort_kernel(const T* y_sorted, T* y_rows, const int32_t* row_slot, int H) {
-  const int row = blockIdx.x;
-  const int slot = row_slot[row];
-  constexpr int EPV = DT<T>::EPV;
-  const u32x4 z = {0u, 0u, 0u, 0u};
-  for (int h = threadIdx.x * EPV; h < H; h += 256 * EPV)
-    *reinterpret_cast<u32x4*>(y_rows + (size_t)row * H + h) = (slot >= 0) ? ld16(y_sorted + (size_t)slot * H + h) : z;
-}
-hipError_t launch_ep_unsort(const void* y_sorted, void* y_rows, const int32_t* row_slot, int n_rows, int H, int dtype,
-                            hipStream_t st) {
-  if (n_rows <= 0) return hipSuccess;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(ep_unsort_kernel<uint16_t>, dim3(n_rows), dim3(256), 0, st, (const uint16_t*)y_sorted,
-                       (uint16_t*)y_rows, row_slot, H);
-  else
-    hipLaunchKernelGGL(ep_unsort_kernel<float>, dim3(n_rows), dim3(256), 0, st, (const float*)y_sorted, (float*)y_rows,
-                       row_slot, H);
   return hipGetLastError();
 }
 
