@@ -880,7 +880,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (!route_only && !(flags & MOEINF_FWD_NO_COMBINE) && !out_dev) return fail(MOEINF_ERR_INVALID, "out_dev is NULL");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
-  const int T = tokens, K = g->K, E = g->E, E1 = E + 1;
+  const int T = tokens, K = g->K, E = g->E;
 
   RouteArgs ra;
   memset(&ra, 0, sizeof ra);
@@ -954,7 +954,7 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
-  const int E = g->E, E1 = E + 1;
+  const int E = g->E;
   drain_mirrors(g, true);
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
