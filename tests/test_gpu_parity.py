@@ -472,3 +472,46 @@ def test_mid_sized_batch_17_to_64_rows_per_expert(family):
     ref = R.block_mixtral(x[None], gate, experts, top_k=k) if family == "mixtral" else R.block_nllb(x[None], gate, experts)
     assert_block_close(out, ref, torch.bfloat16, f"{family} 160-token block")
     eng.close()
+
+
+@pytest.mark.parametrize("t", [160, 600], ids=["hybrid_kernel", "lds_gemm_256_token_variant"])
+@pytest.mark.parametrize("family", ["mixtral", "switch", "nllb"])
+def test_fp32_many_tokens(family, t):
+    """The GEMM kernels in fp32 (16x16x4 MFMA, 16-element k-tiles, 4-element chunks in the full-line activation
+    staging): gated (Mixtral), plain (Switch) and plain + bias (NLLB) experts.  Two passes: decision path, then
+    the sync-free path (which picks the kernel from the expected rows per expert)."""
+    h, f, e = 256, 320, 8
+    k = 1 if family == "switch" else 2
+    kw = {"gate_std": 0.5} if family in ("switch", "nllb") else {}
+    gate, experts, _ = make_weights(family, h, f, e, 990, torch.float32, **kw)
+    ekw = {"expert_capacity": t} if family == "switch" else {}
+    eng = engine_for(family, h, f, e, k, torch.float32, max_tokens=t, **ekw)
+    register_all(eng, experts)
+    x = acts(t, h, torch.float32, 991)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    if family == "mixtral":
+        ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    elif family == "switch":
+        ref = R.block_switch(x[None], gate, experts, expert_capacity=t)
+    else:
+        ref = R.block_nllb(x[None], gate, experts)
+    assert_block_close(out, ref, torch.float32, f"fp32 {family} {t}-token block")
+    eng.close()
+
+
+@pytest.mark.parametrize("t", [160, 600])
+@pytest.mark.parametrize("f", [160, 176], ids=["odd_number_of_k_tiles", "k_not_a_multiple_of_the_k_tile"])
+def test_many_tokens_awkward_reduction_lengths(f, t):
+    """F = 160: 5 k-tiles (no full-line activation staging, which moves k-tiles in pairs); F = 176: not a multiple of
+    the 32-element k-tile (register-tiled GEMM with a zero-padded last tile)."""
+    h, e, k = 256, 8, 2
+    gate, experts, _ = make_weights("mixtral", h, f, e, 995, torch.bfloat16)
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 996)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    assert_block_close(out, ref, torch.bfloat16, f"F={f}, {t}-token block")
+    eng.close()
