@@ -515,3 +515,18 @@ def test_many_tokens_awkward_reduction_lengths(f, t):
     ref = R.block_mixtral(x[None], gate, experts, top_k=k)
     assert_block_close(out, ref, torch.bfloat16, f"F={f}, {t}-token block")
     eng.close()
+
+
+def test_deepseek_many_tokens_shared_expert_through_the_gemm_kernels():
+    """300 tokens: the shared expert (its own F and reduction length) has 300 rows -> 256-token LDS GEMM variant,
+    the routed experts ~28 rows each in the same launches."""
+    t, h, f, e, k, n_shared = 300, 256, 192, 64, 6, 2
+    gate, experts, shared = make_weights("deepseek", h, f, e, 997, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for("deepseek", h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=t)
+    register_all(eng, experts, shared)
+    x = acts(t, h, torch.bfloat16, 998)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+    assert_block_close(out, ref, torch.bfloat16, "deepseek 300-token block")
+    eng.close()
