@@ -200,3 +200,51 @@ def test_experts_loaded_from_a_reference_format_offload_directory(tmp_path):
         st.register_expert(eng, 0, 0, [ids[0][0], 9999, ids[0][2]])  # unknown tensor id
     eng.close()
     st.close()
+
+
+def test_expert_parallel_module_through_rccl_world_size_1():
+    """moe_infinity_amd.ep.ExpertParallelMoE with the HIP ops and the real collective (torch.distributed "nccl" =
+    RCCL) at world size 1: route -> pack -> all_to_all -> owner FFN -> all_to_all -> combine must equal the oracle
+    block, for a decode-sized and a 40-token batch, Mixtral and DeepSeek (shared expert on the home rank)."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd.ep import ExpertParallelMoE, HipEpOps
+
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        for family in ("mixtral", "deepseek"):
+            h, f, e, k, n_shared = 256, 192, 8, 2, 0
+            if family == "deepseek":
+                e, k, n_shared = 16, 4, 2
+            gate, experts, shared = make_weights(family, h, f, e, 540, torch.bfloat16, n_shared=n_shared)
+            tmax = 40
+            eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=tmax)
+            register_all(eng, experts, shared)
+            ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, DEV)
+            g = gate.to(DEV)
+            for t in (3, 40):
+                x = acts(t, h, torch.bfloat16, 541 + t)
+                for _ in range(2):
+                    out = ep.forward(0, x.to(DEV), g)
+                if family == "mixtral":
+                    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+                else:
+                    ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+                assert_block_close(out, ref, torch.bfloat16, f"EP module, {family}, {t} tokens")
+            eng.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
