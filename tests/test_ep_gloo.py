@@ -1,4 +1,4 @@
-"""World-size-2 test of the expert-parallel host path (moe-infinity_amd/ep.py) on CPU with gloo:
+"""World-size-2 and -4 tests of the expert-parallel host path (moe-infinity_amd/ep.py) on CPU with gloo:
 each rank routes its own tokens, rows cross ranks with all_to_all, the result must equal the
 single-process oracle block.  Compute steps are supplied by the oracle (tests/ep_cpu_ops.py)."""
 import os
@@ -48,8 +48,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_ep_world2_gloo_matches_single_process_oracle():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ep_gloo_matches_single_process_oracle(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
