@@ -245,13 +245,19 @@ def main():
     # Expert-parallel runs: every rank repeats the steps (the collectives need all of them); the events bracket the
     # owner-side FFN launches of THIS rank, and rank 0 reports its own kernels.
     roof, kernels = None, {}
-    if True:
+    p = None
+    try:
         eng.set_profiling(True)
         fence()
         run_steps(args.warmup, args.steps)
         fence()
         p = eng.profile()
         eng.set_profiling(False)
+    except Exception as ex:  # the measured line above must survive a failure of this extra leg in multi-rank runs
+        if world == 1:
+            raise
+        log(f"roofline leg failed on rank {rank}: {ex!r}")
+    if p is not None:
 
         def kstat(ms, launches, nbytes):
             if launches == 0 or ms <= 0:
