@@ -8,5 +8,6 @@ point raises if the HIP library is missing or no GPU is visible.
 from ._lib import MoeInfError, lib_path, load_library  # noqa: F401
 from .config import ArcherConfig, EngineConfig  # noqa: F401
 from .engine import CacheSim, ExpertTracerNative, MoEEngine  # noqa: F401
+from .prefetch_handle import PrefetchHandle  # noqa: F401
 
 __version__ = "0.1.0"

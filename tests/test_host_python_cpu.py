@@ -3,6 +3,8 @@ driving a recording stand-in for the engine."""
 import json
 
 import numpy as np
+import pytest
+import torch
 
 from moe_infinity_amd import config as Cf
 from moe_infinity_amd.memory import ExpertPredictor, ExpertPrefetcher, ExpertTracer
@@ -68,3 +70,119 @@ def test_prefetcher_issues_the_reference_order_and_filters():
     ls2, es2, _ = pf.prefetch_experts(1, m, max_experts=4, min_share=0.2, lookahead=2)
     assert len(ls2) == 4 and set(ls2.tolist()) <= {1, 2} and set(es2.tolist()) <= {0, 1}
     tr.finish_entry(seq)
+
+
+class _RecordingEngine:
+    """Stands in for MoEEngine on a GPU-less host: records what the adapter asks for."""
+
+    class cfg:
+        device_id = 0
+        num_layers = 3
+        num_experts = 4
+
+    def __init__(self):
+        self.calls = []
+        self.resident = set()
+
+    def protect(self, pairs):
+        self.calls.append(("protect", [tuple(p) for p in pairs]))
+
+    def prefetch(self, layer, experts, scores=None):
+        self.calls.append(("prefetch", layer, list(experts)))
+        self.resident.update((layer, e) for e in experts)
+
+    def is_resident(self, layer, expert):
+        return (layer, expert) in self.resident
+
+    def expert_counters(self):
+        c = np.zeros((3, 4, 6), np.int64)
+        c[1, 2] = [5, 3, 2, 1, 3, 1]
+        return c
+
+    def clear_expert_cache_counts(self):
+        self.calls.append(("clear",))
+
+    def close(self):
+        self.calls.append(("close",))
+
+
+def test_prefetch_handle_adapter_keeps_the_reference_method_names_and_order():
+    from moe_infinity_amd.prefetch_handle import PrefetchHandle
+
+    eng = _RecordingEngine()
+    tmap = {(l, e): 100 + 10 * l + e for l in range(3) for e in range(4)}  # expert_tensor_map of the reference
+    h = PrefetchHandle(eng, tmap)
+    h.register_expert_tensors(1, 2, [912, 913])  # the expert's other parameter ids
+    h.replace_cache_candidates([tmap[(2, 1)], tmap[(1, 2)], 913])
+    assert eng.calls[-1] == ("protect", [(2, 1), (1, 2)]), "ids of one expert collapse, order kept"
+    assert h.get_node_default_device([tmap[(2, 1)]]) == 0
+    assert h.get_node_device([tmap[(2, 1)]]) == -1 and not h.is_tensor_on_device(tmap[(2, 1)])
+    h.enqueue_prefetch(tmap[(2, 1)], 0)
+    assert eng.calls[-1] == ("prefetch", 2, [1]) and h.is_tensor_on_device(tmap[(2, 1)]) and h.get_node_device([tmap[(2, 1)]]) == 0
+    hr = h.get_hit_rate()
+    assert hr.shape == (12, 11) and hr.dtype == torch.int64
+    row = hr[1 * 4 + 2]  # columns of model_topology.cpp:253-263
+    assert [int(v) for v in row] == [5, 5, 0, 3, 3, 0, 3, 1, 0, 0, 1]
+    with pytest.raises(KeyError):
+        h.enqueue_prefetch(7, 0)
+    with pytest.raises(ValueError):
+        h.enqueue_prefetch(tmap[(0, 0)], 3)
+    with pytest.raises(NotImplementedError, match="8f-2"):
+        h.begin(0, None)
+    assert h.prefetch_tensors(0, [1]) is None
+    h.clean_up_resources()
+    assert eng.calls[-1] == ("close",)
+
+
+def test_reference_expert_prefetcher_drives_the_adapter_unmodified():
+    """The reference's own memory/expert_prefetcher.py (imported from /root/reference when it is there; CPU-only
+    build container) against the adapter: same protected set and the same prefetch order as our mirror class."""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    src = "/root/reference/moe_infinity/memory/expert_prefetcher.py"
+    if not os.path.exists(src):
+        pytest.skip("reference checkout not present")
+    from moe_infinity_amd.memory import ExpertPrefetcher, ExpertTracer
+    from moe_infinity_amd.prefetch_handle import PrefetchHandle
+
+    # the module imports moe_infinity.utils.parse_moe_param; stub the package around the one file we want
+    L, E = 3, 4
+    stub = types.ModuleType("moe_infinity")
+    utils = types.ModuleType("moe_infinity.utils")
+    utils.parse_moe_param = lambda config: (L, E, 0)
+    stub.utils = utils
+    saved = {k: sys.modules.get(k) for k in ("moe_infinity", "moe_infinity.utils")}
+    sys.modules["moe_infinity"], sys.modules["moe_infinity.utils"] = stub, utils
+    sys.dont_write_bytecode = True
+    try:
+        spec = importlib.util.spec_from_file_location("ref_expert_prefetcher", src)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    tmap = {(l, e): 100 + 10 * l + e for l in range(L) for e in range(E)}
+    m = np.array([[0, 0, 0, 0], [0.5, 0, 0.25, 0], [0, 0.125, 0, 0.75]])
+    ref_eng = _RecordingEngine()
+    ref = mod.ExpertPrefetcher(config=None)
+    ref.set_archer_engine(PrefetchHandle(ref_eng, tmap))
+    ref.expert_tensor_map = tmap
+    ref.prefetch_experts(1, m)
+    ours_eng = _RecordingEngine()
+    ours = ExpertPrefetcher(L, E, ExpertTracer(4, L, E))
+    ours.set_archer_engine(ours_eng)
+    ours.prefetch_experts(1, m)
+
+    def flat(calls):
+        prot = [c[1] for c in calls if c[0] == "protect"]
+        pre = [(c[1], e) for c in calls if c[0] == "prefetch" for e in c[2]]
+        return prot, pre
+
+    assert flat(ref_eng.calls) == flat(ours_eng.calls)
+    assert flat(ref_eng.calls)[1] == [(2, 3), (1, 0), (1, 2), (2, 1)], "descending predicted share"
