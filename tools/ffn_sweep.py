@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Sweep ffn_rows_kernel tuning knobs (env MOEINF_FFN_{NW,U,OCC}) on real model shapes; one
-subprocess per setting so the static env lookups are fresh.  Prints per-stage us and GB/s."""
+"""Sweep the FFN kernels' tuning knobs (env MOEINF_FFN_* / MOEINF_GEMM_*) on real model
+shapes; one subprocess per setting so the static env lookups are fresh.  Prints per-stage us and GB/s.
+usage: ffn_sweep.py <preset>:<tokens>:<layers> ...   e.g.  mixtral_8x7b:512:2 nllb_moe_54b:2048:1"""
 import json
 import os
 import subprocess
@@ -66,7 +67,9 @@ if __name__ == "__main__":
     wls = sys.argv[1:] or ["mixtral_8x7b:1:4", "deepseek_v2_lite:1:4"]
     for spec in wls:
         wl, B, L = spec.split(":")
-        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_XL": 0}, {"MOEINF_FFN_MANY_ROWS": 16}]
+        # default sweep: the shipped choice vs the main alternatives (see DESIGN.md section 4.3 for every knob)
+        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_XL": 0}, {"MOEINF_GEMM_WIDE": 0}, {"MOEINF_FFN_GEMM": 3},
+                                          {"MOEINF_FFN_MANY_ROWS": 32}]
         for env in envs:
             r = run(wl, int(B), int(L), 200 if int(B) <= 16 else 20, env)
             if "error" in r:
