@@ -15,11 +15,24 @@ in HBM under device_memory_ratio exactly as the reference does.
 Default workload (N=1): the configuration BASELINE.json's metric is quoted on — Mixtral-8x7B shapes
 (32 MoE layers x 8 experts, H=4096 F=14336, top-2, bf16; 84 GiB of experts), device_memory_ratio
 0.75, batch 1, synthetic weights N(0, 0.02^2) and RMS-normalised activations.
+
+The timed region is W warm-up steps, then EXACTLY K steps between barrier + synchronize; that K-step window
+is repeated (default 5 windows in total) and `value` is the MEDIAN window (`windows_ms` lists all of them, the
+first one is the contract's window).
+
+Further legs of the same line (N=1 only; none of them touches `value`):
+  roofline       the K steps again with HIP events around every kernel of the path, on the launch stream
+  parity         sampled (step, layer) pairs at FULL size against the oracle with the tests' own bars
+                 (oracle/parity.py), ASSERTED: a parity miss makes the process exit non-zero after the line
+  cpu_baseline   the oracle timed on the host cores (best of a thread sweep), bounded sample
+  miss_heavy     BASELINE config 3: the same engine with the expert cache cut to 50 % of the expert bytes
+                 (moeinf_set_cache_budget): hit rate, H2D GB/s, exposed wait, overlap, PCIe-bound estimate
+  other_configs  BASELINE configs 2 and 5 in short form: DeepSeek-V2-Lite batch 1, NLLB-MoE-54B batch 32
 """
 import argparse
 import json
-import math
 import os
+import statistics
 import sys
 import time
 
@@ -29,6 +42,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (achievable ~6.3 TB/s)
+PCIE_GBS = 63.0        # PCIe Gen5 x16 per direction; measured pinned hipMemcpyAsync peak on this box: 56 GB/s
 
 WORKLOADS = {
     # name: (config factory name, family, human label)
@@ -42,6 +56,15 @@ WORKLOADS = {
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def acts(t, h, dtype, seed):
+    """Synthetic activations: N(0,1) rows, RMS-normalised, seeded — the product's INPUT
+    generator (the parity tests use the same protocol from their own copy)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(t, h, generator=g)
+    x = x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    return x.to(dtype)
 
 
 def fill_experts(eng, cfg, rank, world, dev, seed=1234):
@@ -99,62 +122,41 @@ def host_expert_tensors(eng, cfg, layer, expert):
     return [raw[o:o + s].view(eng.dtype).reshape(sh) for o, s, sh in zip(off, siz, shapes)]
 
 
-def main():
-    # Native libraries (RCCL prints a version banner, HIP/driver warnings) write to the C stdout; keep the
-    # process's real stdout for the ONE JSON line only.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mixtral-8x7b", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=1, help="decode batch (new tokens per step) per rank")
-    ap.add_argument("--ratio", type=float, default=0.75, help="device_memory_ratio")
-    ap.add_argument("--budget-gib", type=float, default=0.0, help="explicit expert-cache budget (miss-heavy runs)")
-    ap.add_argument("--layers", type=int, default=0, help="override the number of MoE layers (0 = the model's)")
-    ap.add_argument("--policy", default="lfu_incache", choices=["lfu_incache", "lru"])
-    ap.add_argument("--prompt", type=int, default=512, help="prefill length run once before decoding (examples/interface_example.py protocol); 0 = skip")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
-    ap.add_argument("--cpu-sample-layers", type=int, default=4)
-    ap.add_argument("--cpu-sample-steps", type=int, default=3)
-    args = ap.parse_args()
+def latest_pmc_traffic(workload_key, kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass of this workload
+    (profiles/r*_pmc_traffic_<workload>.json, produced by tools/run_profiles.sh + tools/pmc_summary.py from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  Returns (bytes, source file) or (None, None):
+    the number is STATIC, taken in an earlier run — the line labels it as such."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.endswith(f"_pmc_traffic_{workload_key}.json"):
+            best = fn
+    if not best:
+        return None, None
+    try:
+        for name, v in json.load(open(os.path.join(pdir, best)))["kernels"].items():
+            if kernel_substr in name:
+                return v["hbm_bytes"], f"profiles/{best}"
+    except Exception:
+        pass
+    return None, None
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_ep = world > 1 or args.force_ep
-    if use_ep:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-
-    import __graft_entry__ as entry
-
-    if rank == 0:
-        entry.build()
-    if world > 1:
-        dist.barrier()
+def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, dist):
+    """One workload end to end.  main=True: every leg; main=False (other_configs): timing + roofline + parity."""
     from moe_infinity_amd import MoEEngine
     from moe_infinity_amd import config as Cf
     from moe_infinity_amd.ep import ExpertParallelMoE, HipEpOps
 
-    factory, family, label = WORKLOADS[args.workload]
-    B = args.batch
+    factory, family, label = WORKLOADS[workload]
+    steps, warmup = args.steps, args.warmup
+    prompt = args.prompt if main else 0
     cfg = getattr(Cf, factory)(device_id=local_rank, device_memory_ratio=args.ratio,
-                               device_memory_bytes=int(args.budget_gib * 2**30),
+                               device_memory_bytes=int(args.budget_gib * 2**30) if main else 0,
                                policy=Cf.POLICY_LRU if args.policy == "lru" else Cf.POLICY_LFU_INCACHE,
-                               ep_rank=rank, ep_size=world, max_tokens=max(B * world, B * args.prompt if world == 1 else 0))
-    if args.layers:
+                               ep_rank=rank, ep_size=world, max_tokens=max(B * world, B * prompt if world == 1 else 0))
+    if args.layers and main:
         cfg.num_layers = args.layers
     L, E, K, H = cfg.num_layers, cfg.num_experts, cfg.top_k, cfg.hidden
     eng = MoEEngine(cfg)
@@ -168,13 +170,12 @@ def main():
         gstd = 0.02 if family in ("mixtral", "deepseek") else 0.5
         gates.append((torch.randn(E, H, generator=gg, device=dev) * gstd).to(gdt))
 
-    from oracle.synth import acts  # synthetic activation protocol (seed 2024+layer, RMS-normalised rows)
-
-    nsteps = args.warmup + args.steps
+    nsteps = warmup + steps
     xs = [[acts(B, H, dt, 2024 + l + 1000 * s + 100000 * rank).to(dev) for l in range(L)] for s in range(nsteps)]
     out = torch.empty(B, H, dtype=dt, device=dev)
     batch_rows = B if family == "switch" else 1
 
+    ep = None
     if use_ep:
         ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev)
 
@@ -203,13 +204,13 @@ def main():
     for l in range(L):
         eng.prefetch(l, [e for e in range(E) if e % world == rank])
     eng.sync_copies()
-    log(f"cache warm ({eng.stats()['slots_used']} experts resident) in {time.time() - t0:.1f}s, h2d {eng.stats()['h2d_bytes'] / 2**30:.1f} GiB, copy-busy {eng.stats()['h2d_busy_ms']:.0f} ms")
     warm = eng.stats()
+    log(f"{label}: cache warm ({warm['slots_used']} experts resident) in {time.time() - t0:.1f}s, h2d {warm['h2d_bytes'] / 2**30:.1f} GiB, link-busy {warm['h2d_busy_ms']:.0f} ms")
     # prefill of the prompt (B sequences x --prompt tokens) through every layer: exercises the large-T
     # path; timed separately, NOT part of `value`
     prefill_ms = None
-    if args.prompt > 0 and not use_ep:
-        xp = acts(B * args.prompt, H, dt, 777).to(dev)
+    if prompt > 0 and not use_ep:
+        xp = acts(B * prompt, H, dt, 777).to(dev)
         outp = torch.empty_like(xp)
         for l in range(L):  # untimed pass: makes every expert the prompt touches resident
             eng.forward(l, xp, gates[l], batch_rows=batch_rows, out=outp)
@@ -220,26 +221,43 @@ def main():
         torch.cuda.synchronize(dev)
         prefill_ms = (time.perf_counter() - tp) * 1e3
         del xp, outp
-    run_steps(0, args.warmup)
+    run_steps(0, warmup)
     eng.sync_copies()
     fence()
-    log(f"warm-up {args.warmup} steps in {time.time() - t0:.1f}s; stats {eng.stats()}")
     eng.clear_expert_cache_counts()
     eng.reset_stats()
 
-    # ---- timed region: exactly K steps
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-    tokens_per_s = world * B * args.steps / elapsed
+    # ---- timed region: exactly K steps per window; the first window is the contract's, the median is reported
+    windows = []
+    for w in range(max(1, args.windows)):
+        fence()
+        t0 = time.perf_counter()
+        run_steps(warmup, steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        windows.append(elapsed)
+    elapsed = statistics.median(windows)
+    ms_per_step = elapsed * 1e3 / steps
+    tokens_per_s = world * B * steps / elapsed
     st = eng.stats()
+
+    # ---- expert-parallel runs: the same K steps once more with per-phase timers (pack / all-to-all / owner FFN /
+    # all-to-all / combine), so a scaling run is diagnosable from its one line
+    ep_phases = None
+    if ep is not None:
+        try:
+            ep.profile = True
+            fence()
+            run_steps(warmup, steps)
+            fence()
+            ep_phases = ep.phase_times_us()
+            ep.profile = False
+        except Exception as ex:
+            log(f"EP phase-timer leg failed on rank {rank}: {ex!r}")
 
     # ---- same K steps again with per-kernel HIP events on the launch stream (roofline leg)
     # Expert-parallel runs: every rank repeats the steps (the collectives need all of them); the events bracket the
@@ -249,7 +267,7 @@ def main():
     try:
         eng.set_profiling(True)
         fence()
-        run_steps(args.warmup, args.steps)
+        run_steps(warmup, steps)
         fence()
         p = eng.profile()
         eng.set_profiling(False)
@@ -281,30 +299,30 @@ def main():
                                                          and os.environ.get("MOEINF_FUSE_COMBINE", "1") != "0"),
                    "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)})
         k1 = kernels["ffn_stage1"]
-        # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; tools/pmc_summary.py)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_mixtral8x7b.json")
-        if args.workload == "mixtral-8x7b" and B == 1 and not use_ep and os.path.exists(pmc):
-            for name, v in json.load(open(pmc))["kernels"].items():
-                if "ffn_rows_kernel<unsigned short, 2" in name:
-                    traffic = v["hbm_bytes"]
+        traffic, traffic_src = (None, None)
+        if B == 1 and not use_ep:
+            traffic, traffic_src = latest_pmc_traffic(workload.replace("-", "").replace(".", ""), "ffn_rows_kernel<unsigned short, 2"
+                                                      if family in ("mixtral", "deepseek") else "ffn_rows_kernel<")
         if k1:
             roof = {"bound": "hbm", "kernel": "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)"
                                               + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
-                    "traffic": traffic, "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"]}
+                    "traffic": traffic,
+                    "traffic_source": (f"static: {traffic_src} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, NOT measured in this run)"
+                                       if traffic_src else None),
+                    "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"],
+                    "note": "HIP-event interval per launch (carries ~3 us of event cost; the rocprofv3 kernel-trace average in profiles/ is the kernel alone)"}
 
     # ---- CPU baseline + full-size parity: the oracle on a bounded sample of the same workload
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not use_ep and not args.no_cpu_baseline:
         from oracle import moe_ref as R
+        from oracle import parity as P
 
         ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         ls = list(range(min(args.cpu_sample_layers, L)))
-        ss = list(range(args.warmup, args.warmup + min(args.cpu_sample_steps, args.steps)))
+        ss = list(range(warmup, warmup + min(args.cpu_sample_steps, steps)))
 
         def oracle_layer(l, x_cpu):
             gate = gates[l].cpu()
@@ -321,57 +339,198 @@ def main():
                 return R.block_switch(x_cpu[None], gate, experts, expert_capacity=cfg.expert_capacity)
             return R.block_nllb(x_cpu[None], gate, experts)
 
-        if True:
-            oracle_layer(ls[0], xs[ss[0]][ls[0]].cpu())  # warm the CPU path
+        # the best CPU number, not a convenient one: sweep the thread count on one (step, layer) pair first
+        sweep = {}
+        cands = sorted({1, 8, 16, 32, 64, ncores} & set(range(1, ncores + 1))) if main else [min(16, ncores)]
+        x0 = xs[ss[0]][ls[0]].cpu()
+        for nt in cands:
+            torch.set_num_threads(nt)
+            oracle_layer(ls[0], x0)
             t0 = time.perf_counter()
-            refs = {}
-            for s in ss:
-                for l in ls:
-                    refs[(s, l)] = oracle_layer(l, xs[s][l].cpu())
-            cpu_s = time.perf_counter() - t0
-            layer_steps = len(ss) * len(ls)
-            cpu_ms_per_token = cpu_s * 1e3 / layer_steps * L / B  # extrapolated to all L layers
-            cpu = {"value": round(1e3 / cpu_ms_per_token, 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
-                   "ms_per_token": round(cpu_ms_per_token, 2),
-                   "sample": f"{len(ss)} decode steps x layers {ls[0]}..{ls[-1]} of the same workload "
-                             f"({layer_steps} MoE-layer passes, {cpu_s:.1f}s), extrapolated x{L}/{len(ls)} layers; "
-                             f"torch CPU ops, {ncores} threads"}
-            # parity of the full-size GPU path on the sampled (step, layer) pairs
-            worst, exact = 0.0, True
-            for (s, l), ref in refs.items():
-                o = eng.forward(l, xs[s][l], gates[l], batch_rows=batch_rows).float().cpu()
-                r = eng.routing()
-                if family == "mixtral":
-                    exact &= bool((torch.from_numpy(r["topk_idx"]).long() == ref.topk_idx).all())
-                elif family == "deepseek":
-                    exact &= all(sorted(a.tolist()) == sorted(b.tolist()) for a, b in zip(r["topk_idx"], ref.topk_idx.numpy()))
-                want = ref.out[0].float()
-                tol = torch.maximum(torch.maximum(want.abs(), o.abs()), want.abs().mean()) * (2.0 ** -7 if dt == torch.bfloat16 else 2e-5)
-                worst = max(worst, float(((o - want).abs() / tol).max()))
-            parity = {"routing_bit_exact": exact, "max_err_ulps_of_dtype": round(worst, 3), "pairs_checked": len(refs)}
+            oracle_layer(ls[0], x0)
+            sweep[nt] = time.perf_counter() - t0
+        best_nt = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_nt)
+        t0 = time.perf_counter()
+        refs = {}
+        for s in ss:
+            for l in ls:
+                refs[(s, l)] = oracle_layer(l, xs[s][l].cpu())
+        cpu_s = time.perf_counter() - t0
+        layer_steps = len(ss) * len(ls)
+        cpu_ms_per_token = cpu_s * 1e3 / layer_steps * L / B  # extrapolated to all L layers
+        cpu = {"value": round(1e3 / cpu_ms_per_token, 4), "unit": "tokens/s", "cores": best_nt, "kind": "port",
+               "ms_per_token": round(cpu_ms_per_token, 2), "host_cores": ncores,
+               "thread_sweep_ms_per_layer": {str(k): round(v * 1e3, 2) for k, v in sweep.items()},
+               "sample": f"{len(ss)} decode steps x layers {ls[0]}..{ls[-1]} of the same workload "
+                         f"({layer_steps} MoE-layer passes, {cpu_s:.1f}s), extrapolated x{L}/{len(ls)} layers; "
+                         f"torch CPU ops, {best_nt} threads (best of the sweep)"}
+        # parity of the full-size GPU path on the sampled (step, layer) pairs: the tests' own bars, asserted
+        worst, exact, amb, ok = 0.0, True, 0, True
+        for (s, l), ref in refs.items():
+            o = eng.forward(l, xs[s][l], gates[l], batch_rows=batch_rows).float().cpu()
+            r = eng.routing()
+            if family == "mixtral":
+                exact &= bool((torch.from_numpy(r["topk_idx"]).long() == ref.topk_idx).all())
+            else:  # routing sets, incl. Switch capacity drops and NLLB zero-weight drops
+                got = torch.zeros(B, E, dtype=torch.bool)
+                for t_ in range(B):
+                    for i in r["topk_idx"][t_]:
+                        if i >= 0:
+                            got[t_, int(i)] = True
+                exact &= bool(torch.equal(got, ref.router_mask.reshape(B, E).bool()))
+            rep = P.block_report(o, ref, dt, x=xs[s][l].cpu())
+            worst = max(worst, rep["worst"])
+            amb += rep["passthrough_ambiguous"]
+            ok &= rep["ok"]
+        parity = {"ok": bool(ok and exact), "routing_bit_exact": bool(exact), "worst_err_over_bar": round(worst, 3),
+                  "bar": "oracle/parity.py block_report (= tests/helpers.py assert_block_close)", "pairs_checked": len(refs)}
+        if family == "nllb":
+            parity["elements_on_the_eq0_passthrough_discontinuity"] = amb
+
+    # ---- miss-heavy leg (BASELINE config 3): same engine, expert cache cut to a byte budget
+    miss = None
+    if main and rank == 0 and world == 1 and not use_ep and args.miss_heavy_frac > 0 and not args.budget_gib:
+        slot = st["slot_bytes"]
+        budget = int(args.miss_heavy_frac * L * E * slot)
+        eng.set_cache_budget(budget)
+        msteps = max(5, min(steps, args.miss_heavy_steps))
+        run_steps(0, min(3, nsteps))  # settle the smaller cache
+        eng.sync_copies()
+        torch.cuda.synchronize(dev)
+        eng.clear_expert_cache_counts()
+        eng.reset_stats()
+        t0 = time.perf_counter()
+        for s in range(msteps):
+            for l in range(L):
+                layer_fwd(l, xs[warmup + (s % steps)][l])
+        torch.cuda.synchronize(dev)
+        mel = time.perf_counter() - t0
+        eng.sync_copies()
+        ms_ = eng.stats()
+        misses = ms_["expert_misses"]
+        link = ms_["h2d_bytes"] / ms_["h2d_busy_ms"] / 1e6 if ms_["h2d_busy_ms"] > 0 else None
+        bound_ms = misses * slot / (56.0e9) * 1e3 / msteps  # every miss crosses the link once at the measured 56 GB/s
+        miss = {"what": f"{label}, expert cache = {args.miss_heavy_frac:.0%} of the expert bytes ({budget / 2**30:.1f} GiB, "
+                        f"{ms_['slots_total']} of {L * E} experts), on-demand fetches only",
+                "steps": msteps, "ms_per_token": round(mel * 1e3 / msteps / B, 3), "tokens_per_s": round(B * msteps / mel, 3),
+                "hit_rate": round(ms_["expert_hits"] / max(1, ms_["expert_hits"] + misses), 4),
+                "misses_per_token": round(misses / msteps / B, 2),
+                "h2d_GiB": round(ms_["h2d_bytes"] / 2**30, 2), "h2d_link_busy_ms": round(ms_["h2d_busy_ms"], 1),
+                "h2d_GBps": None if link is None else round(link, 2),
+                "h2d_frac_of_pcie5_x16": None if link is None else round(link / PCIE_GBS, 3),
+                "h2d_frac_of_hbm_peak": None if link is None else round(link / HBM_PEAK_GBS, 4),
+                "exposed_wait_ms": round(ms_["exposed_wait_ms"], 1),
+                "overlap": None if ms_["h2d_busy_ms"] <= 0 else round(max(0.0, 1.0 - ms_["exposed_wait_ms"] / ms_["h2d_busy_ms"]), 4),
+                "pcie_bound_ms_per_token": round(bound_ms / B, 3),
+                "ms_per_token_over_pcie_bound": round(mel * 1e3 / msteps / max(bound_ms, 1e-9), 3)}
+
+    res = {"label": label, "family": family, "cfg": cfg, "L": L, "E": E, "K": K, "H": H, "B": B, "dt": dt,
+           "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
+           "prefill_ms": prefill_ms, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
+           "warm": warm, "st": st, "ep_phases": ep_phases}
+    eng.close()
+    return res
+
+
+def main():
+    # Native libraries (RCCL prints a version banner, HIP/driver warnings) write to the C stdout; keep the
+    # process's real stdout for the ONE JSON line only.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5, help="how many times the K-step window is timed (median reported)")
+    ap.add_argument("--workload", default="mixtral-8x7b", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=1, help="decode batch (new tokens per step) per rank")
+    ap.add_argument("--ratio", type=float, default=0.75, help="device_memory_ratio")
+    ap.add_argument("--budget-gib", type=float, default=0.0, help="explicit expert-cache budget for the MAIN leg (miss-heavy runs)")
+    ap.add_argument("--layers", type=int, default=0, help="override the number of MoE layers (0 = the model's)")
+    ap.add_argument("--policy", default="lfu_incache", choices=["lfu_incache", "lru"])
+    ap.add_argument("--prompt", type=int, default=512, help="prefill length run once before decoding (examples/interface_example.py protocol); 0 = skip")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the cpu_baseline AND parity legs")
+    ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
+    ap.add_argument("--cpu-sample-layers", type=int, default=4)
+    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    ap.add_argument("--miss-heavy-frac", type=float, default=0.5, help="miss_heavy leg: cache budget as a fraction of the expert bytes (0 = skip)")
+    ap.add_argument("--miss-heavy-steps", type=int, default=6)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_ep = world > 1 or args.force_ep
+    if use_ep:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+
+    import __graft_entry__ as entry
 
     if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+
+    r = run_workload(args, args.workload, args.batch, world, rank, local_rank, dev, use_ep, True, dist)
+    others = []
+    default_main = (args.workload == "mixtral-8x7b" and args.batch == 1 and not args.layers and not args.budget_gib)
+    if world == 1 and not use_ep and default_main and not args.no_other_configs:
+        for wl, b in (("deepseek-v2-lite", 1), ("nllb-moe-54b", 32)):
+            try:
+                o = run_workload(args, wl, b, world, rank, local_rank, dev, False, False, dist)
+                k1, k2 = o["kernels"].get("ffn_stage1"), o["kernels"].get("ffn_stage2")
+                others.append({"workload": f"{o['label']} MoE layers: L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}"
+                                           + (f" +shared F={o['cfg'].shared_inter}" if o["cfg"].shared_inter else "")
+                                           + f", decode batch {b}, device_memory_ratio={args.ratio}",
+                               "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2),
+                               "windows_ms": o["windows_ms"],
+                               "algorithmic_GB_per_step": None if not (k1 and k2) else round((k1["bytes_per_launch"] + k2["bytes_per_launch"]) * o["L"] / 1e9, 3),
+                               "frac_of_hbm_peak_whole_step": None if not (k1 and k2) else round((k1["bytes_per_launch"] + k2["bytes_per_launch"]) * o["L"] / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "ffn_stage1": k1, "ffn_stage2": k2, "route": o["kernels"].get("route(gate+topk+index)"),
+                               "parity": o["parity"], "cpu_baseline": o["cpu"]})
+            except Exception as ex:  # an extra leg must not take the measured line down
+                log(f"other_configs leg {wl} failed: {ex!r}")
+                others.append({"workload": wl, "error": repr(ex)})
+
+    parity_ok = True
+    if rank == 0:
+        cfg, st, warm = r["cfg"], r["st"], r["warm"]
+        L, E, K, H, B = r["L"], r["E"], r["K"], r["H"], r["B"]
+        label = r["label"]
         line = {
             "metric": f"decode tokens/s through all MoE layers (expert-offload hot path), {label}, device_memory_ratio={args.ratio}",
-            "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dt == torch.bfloat16 else "f32", "data": "synthetic",
+            "value": round(r["tokens_per_s"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if r["dt"] == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": f"{label} MoE layers: L={L} E={E} K={K} H={H} F={cfg.inter}"
                                    + (f" +shared F={cfg.shared_inter}" if cfg.shared_inter else "")
                                    + f", decode batch {B}/rank, device_memory_ratio={args.ratio}"
                                    + (f", expert-cache budget {args.budget_gib} GiB" if args.budget_gib else ""),
-                       "parallelism": f"ep{world}" if use_ep else "single", "per_token_decode_latency_ms": round(ms_per_step, 4),
+                       "parallelism": f"ep{world}" if use_ep else "single", "per_token_decode_latency_ms": round(r["ms_per_step"], 4),
                        "cache_policy": args.policy},
-            "prefill": None if prefill_ms is None else {"tokens": B * args.prompt, "ms_all_layers": round(prefill_ms, 2),
-                                                        "tokens_per_s": round(B * args.prompt / prefill_ms * 1e3, 1)},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "kernels": kernels,
+            "windows_ms": r["windows_ms"], "value_is": f"median of {len(r['windows_ms'])} windows of {args.steps} steps (first = the contract's window)",
+            "prefill": None if r["prefill_ms"] is None else {"tokens": B * r["prompt"], "ms_all_layers": round(r["prefill_ms"], 2),
+                                                             "tokens_per_s": round(B * r["prompt"] / r["prefill_ms"] * 1e3, 1)},
+            "roofline": r["roof"],
+            "cpu_baseline": r["cpu"],
+            "kernels": r["kernels"],
             "prefetch_stream": None if warm["h2d_busy_ms"] <= 0 else {
-                "what": "cache warm-up: every owned expert streamed host(pinned)->HBM on the prefetch stream (hipMemcpyAsync + device re-tile)",
-                "GiB": round(warm["h2d_bytes"] / 2**30, 2), "busy_ms": round(warm["h2d_busy_ms"], 1),
+                "what": "cache warm-up: every owned expert streamed host(pinned)->HBM through the speculative lane (hipMemcpyAsync tensor by tensor, double-buffered staging + device re-tile)",
+                "GiB": round(warm["h2d_bytes"] / 2**30, 2), "link_busy_ms": round(warm["h2d_busy_ms"], 1),
                 "GBps": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6, 2),
-                "frac_of_pcie5_x16_63GBps": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6 / 63.0, 3),
+                "frac_of_pcie5_x16_63GBps": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6 / PCIE_GBS, 3),
                 "frac_of_hbm_peak": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6 / HBM_PEAK_GBS, 4)},
             "timed_region_h2d": {"bytes": st["h2d_bytes"], "busy_ms": round(st["h2d_busy_ms"], 2),
                                  "GBps": round(st["h2d_bytes"] / st["h2d_busy_ms"] / 1e6, 2) if st["h2d_busy_ms"] > 0 else None,
@@ -379,13 +538,21 @@ def main():
                                  "overlap": None if st["h2d_busy_ms"] <= 0 else round(max(0.0, 1.0 - st["exposed_wait_ms"] / st["h2d_busy_ms"]), 4),
                                  "hit_rate": round(st["expert_hits"] / max(1, st["expert_hits"] + st["expert_misses"]), 4)},
             "cache": {k: st[k] for k in ("expert_hits", "expert_misses", "evictions", "h2d_bytes", "slots_total", "slots_used", "slot_bytes", "host_arena_bytes")},
-            "parity": parity,
+            "parity": r["parity"],
+            "miss_heavy": r["miss"],
+            "ep_phases_us_per_layer": r["ep_phases"],
+            "other_configs": others or None,
         }
+        for pr in [r["parity"]] + [o.get("parity") for o in others]:
+            if pr is not None and not pr.get("ok", True):
+                parity_ok = False
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    eng.close()
     if use_ep:
         dist.destroy_process_group()
+    if not parity_ok:
+        print("[bench] PARITY FAILED: the full-size GPU path is outside the tests' bars (see \"parity\" in the line)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

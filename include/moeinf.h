@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MOEINF_ABI_VERSION 1
+#define MOEINF_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -110,8 +110,18 @@ typedef struct moeinf_stats {
   int64_t slots_used;
   int64_t slot_bytes;      /* bytes per slot (= expert blob size rounded to 4 KiB) */
   int64_t host_arena_bytes;
-  double h2d_busy_ms;      /* copy-stream busy time measured with HIP events (demand + prefetch) */
+  double h2d_busy_ms;      /* link-busy time: first to last hipMemcpyAsync of every transfer, HIP events on the copy streams */
   double exposed_wait_ms;  /* time the compute stream spent waiting on copies (event-timed) */
+  /* pending-transfer queue (reference: ArcherTaskPool, core/prefetch/task_scheduler.cpp) */
+  int64_t prefetch_queued;    /* speculative transfers waiting in the queue right now */
+  int64_t prefetch_cancelled; /* queued transfers dropped: stale layer, displaced by a more urgent request, overtaken by a demand fetch, queue cleared */
+  int64_t prefetch_dropped;   /* popped but not started: no evictable slot ("evict failed", task_scheduler.cpp:505-510) */
+  int64_t prefetch_wasted;    /* prefetched experts evicted before any dispatch used them */
+  int64_t inflight_hits;      /* dispatches that found the expert's transfer still in flight (counted in expert_hits) */
+  /* host tier as a cache over the disk tier */
+  int64_t host_evictions;     /* host blobs dropped from the pinned arena (re-readable from the offload directory) */
+  int64_t disk_reads;         /* experts read disk -> pinned host */
+  int64_t disk_bytes;
 } moeinf_stats;
 
 /* ---- errors ------------------------------------------------------------------------------ */
@@ -210,8 +220,11 @@ int moeinf_protect(moeinf_engine* eng, const int32_t* layers, const int32_t* exp
 int moeinf_clear_cache_counts(moeinf_engine* eng);
 /* 1 if resident on device, 0 otherwise: prefetch_handle.is_tensor_on_device (py_archer_prefetch.cpp:64-69) */
 int moeinf_is_resident(moeinf_engine* eng, int layer, int expert, int32_t* resident);
-/* blocks until every issued H2D copy has landed (tests/bench warm-up) */
+/* serves the whole pending queue and blocks until every H2D copy has landed (tests/bench warm-up) */
 int moeinf_sync_copies(moeinf_engine* eng);
+/* DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink (evicting by
+ * the replacement policy, freeing the slots' memory) or grow the expert cache.  Synchronises the device. */
+int moeinf_set_cache_budget(moeinf_engine* eng, int64_t device_memory_bytes);
 
 /* prefetch_handle.get_hit_rate() (archer_prefetch_handle.cpp:281-297): per-expert counters,
  * out[L*E][6] = {visit_cnt, hit_cnt, miss_cnt, prefetch_cnt, incache_visit_count, resident} */
@@ -286,6 +299,10 @@ int moeinf_store_get(const moeinf_store* st, uint32_t tensor_id, void* dst, uint
  * receives them) from the store straight into the expert's pinned arena blob. */
 int moeinf_register_expert_from_store(moeinf_engine* eng, int layer, int expert, const moeinf_store* st,
                                       const uint32_t* tensor_ids, int n);
+/* With cfg.host_memory_bytes > 0 the pinned arena is an LRU cache over the offload directory: experts registered
+ * after the cap is reached stay on disk and are read on their first miss, and a full arena drops the least recently
+ * needed re-readable blob (Node::SetDevice(DISK), model_topology.cpp:76-88).  `st` must stay open for the
+ * engine's lifetime. */
 
 /* ---- cache-policy simulator (host only, no GPU) --------------------------------------------
  * The engine's replacement policy as a standalone object, so the policy can be checked against
@@ -297,6 +314,27 @@ int moeinf_cache_sim_destroy(moeinf_cache_sim* sim);
 int moeinf_cache_sim_access(moeinf_cache_sim* sim, int64_t id, int32_t* hit, int64_t* evicted);
 int moeinf_cache_sim_protect(moeinf_cache_sim* sim, const int64_t* ids, int n);
 int moeinf_cache_sim_clear_counts(moeinf_cache_sim* sim);
+
+/* ---- pending-transfer queue, standalone (host only, no GPU) ------------------------------------
+ * The engine's queue discipline as an object of its own, so it can be checked against the oracle's restatement of
+ * ArcherTaskPool (core/prefetch/task_scheduler.cpp) without a device.  node ids are arbitrary non-negative ints,
+ * `layer` is the reference's corr_id & 0xffffffff, level 0 is the most urgent of 20. */
+typedef struct moeinf_pq moeinf_pq;
+int moeinf_pq_create(moeinf_pq** out);
+int moeinf_pq_destroy(moeinf_pq* q);
+/* EnqueueTask (task_scheduler.cpp:82-118) */
+int moeinf_pq_enqueue(moeinf_pq* q, int64_t node, int layer, int priority, int remove_layer, int32_t* dropped);
+/* StartExec's queue step (:158-168); node < 0: only the stale-layer rule */
+int moeinf_pq_on_demand(moeinf_pq* q, int64_t node, int layer, int32_t* dropped);
+/* FetchExec (:44-80); already_there: the node is on its target device (not queued) */
+int moeinf_pq_fetch(moeinf_pq* q, int64_t node, int layer, int already_there, int32_t* dropped);
+/* ReplaceCacheCandidates / ClearQueue (task_scheduler.h:55-79) */
+int moeinf_pq_clear_prefetch(moeinf_pq* q, int32_t* dropped);
+/* GPUThreadFunc's pick (:451-497): *found = 0 when empty */
+int moeinf_pq_pop(moeinf_pq* q, int64_t* node, int32_t* layer, int32_t* priority, int32_t* found);
+int moeinf_pq_snapshot(const moeinf_pq* q, int64_t* nodes, int32_t* layers, int32_t* priorities, int capacity, int32_t* n);
+/* prefetch score in (0,1] -> queue level 1..19 (moeinf_prefetch with scores) */
+int moeinf_priority_from_score(float score, int32_t* level);
 
 /* ---- expert-parallel exchange helpers (multi-GPU) ---------------------
  * Pack routed rows for an all-to-all and unpack the replies.  The collective itself (RCCL
@@ -313,6 +351,13 @@ int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_
 /* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, ep_row_elems];
  * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows are left untouched: nobody reads them). */
 int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream);
+/* Variable-split exchange for prefill-sized batches (tokens*K rows >> what a fixed per-peer capacity should carry):
+ * send rows are COMPACT and sorted by destination rank, send_counts_dev[ep_size] holds the rows per destination; the
+ * host layer exchanges the counts, then moves exactly the routed rows with split sizes.  After this call
+ * moeinf_ep_combine takes cap_rows = 0 and ret_dev in the same compact order. */
+int moeinf_ep_pack_compact(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* send_counts_dev, void* stream);
+/* moeinf_ep_expert_ffn over exactly nrows received rows (no padding rows), y_dev [nrows, H] in arrival order */
+int moeinf_ep_expert_ffn_rows(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int nrows, void* stream);
 /* Combine replies: ret_dev [ep_size*cap_rows, H] holds, in the order moeinf_ep_pack produced,
  * the expert outputs for this rank's routed rows; writes out_dev [tokens, H].  With a shared expert
  * (DeepSeek) registered, its FFN over x_dev runs here, on the token's home rank, and is added last. */

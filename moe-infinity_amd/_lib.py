@@ -5,6 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+ABI_VERSION = 2  # include/moeinf.h MOEINF_ABI_VERSION
 
 
 class MoeInfError(RuntimeError):
@@ -37,6 +38,9 @@ class Stats(C.Structure):
         ("prefetch_issued", C.c_int64), ("prefetch_useful", C.c_int64), ("evictions", C.c_int64),
         ("h2d_bytes", C.c_int64), ("slots_total", C.c_int64), ("slots_used", C.c_int64), ("slot_bytes", C.c_int64),
         ("host_arena_bytes", C.c_int64), ("h2d_busy_ms", C.c_double), ("exposed_wait_ms", C.c_double),
+        ("prefetch_queued", C.c_int64), ("prefetch_cancelled", C.c_int64), ("prefetch_dropped", C.c_int64),
+        ("prefetch_wasted", C.c_int64), ("inflight_hits", C.c_int64), ("host_evictions", C.c_int64),
+        ("disk_reads", C.c_int64), ("disk_bytes", C.c_int64),
     ]
 
     def as_dict(self):
@@ -82,6 +86,7 @@ PROTOTYPES = {
     "moeinf_clear_cache_counts": (C.c_int, [_P]),
     "moeinf_is_resident": (C.c_int, [_P, C.c_int, C.c_int, _I32P]),
     "moeinf_sync_copies": (C.c_int, [_P]),
+    "moeinf_set_cache_budget": (C.c_int, [_P, C.c_int64]),
     "moeinf_get_expert_counters": (C.c_int, [_P, _I64P, C.c_int64]),
     "moeinf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "moeinf_reset_stats": (C.c_int, [_P]),
@@ -109,9 +114,20 @@ PROTOTYPES = {
     "moeinf_cache_sim_access": (C.c_int, [_P, C.c_int64, _I32P, _I64P]),
     "moeinf_cache_sim_protect": (C.c_int, [_P, _I64P, C.c_int]),
     "moeinf_cache_sim_clear_counts": (C.c_int, [_P]),
+    "moeinf_pq_create": (C.c_int, [C.POINTER(_P)]),
+    "moeinf_pq_destroy": (C.c_int, [_P]),
+    "moeinf_pq_enqueue": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _I32P]),
+    "moeinf_pq_on_demand": (C.c_int, [_P, C.c_int64, C.c_int, _I32P]),
+    "moeinf_pq_fetch": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _I32P]),
+    "moeinf_pq_clear_prefetch": (C.c_int, [_P, _I32P]),
+    "moeinf_pq_pop": (C.c_int, [_P, _I64P, _I32P, _I32P, _I32P]),
+    "moeinf_pq_snapshot": (C.c_int, [_P, _I64P, _I32P, _I32P, C.c_int, _I32P]),
+    "moeinf_priority_from_score": (C.c_int, [C.c_float, _I32P]),
     "moeinf_ep_row_elems": (C.c_int, [_P, _I32P]),
     "moeinf_ep_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "moeinf_ep_expert_ffn": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P]),
+    "moeinf_ep_pack_compact": (C.c_int, [_P, _P, _P, _P, _P]),
+    "moeinf_ep_expert_ffn_rows": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P]),
     "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
 }
 
@@ -131,7 +147,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.moeinf_abi_version() != 1:
+    if lib.moeinf_abi_version() != ABI_VERSION:
         raise ImportError("libmoeinf_hip.so ABI version mismatch")
     _LIB = lib
     return lib

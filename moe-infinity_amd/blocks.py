@@ -128,9 +128,9 @@ class SyncSwitchTransformersSparseMLP(_MoeBlockBase):
         out = self._run(hidden_states, batch_rows=b)
         logits, idx, _ = self.engine.routing_tensors(logits=True, topk=True)
         router_logits = logits.reshape(*hidden_states.shape[:-1], self.num_experts)
-        # expert_index = argmax(router_mask) in the reference: dropped tokens have an all-zero mask row -> 0
-        # (the engine's device copy keeps the chosen id; capacity drops are visible through routing())
-        expert_index = idx.reshape(b, -1).long()
+        # expert_index = argmax(router_mask) in the reference (switch_transformers.py:112): capacity-dropped tokens have
+        # an all-zero mask row -> 0.  The engine reports dropped pairs as -1 (moeinf_copy_routing_dev).
+        expert_index = idx.reshape(b, -1).long().clamp_min(0)
         return out, (router_logits, expert_index)
 
     @staticmethod

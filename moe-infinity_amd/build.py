@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmoeinf_hip.so")
 SOURCES = ["kernels.hip", "engine.cpp"]
-HEADERS = ["kernels.h", "cache_policy.h", "tracer.h", os.path.join("..", "..", "include", "moeinf.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "moeinf.h")]
 
 
 def _hipcc():

@@ -23,6 +23,7 @@
 #include "cache_policy.h"
 #include "kernels.h"
 #include "offload_store.h"
+#include "prefetch_queue.h"
 #include "tracer.h"
 
 using namespace moeinf;
@@ -118,12 +119,18 @@ static DevLayout make_dev_layout(int expert_type, int64_t H, int64_t F, int dt, 
 // engine
 // ------------------------------------------------------------------------------------------------
 struct Node {
-  void* host = nullptr;
+  void* host = nullptr;        // pinned arena blob (reference layout); nullptr + store != nullptr: on disk only
   int slot = -1;
-  hipEvent_t ready = nullptr;  // recorded after the H2D copy of this expert
+  hipEvent_t ready1 = nullptr; // recorded once the tensors FFN stage 1 reads are in the slot
+  hipEvent_t ready = nullptr;  // recorded once the whole expert is in the slot
+  bool waited1 = true;         // compute stream already ordered after `ready1`
   bool ready_waited = true;    // compute stream already ordered after `ready`
   bool prefetched = false;     // resident because of a prefetch, not yet dispatched
   int64_t visit = 0, hit = 0, miss = 0, prefetch_cnt = 0;
+  // disk tier (register_expert_from_store): where the host blob can be re-read from when the arena evicted it
+  const OffloadStore* store = nullptr;
+  uint32_t store_ids[4] = {0, 0, 0, 0};
+  uint64_t host_clock = 0;     // last time the host blob was needed (host-tier LRU)
 };
 struct Slot {
   void* dev = nullptr;
@@ -133,13 +140,29 @@ struct Slot {
 
 static constexpr int kFenceRing = 64;
 
+// One H2D lane = a copy stream (hipMemcpyAsync, served by an SDMA engine) + a re-tile stream (kernels) + a ring of two
+// staging buffers, each large enough for the biggest tensor of a blob.  Tensor i+1 is copied into the other
+// buffer while tensor i is re-tiled into its slot, so the link never waits for a kernel; the slot-reuse fences are
+// waited for by the RE-TILE stream only (the copy into staging does not touch the slot).
+struct StageBuf {
+  void* dev = nullptr;
+  hipEvent_t filled = nullptr, freed = nullptr;
+  bool used = false;
+};
+struct CopyLane {
+  hipStream_t copy = nullptr, retile = nullptr;
+  StageBuf ring[2];
+  int next = 0;
+};
+
 struct moeinf_engine {
   moeinf_config cfg;
   int64_t es = 2;  // element size
   int dt = DT_BF16;
   BlobLayout lay, lay_sh;   // host blob (reference layout)
   DevLayout dlay, dlay_sh;  // HBM slot (tiled)
-  void *stage_demand = nullptr, *stage_prefetch = nullptr;  // H2D landing buffers, one per copy stream
+  CopyLane demand, prefetch;  // on-demand misses (high priority) / speculative copies (low priority)
+  int64_t stage_bytes = 0;
   int64_t slot_bytes = 0;
   int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
   bool has_shared = false;
@@ -159,8 +182,14 @@ struct moeinf_engine {
   uint64_t clock = 0;
   std::vector<int> resident_per_layer;  // #experts of layer l resident AND ordered (ready_waited)
 
+  // pending speculative transfers (reference: ArcherTaskPool's unified_queue_) and the copies in flight
+  PrefetchQueue pq;
+  std::deque<int> prefetch_inflight;  // node indices whose copy was issued on the prefetch lane, oldest first
+  int prefetch_window = 2;            // experts in flight on the prefetch lane at most
+  std::vector<void*> host_free;       // arena blocks returned by host-tier eviction
+  uint64_t host_clock = 0;
+
   // streams / events
-  hipStream_t demand_stream = nullptr, prefetch_stream = nullptr;
   hipEvent_t route_ev = nullptr;
   hipEvent_t fence_ev[kFenceRing];
   uint64_t seq = 0;  // forwards issued
@@ -195,7 +224,8 @@ struct moeinf_engine {
   int32_t *d_ep_key = nullptr, *d_ep_counts = nullptr, *d_ep_offsets = nullptr, *d_ep_active = nullptr,
           *d_ep_nactive = nullptr, *d_ep_pair_slot = nullptr, *d_ep_slot_token = nullptr, *d_ep_slot_pair = nullptr,
           *d_ep_pair_pos = nullptr;
-  int ep_cap_rows = 0;
+  int ep_cap_rows = 0;   // per-peer capacity of the last ep_pack (0: compact, variable-split exchange)
+  int ep_alloc_cap = 0;  // what the EP workspace is sized for
 
   // stage-2 output override of the expert-parallel FFN: rows go straight to the reply buffer, in arrival order
   void* ovr_out = nullptr;
@@ -302,7 +332,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
   for (auto p : g->arena_chunks) hipHostFree(p);
-  for (auto& n : g->nodes) if (n.ready) hipEventDestroy(n.ready);
+  for (auto& n : g->nodes) { if (n.ready) hipEventDestroy(n.ready); if (n.ready1) hipEventDestroy(n.ready1); }
   for (auto e : g->event_pool) hipEventDestroy(e);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* bufs[] = {g->d_wptr, g->d_logits, g->d_topk_idx, g->d_pair_valid, g->d_pair_order, g->d_pair_slot, g->d_topk_w,
@@ -311,14 +341,19 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
-  if (g->stage_demand) hipFree(g->stage_demand);
-  if (g->stage_prefetch) hipFree(g->stage_prefetch);
+  for (CopyLane* ln : {&g->demand, &g->prefetch}) {
+    for (auto& b : ln->ring) {
+      if (b.dev) hipFree(b.dev);
+      if (b.filled) hipEventDestroy(b.filled);
+      if (b.freed) hipEventDestroy(b.freed);
+    }
+    if (ln->copy) hipStreamDestroy(ln->copy);
+    if (ln->retile) hipStreamDestroy(ln->retile);
+  }
   if (g->h_mirror) hipHostFree(g->h_mirror);
   if (g->h_miss) hipHostFree(g->h_miss);
   if (g->route_ev) hipEventDestroy(g->route_ev);
   for (int i = 0; i < kFenceRing; ++i) if (g->fence_ev[i]) hipEventDestroy(g->fence_ev[i]);
-  if (g->demand_stream) hipStreamDestroy(g->demand_stream);
-  if (g->prefetch_stream) hipStreamDestroy(g->prefetch_stream);
   delete g;
   return MOEINF_OK;
 }
@@ -368,8 +403,12 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
 
   int lo = 0, hi = 0;
   TRYHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  TRYHIP(hipStreamCreateWithPriority(&g->demand_stream, hipStreamNonBlocking, hi));  // on-demand misses outrank prefetch
-  TRYHIP(hipStreamCreateWithPriority(&g->prefetch_stream, hipStreamNonBlocking, lo));
+  // on-demand misses outrank speculative copies
+  TRYHIP(hipStreamCreateWithPriority(&g->demand.copy, hipStreamNonBlocking, hi));
+  TRYHIP(hipStreamCreateWithPriority(&g->demand.retile, hipStreamNonBlocking, hi));
+  TRYHIP(hipStreamCreateWithPriority(&g->prefetch.copy, hipStreamNonBlocking, lo));
+  TRYHIP(hipStreamCreateWithPriority(&g->prefetch.retile, hipStreamNonBlocking, lo));
+  if (const char* w = getenv("MOEINF_PREFETCH_WINDOW")) g->prefetch_window = std::max(1, atoi(w));
   TRYHIP(hipEventCreateWithFlags(&g->route_ev, hipEventDisableTiming));
   for (int i = 0; i < kFenceRing; ++i) TRYHIP(hipEventCreateWithFlags(&g->fence_ev[i], hipEventDisableTiming));
 
@@ -390,8 +429,14 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
   TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
-  TRYHIP(hipMalloc(&g->stage_demand, (size_t)std::max(g->lay.total, g->lay_sh.total)));
-  TRYHIP(hipMalloc(&g->stage_prefetch, (size_t)g->lay.total));
+  for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i], kAioAlignment)));
+  for (CopyLane* ln : {&g->demand, &g->prefetch}) {
+    for (auto& b : ln->ring) {
+      TRYHIP(hipMalloc(&b.dev, (size_t)g->stage_bytes));
+      TRYHIP(hipEventCreateWithFlags(&b.filled, hipEventDisableTiming));
+      TRYHIP(hipEventCreateWithFlags(&b.freed, hipEventDisableTiming));
+    }
+  }
   TRYHIP(hipHostMalloc((void**)&g->h_mirror, (1 + 2 * E1) * sizeof(int32_t), hipHostMallocDefault));
   {
     const size_t per = ((size_t)(1 + 2 * E1) + 15) / 16 * 16;  // ints per mirror, 64-byte aligned
@@ -406,7 +451,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
 #undef TRYHIP
 }
 
-static int retile_blob(const moeinf_engine* g, const BlobLayout& lay, const DevLayout& dl, const void* staged, void* slot, hipStream_t cs);
+static int retile_tensor(const moeinf_engine* g, const DevLayout& dl, int i, const void* staged, void* slot, hipStream_t cs);
 
 // ---- registration --------------------------------------------------------------------------
 extern "C" int moeinf_expert_layout(const moeinf_engine* g, int which, int64_t offsets[4], int64_t sizes[4], int32_t* n_tensors, int64_t* total_bytes) {
@@ -452,10 +497,14 @@ extern "C" int moeinf_register_shared(moeinf_engine* g, int layer, const void* b
   if (!blob || nbytes != g->lay_sh.total) return fail(MOEINF_ERR_INVALID, "shared blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay_sh.total);
   HIPCHK(hipSetDevice(g->cfg.device_id));
   if (!g->shared_dev[layer]) HIPCHK(hipMalloc(&g->shared_dev[layer], (size_t)g->dlay_sh.total));
-  HIPCHK(hipStreamSynchronize(g->demand_stream));
-  HIPCHK(hipMemcpyAsync(g->stage_demand, blob, (size_t)nbytes, hipMemcpyHostToDevice, g->demand_stream));
-  CHK(retile_blob(g, g->lay_sh, g->dlay_sh, g->stage_demand, g->shared_dev[layer], g->demand_stream));
-  HIPCHK(hipStreamSynchronize(g->demand_stream));
+  // one-off, synchronous: tensor by tensor through the demand lane's first staging buffer
+  HIPCHK(hipStreamSynchronize(g->demand.copy));
+  HIPCHK(hipStreamSynchronize(g->demand.retile));
+  for (int i = 0; i < g->dlay_sh.n; ++i) {
+    HIPCHK(hipMemcpyAsync(g->demand.ring[0].dev, (const char*)blob + g->lay_sh.off[i], (size_t)g->lay_sh.size[i], hipMemcpyHostToDevice, g->demand.copy));
+    CHK(retile_tensor(g, g->dlay_sh, i, g->demand.ring[0].dev, g->shared_dev[layer], g->demand.copy));
+    HIPCHK(hipStreamSynchronize(g->demand.copy));
+  }
   uint64_t p = (uint64_t)g->shared_dev[layer];
   HIPCHK(hipMemcpy(g->d_wptr + (size_t)layer * (g->E + 1) + g->E, &p, sizeof p, hipMemcpyHostToDevice));
   return MOEINF_OK;
@@ -486,7 +535,9 @@ static void drop_ready_count(moeinf_engine* g, int idx) {
 }
 
 // obtain a device slot for node `idx`; may evict.  Pinned entries (pol[].pinned) are never evicted.
-static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_protected) {
+// *victim_out = node index of the evicted tenant (-1: the slot was free / fresh).
+static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_protected, int* victim_out) {
+  *victim_out = -1;
   if (!g->free_slots.empty()) {
     *slot_out = g->free_slots.back();
     g->free_slots.pop_back();
@@ -512,6 +563,7 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   drop_ready_count(g, (int)v);
   const int slot = vn.slot;
   vn.slot = -1;
+  if (vn.prefetched) g->st.prefetch_wasted += 1;  // brought in speculatively, evicted before any dispatch used it
   vn.prefetched = false;
   g->pol[v].resident = false;
   g->slots[slot].node = -1;
@@ -519,50 +571,91 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   g->st.slots_used -= 1;
   queue_poke(g, (int)(v % g->L), (int)(v / g->L), 0);
   *slot_out = slot;
+  *victim_out = (int)v;
   return MOEINF_OK;
 }
 
-// staged row-major blob (device) -> tiled slot, on stream cs
-static int retile_blob(const moeinf_engine* g, const BlobLayout& lay, const DevLayout& dl, const void* staged, void* slot, hipStream_t cs) {
-  for (int i = 0; i < dl.n; ++i) {
-    const char* src = (const char*)staged + lay.off[i];
-    char* dst = (char*)slot + dl.off[i];
-    if (dl.K[i] > 0) HIPCHK(launch_retile(src, dst, dl.R[i], dl.K[i], g->dt, cs));
-    else HIPCHK(hipMemcpyAsync(dst, src, (size_t)dl.size[i], hipMemcpyDeviceToDevice, cs));
+// staged row-major tensor i (device staging buffer) -> its place in the tiled slot, on stream cs
+static int retile_tensor(const moeinf_engine* g, const DevLayout& dl, int i, const void* staged, void* slot, hipStream_t cs) {
+  char* dst = (char*)slot + dl.off[i];
+  if (dl.K[i] > 0) HIPCHK(launch_retile(staged, dst, dl.R[i], dl.K[i], g->dt, cs));
+  else HIPCHK(hipMemcpyAsync(dst, staged, (size_t)dl.size[i], hipMemcpyDeviceToDevice, cs));
+  return MOEINF_OK;
+}
+
+// Copy order of a blob's tensors: what FFN stage 1 reads first (w1 AND w3 / gate AND up / fc1 + bias / wi), then
+// the stage-2 tensors — so the compute stream can start stage 1 while the down projection is still on the link.
+// Returns the number of stage-1 tensors.
+static int copy_order(int expert_type, int order[4]) {
+  switch (expert_type) {
+    case MOEINF_EXPERT_MIXTRAL: order[0] = 0; order[1] = 2; order[2] = 1; return 2;   // w1 w3 | w2
+    case MOEINF_EXPERT_DEEPSEEK: order[0] = 0; order[1] = 1; order[2] = 2; return 2;  // gate up | down
+    case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: order[0] = 0; order[1] = 1; order[2] = 2; order[3] = 3; return 2;  // fc1.w fc1.b | fc2.w fc2.b
+    default: order[0] = 0; order[1] = 1; return 1;                                     // wi | wo
   }
-  return MOEINF_OK;
 }
 
-// start the H2D copy of node idx into a slot on `cs`
-static int issue_copy(moeinf_engine* g, int idx, hipStream_t cs, bool allow_protected) {
+static int ensure_host(moeinf_engine* g, int idx);
+
+// start the H2D transfer of node idx into a slot on lane `ln` (reference: Node::SetDevice host->device leg,
+// model_topology.cpp:102-119, which is a cudaMemcpyAsync + cudaStreamSynchronize of the whole blob)
+static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protected) {
   Node& n = g->nodes[idx];
-  if (!n.host) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) was dispatched but never registered", idx % g->L, idx / g->L);
-  int slot = -1;
-  CHK(acquire_slot(g, idx, &slot, allow_protected));
+  if (!n.host && !n.store) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) was dispatched but never registered", idx % g->L, idx / g->L);
+  CHK(ensure_host(g, idx));
+  int slot = -1, victim = -1;
+  CHK(acquire_slot(g, idx, &slot, allow_protected, &victim));
   Slot& s = g->slots[slot];
-  // the slot's previous tenant may still be read by kernels of forward #last_use_seq
-  // (fence ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence)
-  if (s.last_use_seq > 0) {
-    const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
-    hipEvent_t fe = g->fence_ev[fs % kFenceRing];
-    if (hipEventQuery(fe) != hipSuccess) {
-      (void)hipGetLastError();
-      HIPCHK(hipStreamWaitEvent(cs, fe, 0));
-    }
-  }
-  hipEvent_t start = get_event(g), stop = get_event(g);
   if (!n.ready) HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
-  if (start && stop) HIPCHK(hipEventRecord(start, cs));
-  void* staged = (cs == g->demand_stream) ? g->stage_demand : g->stage_prefetch;
-  HIPCHK(hipMemcpyAsync(staged, n.host, (size_t)g->lay.total, hipMemcpyHostToDevice, cs));
-  CHK(retile_blob(g, g->lay, g->dlay, staged, s.dev, cs));
+  if (!n.ready1) HIPCHK(hipEventCreateWithFlags(&n.ready1, hipEventDisableTiming));
+  hipEvent_t start = get_event(g), stop = get_event(g);
+  if (start && stop) HIPCHK(hipEventRecord(start, ln.copy));
+  int order[4];
+  const int n1 = copy_order(g->cfg.expert_type, order);
+  for (int k = 0; k < g->lay.n; ++k) {
+    const int i = order[k];
+    StageBuf& b = ln.ring[ln.next];
+    ln.next ^= 1;
+    if (b.used) HIPCHK(hipStreamWaitEvent(ln.copy, b.freed, 0));  // its previous content has been re-tiled
+    HIPCHK(hipMemcpyAsync(b.dev, (const char*)n.host + g->lay.off[i], (size_t)g->lay.size[i], hipMemcpyHostToDevice, ln.copy));
+    HIPCHK(hipEventRecord(b.filled, ln.copy));
+    HIPCHK(hipStreamWaitEvent(ln.retile, b.filled, 0));
+    if (k == 0) {
+      // first write into the slot.  (a) kernels of forward #last_use_seq may still read the previous tenant (fence
+      // ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence);
+      if (s.last_use_seq > 0) {
+        const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
+        hipEvent_t fe = g->fence_ev[fs % kFenceRing];
+        if (hipEventQuery(fe) != hipSuccess) {
+          (void)hipGetLastError();
+          HIPCHK(hipStreamWaitEvent(ln.retile, fe, 0));
+        }
+      }
+      // (b) the previous tenant's OWN transfer may still be in flight on the other lane (a prefetched expert is
+      // evictable from the moment its copy is issued): write-after-write on the slot
+      if (victim >= 0) {
+        Node& vn = g->nodes[victim];
+        if (!vn.ready_waited && vn.ready && hipEventQuery(vn.ready) != hipSuccess) {
+          (void)hipGetLastError();
+          HIPCHK(hipStreamWaitEvent(ln.retile, vn.ready, 0));
+        }
+        vn.ready_waited = true; vn.waited1 = true;
+      }
+    }
+    CHK(retile_tensor(g, g->dlay, i, b.dev, s.dev, ln.retile));
+    HIPCHK(hipEventRecord(b.freed, ln.retile));
+    b.used = true;
+    if (k == n1 - 1) HIPCHK(hipEventRecord(n.ready1, ln.retile));
+  }
   if (start && stop) {
-    HIPCHK(hipEventRecord(stop, cs));
+    HIPCHK(hipEventRecord(stop, ln.copy));  // link-busy interval: first to last hipMemcpyAsync of this expert
     g->copy_timers.push_back({start, stop});
   }
-  HIPCHK(hipEventRecord(n.ready, cs));
+  HIPCHK(hipEventRecord(n.ready, ln.retile));
   n.slot = slot;
   n.ready_waited = false;
+  n.waited1 = false;
+  n.host_clock = ++g->host_clock;
   s.node = idx;
   g->pol[idx].resident = true;
   g->st.slots_used += 1;
@@ -604,7 +697,58 @@ static void settle_copy_timers(moeinf_engine* g, bool wait) {
   g->wait_timers.resize(keep);
 }
 
+// ---- host tier as a cache over the disk tier -------------------------------------------------
+// Experts registered from an offload directory keep (store, tensor ids); when the pinned arena is capped
+// (cfg.host_memory_bytes — the reference's host_memory_ratio, memory_pool.cpp:150-158) and full, the least recently
+// needed host blob that can be re-read from disk gives up its arena block (reference: Node::SetDevice(DISK),
+// model_topology.cpp:76-88) and the wanted expert is read disk -> pinned host (-> HBM by the caller).
+static int ensure_host(moeinf_engine* g, int idx) {
+  Node& n = g->nodes[idx];
+  n.host_clock = ++g->host_clock;
+  if (n.host) return MOEINF_OK;
+  if (!n.store) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) has no host copy and no disk copy", idx % g->L, idx / g->L);
+  void* blk = nullptr;
+  if (!g->host_free.empty()) {
+    blk = g->host_free.back();
+    g->host_free.pop_back();
+  } else if (g->cfg.host_memory_bytes <= 0 || g->arena_total + g->lay.total <= g->cfg.host_memory_bytes) {
+    CHK(arena_alloc(g, g->lay.total, &blk));
+  } else {
+    int victim = -1;
+    for (int i = 0; i < (int)g->nodes.size(); ++i) {
+      Node& v = g->nodes[i];
+      if (i == idx || !v.host || !v.store) continue;
+      if (v.slot >= 0 && !v.ready_waited && v.ready && hipEventQuery(v.ready) != hipSuccess) { (void)hipGetLastError(); continue; }  // its H2D copy still reads the blob
+      if (victim < 0 || v.host_clock < g->nodes[victim].host_clock) victim = i;
+    }
+    if (victim < 0) return fail(MOEINF_ERR_OOM, "pinned host arena cap (%lld bytes) reached and no host blob can be dropped", (long long)g->cfg.host_memory_bytes);
+    blk = g->nodes[victim].host;
+    g->nodes[victim].host = nullptr;
+    g->st.host_evictions += 1;
+  }
+  for (int i = 0; i < g->lay.n; ++i) {
+    // each tensor's region in the blob is 4 KiB aligned and padded -> eligible for O_DIRECT
+    const uint64_t room = (uint64_t)((i + 1 < g->lay.n ? g->lay.off[i + 1] : g->lay.total) - g->lay.off[i]);
+    const std::string err = n.store->get(n.store_ids[i], (char*)blk + g->lay.off[i], room);
+    if (!err.empty()) { g->host_free.push_back(blk); return fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
+  }
+  g->st.disk_reads += 1;
+  g->st.disk_bytes += g->lay.total;
+  n.host = blk;
+  return MOEINF_OK;
+}
+
 // ---- the hot path --------------------------------------------------------------------------
+static int pump_prefetch(moeinf_engine* g);
+// a layer is being dispatched: speculative transfers queued for layers the pass has already left are stale
+// (StartExec drops every queued task with a smaller layer id, task_scheduler.cpp:158-168)
+static inline void drop_stale_prefetches(moeinf_engine* g, int layer) {
+  if (!g->pq.empty()) g->st.prefetch_cancelled += g->pq.on_demand(-1, layer);
+}
+static inline int pump_if_pending(moeinf_engine* g) {
+  if (g->pq.empty() && g->prefetch_inflight.empty()) return MOEINF_OK;
+  return pump_prefetch(g);
+}
 static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
   const DevLayout& b = g->dlay;
   const DevLayout& bs = g->dlay_sh;
@@ -721,6 +865,7 @@ static void settle_ready(moeinf_engine* g, int layer) {
     if (n.slot < 0 || n.ready_waited || !n.ready) continue;
     if (hipEventQuery(n.ready) == hipSuccess) {
       n.ready_waited = true;
+      n.waited1 = true;
       g->resident_per_layer[layer] += 1;
     } else {
       (void)hipGetLastError();
@@ -728,51 +873,73 @@ static void settle_ready(moeinf_engine* g, int layer) {
   }
 }
 
-// make every active routed expert of `layer` resident and order the compute stream after its copy.
+// make every active routed expert of `layer` resident and order the compute stream after the part of its transfer
+// that FFN STAGE 1 reads (ready1).  Experts whose stage-2 tensors may still be in flight are appended to `late`:
+// the caller orders the compute stream after their `ready` event between the two FFN launches, so stage 1 runs
+// while the down projections are still on the link.
 // h_mirror = {n_active, counts[E+1], active[E+1]} (already on the host).
-static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, int a0 = 0, int a1 = -1) {
+static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vector<int>& late, int a0 = 0, int a1 = -1) {
   const int E1 = g->E + 1;
   const int na = a1 < 0 ? g->h_mirror[0] : a1;
-  const int32_t* counts = g->h_mirror + 1;
   const int32_t* active = g->h_mirror + 1 + E1;
   // pin this layer's active experts so a miss cannot evict a sibling that the same launch reads
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
   int rc = MOEINF_OK;
   // if the compute stream will have to wait for a copy, time the stall (exposed copy time)
   bool will_wait = false;
-  for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) { const Node& n = g->nodes[node_index(g, layer, e)]; if (n.slot < 0 || !n.ready_waited) will_wait = true; } }
+  for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) { const Node& n = g->nodes[node_index(g, layer, e)]; if (n.slot < 0 || !n.waited1) will_wait = true; } }
   hipEvent_t w0 = nullptr, w1 = nullptr;
   if (will_wait) { w0 = get_event(g); w1 = get_event(g); if (w0 && w1) hipEventRecord(w0, st); }
   for (int i = a0; i < na && rc == MOEINF_OK; ++i) {
     const int e = active[i];
     if (e >= g->E) continue;  // shared pseudo-expert
-    (void)counts;
     const int idx = node_index(g, layer, e);
     Node& n = g->nodes[idx];
     n.visit += 1;
     if (n.slot >= 0) {
       n.hit += 1;
       g->st.expert_hits += 1;
+      if (!n.ready_waited && hipEventQuery(n.ready) != hipSuccess) { (void)hipGetLastError(); g->st.inflight_hits += 1; }
       if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; }
     } else {
       n.miss += 1;
       g->st.expert_misses += 1;
-      rc = issue_copy(g, idx, g->demand_stream, true);
+      // a queued speculative transfer of this expert is overtaken by the demand (StartExec, task_scheduler.cpp:158-168)
+      g->st.prefetch_cancelled += g->pq.remove_node(idx);
+      rc = issue_copy(g, idx, g->demand, true);
       if (rc != MOEINF_OK) break;
     }
-    if (!n.ready_waited) {
-      hipError_t he = hipStreamWaitEvent(st, n.ready, 0);
+    if (!n.waited1) {
+      hipError_t he = hipStreamWaitEvent(st, n.ready1, 0);
       if (he != hipSuccess) { rc = fail(MOEINF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(he)); break; }
-      n.ready_waited = true;
-      g->resident_per_layer[layer] += 1;
+      n.waited1 = true;
     }
+    if (!n.ready_waited) late.push_back(idx);
     g->pol[idx].incache += 1;  // incache_visit_count += 1 on every dispatch (expert_dispatcher.cpp:263)
     g->pol[idx].last_access = ++g->clock;
+    n.host_clock = ++g->host_clock;
     g->slots[n.slot].last_use_seq = g->seq + 1;
   }
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
   if (w0 && w1) { hipEventRecord(w1, st); g->wait_timers.push_back({w0, w1}); }
   return rc;
+}
+
+// order the compute stream after the full transfers of `late` (between FFN stage 1 and stage 2)
+static int wait_late(moeinf_engine* g, int layer, hipStream_t st, std::vector<int>& late) {
+  if (late.empty()) return MOEINF_OK;
+  hipEvent_t w0 = get_event(g), w1 = get_event(g);
+  if (w0 && w1) hipEventRecord(w0, st);
+  for (int idx : late) {
+    Node& n = g->nodes[idx];
+    if (n.ready_waited || n.slot < 0) continue;
+    HIPCHK(hipStreamWaitEvent(st, n.ready, 0));
+    n.ready_waited = true;
+    g->resident_per_layer[layer] += 1;
+  }
+  if (w0 && w1) { hipEventRecord(w1, st); g->wait_timers.push_back({w0, w1}); }
+  late.clear();
+  return MOEINF_OK;
 }
 
 // Launch both FFN stages for the active list in h_mirror.  If the layer needs more experts than
@@ -796,7 +963,8 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     int b = a;
     int64_t used = 0;
     while (b < na && (active[b] >= E || used < cap)) { if (active[b] < E) ++used; ++b; }
-    CHK(ensure_resident(g, layer, st, a, b));
+    std::vector<int> late;
+    CHK(ensure_resident(g, layer, st, late, a, b));
     CHK(flush_pokes(g, st));
     s1.active = g->d_active + a; s2.active = g->d_active + a;
     s1.n_active_host = b - a; s2.n_active_host = b - a;
@@ -808,6 +976,7 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     for (int i = a; i < b; ++i) max_rows = std::max(max_rows, (int)g->h_mirror[1 + active[i]]);
     HIPCHK(launch_ffn_stage(s1, b - a, max_rows, st));
     if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
+    CHK(wait_late(g, layer, st, late));  // stage 2 reads the down projections: wait for the rest of each transfer
     HIPCHK(launch_ffn_stage(s2, b - a, max_rows, st));
     a = b;
     if (a < na) {
@@ -895,7 +1064,10 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool prof = g->profiling && !route_only;
   if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
   MirrorPlan mp;
-  if (!route_only) CHK(plan_mirror(g, layer, mp));
+  if (!route_only) {
+    drop_stale_prefetches(g, layer);
+    CHK(plan_mirror(g, layer, mp));
+  }
 
   IndexArgs ia;
   memset(&ia, 0, sizeof ia);
@@ -941,7 +1113,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // fence: slots used by this forward may be recycled only after this point of the stream
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-  return MOEINF_OK;
+  return pump_if_pending(g);  // the host is idle until the next layer: serve the speculative queue now
 }
 
 extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_dev, int tokens, const void* mask_dev, int mask_elem_bytes,
@@ -961,6 +1133,8 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   ia.T = tokens; ia.K = 1; ia.E = E;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->h_mirror;
+  ia.slot_cap = g->cfg.max_tokens * g->K;  // rows the workspace holds: the kernel never writes past them
+  drop_stale_prefetches(g, layer);
   HIPCHK(launch_mask_index(mask_dev, mask_elem_bytes, tokens, E, ia, st));
   HIPCHK(hipEventRecord(g->route_ev, st));
   HIPCHK(hipEventSynchronize(g->route_ev));
@@ -978,7 +1152,7 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-  return MOEINF_OK;
+  return pump_if_pending(g);
 }
 
 extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int32_t* topk_idx_dev, float* topk_w_dev, void* stream) {
@@ -988,7 +1162,8 @@ extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int3
   hipStream_t st = (hipStream_t)stream;
   const size_t T = (size_t)g->last_T;
   if (logits_dev) HIPCHK(hipMemcpyAsync(logits_dev, g->d_logits, T * g->E * 4, hipMemcpyDeviceToDevice, st));
-  if (topk_idx_dev) HIPCHK(hipMemcpyAsync(topk_idx_dev, g->d_topk_idx, T * g->K * 4, hipMemcpyDeviceToDevice, st));
+  // capacity-dropped / unrouted pairs are reported as -1, like moeinf_get_routing does on the host
+  if (topk_idx_dev) HIPCHK(launch_masked_idx(g->d_topk_idx, g->d_pair_valid, topk_idx_dev, (int)(T * g->K), st));
   if (topk_w_dev) HIPCHK(hipMemcpyAsync(topk_w_dev, g->d_topk_w, T * g->K * 4, hipMemcpyDeviceToDevice, st));
   return MOEINF_OK;
 }
@@ -1061,12 +1236,43 @@ extern "C" int moeinf_get_logits(moeinf_engine* g, float* host_out, int64_t n_fl
 }
 
 // ---- prefetch / cache control ----------------------------------------------------------------
+// Serve the pending-transfer queue: keep at most `prefetch_window` speculative copies in flight on the low-priority
+// lane (reference: one worker thread per GPU popping ArcherTaskPool's queue, task_scheduler.cpp:451-517).  Called
+// from every entry point that may have freed the lane or added work; never blocks.
+static int pump_prefetch(moeinf_engine* g) {
+  while (!g->prefetch_inflight.empty()) {  // retire finished copies, oldest first
+    const int idx = g->prefetch_inflight.front();
+    Node& n = g->nodes[idx];
+    if (n.slot >= 0 && !n.ready_waited && n.ready && hipEventQuery(n.ready) != hipSuccess) { (void)hipGetLastError(); break; }
+    g->prefetch_inflight.pop_front();
+  }
+  while ((int)g->prefetch_inflight.size() < g->prefetch_window) {
+    QueuedTask t;
+    if (!g->pq.pop(&t)) break;
+    const int idx = (int)t.node;
+    Node& nd = g->nodes[idx];
+    if (nd.slot >= 0) continue;  // became resident (demand fetch) while it waited
+    // a speculative copy never evicts the protected set (candidates_, task_scheduler.cpp:292-297) nor an expert of
+    // the layer being dispatched; if nothing can be freed the task is dropped ("evict failed", :505-510)
+    g->pol[idx].pinned = true;
+    const int rc = issue_copy(g, idx, g->prefetch, false);
+    g->pol[idx].pinned = false;
+    if (rc == MOEINF_ERR_OOM) { g->st.prefetch_dropped += 1; continue; }
+    if (rc != MOEINF_OK) return rc;
+    nd.prefetched = true;
+    nd.prefetch_cnt += 1;
+    g->st.prefetch_issued += 1;
+    g->prefetch_inflight.push_back(idx);
+  }
+  g->st.prefetch_queued = (int64_t)g->pq.size();
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* experts, const float* scores, int n) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   drain_mirrors(g, true);
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   if (n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "experts is NULL");
-  (void)scores;  // the caller passes experts in priority order; scores are kept for tracing only
   HIPCHK(hipSetDevice(g->cfg.device_id));
   for (int i = 0; i < n; ++i) {
     const int e = experts[i];
@@ -1074,19 +1280,12 @@ extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* exper
     if (!owns(g, e)) continue;
     const int idx = node_index(g, layer, e);
     Node& nd = g->nodes[idx];
-    if (nd.slot >= 0) continue;  // resident or already in flight: dedup (task_scheduler.cpp:82-118)
-    if (!nd.host) return fail(MOEINF_ERR_STATE, "expert (%d,%d) not registered", layer, e);
-    // never evict a protected expert or one hotter than nothing: if no slot can be freed, stop quietly
-    g->pol[idx].pinned = true;
-    int rc = issue_copy(g, idx, g->prefetch_stream, false);
-    g->pol[idx].pinned = false;
-    if (rc == MOEINF_ERR_OOM) break;
-    if (rc != MOEINF_OK) return rc;
-    nd.prefetched = true;
-    nd.prefetch_cnt += 1;
-    g->st.prefetch_issued += 1;
+    if (nd.slot >= 0) continue;  // resident or already in flight (src == dst device: EnqueueTask returns, :105-110)
+    if (!nd.host && !nd.store) return fail(MOEINF_ERR_STATE, "expert (%d,%d) not registered", layer, e);
+    // EnqueueTask: same-node tasks of equal or lower urgency are displaced (dedup / upgrade)
+    g->st.prefetch_cancelled += g->pq.enqueue(idx, layer, priority_from_score(scores, i));
   }
-  return MOEINF_OK;
+  return pump_prefetch(g);
 }
 
 extern "C" int moeinf_protect(moeinf_engine* g, const int32_t* layers, const int32_t* experts, int n) {
@@ -1095,6 +1294,9 @@ extern "C" int moeinf_protect(moeinf_engine* g, const int32_t* layers, const int
   for (int i = 0; i < n; ++i) CHK(check_le(g, layers[i], experts[i]));
   for (auto& p : g->pol) p.is_protected = false;
   for (int i = 0; i < n; ++i) g->pol[node_index(g, layers[i], experts[i])].is_protected = true;
+  // the new candidate set also empties the speculative levels of the queue (task_scheduler.h:66-79)
+  g->st.prefetch_cancelled += g->pq.clear_prefetch();
+  g->st.prefetch_queued = 0;
   return MOEINF_OK;
 }
 
@@ -1115,8 +1317,15 @@ extern "C" int moeinf_is_resident(moeinf_engine* g, int layer, int expert, int32
 extern "C" int moeinf_sync_copies(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   HIPCHK(hipSetDevice(g->cfg.device_id));
-  HIPCHK(hipStreamSynchronize(g->demand_stream));
-  HIPCHK(hipStreamSynchronize(g->prefetch_stream));
+  for (;;) {  // serve the whole pending queue, a window at a time
+    CHK(pump_prefetch(g));
+    for (CopyLane* ln : {&g->demand, &g->prefetch}) {
+      HIPCHK(hipStreamSynchronize(ln->copy));
+      HIPCHK(hipStreamSynchronize(ln->retile));
+    }
+    if (g->pq.empty()) break;
+  }
+  CHK(pump_prefetch(g));
   settle_copy_timers(g, true);
   return MOEINF_OK;
 }
@@ -1139,6 +1348,8 @@ extern "C" int moeinf_get_stats(moeinf_engine* g, moeinf_stats* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
   drain_mirrors(g, true);
   settle_copy_timers(g, false);
+  CHK(pump_if_pending(g));
+  g->st.prefetch_queued = (int64_t)g->pq.size();
   *out = g->st;
   return MOEINF_OK;
 }
@@ -1150,6 +1361,66 @@ extern "C" int moeinf_reset_stats(moeinf_engine* g) {
   const int64_t st = g->st.slots_total, su = g->st.slots_used, sb = g->st.slot_bytes, ha = g->st.host_arena_bytes;
   memset(&g->st, 0, sizeof g->st);
   g->st.slots_total = st; g->st.slots_used = su; g->st.slot_bytes = sb; g->st.host_arena_bytes = ha;
+  g->st.prefetch_queued = (int64_t)g->pq.size();
+  return MOEINF_OK;
+}
+
+// DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink or grow the
+// expert cache.  Shrinking evicts by the replacement policy until the resident set fits and returns the freed slots'
+// memory to the device; the host copies are authoritative, nothing is written back.
+extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_bytes) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (device_memory_bytes < g->slot_bytes) return fail(MOEINF_ERR_OOM, "budget %lld bytes cannot hold one expert of %lld bytes", (long long)device_memory_bytes, (long long)g->slot_bytes);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  drain_mirrors(g, true);
+  g->st.prefetch_cancelled += g->pq.clear_prefetch();
+  HIPCHK(hipDeviceSynchronize());  // no kernel or copy may still touch a slot that is about to be freed
+  g->prefetch_inflight.clear();
+  for (int l = 0; l < g->L; ++l) settle_ready(g, l);
+  const int64_t new_max = std::min<int64_t>(device_memory_bytes / g->slot_bytes, (int64_t)g->owned_experts * g->L);
+  while (g->st.slots_used > new_max) {
+    const int64_t v = pick_victim(g->pol.data(), (int64_t)g->pol.size(), g->cfg.policy, true);
+    if (v < 0) return fail(MOEINF_ERR_STATE, "cannot shrink the cache: nothing evictable");
+    Node& vn = g->nodes[v];
+    drop_ready_count(g, (int)v);
+    g->free_slots.push_back(vn.slot);
+    g->slots[vn.slot].node = -1;
+    g->slots[vn.slot].last_use_seq = 0;
+    vn.slot = -1; vn.prefetched = false;
+    g->pol[v].resident = false;
+    g->st.evictions += 1;
+    g->st.slots_used -= 1;
+    queue_poke(g, (int)(v % g->L), (int)(v / g->L), 0);
+  }
+  // free slots beyond the new capacity give their memory back
+  while ((int64_t)g->slots.size() > new_max && !g->free_slots.empty()) {
+    // compact: move the last slot's tenant bookkeeping is not needed — only FREE slots are released, and only from
+    // the tail of the slot array so indices of live slots stay valid
+    const int last = (int)g->slots.size() - 1;
+    auto it = std::find(g->free_slots.begin(), g->free_slots.end(), last);
+    if (it == g->free_slots.end()) {
+      // the tail slot is live: move its tenant into a free slot with a lower index (device-to-device copy)
+      const int dst = *std::min_element(g->free_slots.begin(), g->free_slots.end());
+      Slot& from = g->slots[last];
+      Slot& to = g->slots[dst];
+      HIPCHK(hipMemcpy(to.dev, from.dev, (size_t)g->slot_bytes, hipMemcpyDeviceToDevice));
+      to.node = from.node; to.last_use_seq = from.last_use_seq;
+      g->nodes[to.node].slot = dst;
+      queue_poke(g, to.node % g->L, to.node / g->L, (uint64_t)to.dev);
+      from.node = -1;
+      g->free_slots.erase(std::find(g->free_slots.begin(), g->free_slots.end(), dst));
+      g->free_slots.push_back(last);
+      it = std::find(g->free_slots.begin(), g->free_slots.end(), last);
+    }
+    g->free_slots.erase(it);
+    HIPCHK(hipFree(g->slots[last].dev));
+    g->slots.pop_back();
+  }
+  CHK(flush_pokes(g, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  g->max_slots = new_max;
+  g->slab_exhausted = false;
+  g->st.slots_total = new_max;
   return MOEINF_OK;
 }
 
@@ -1220,14 +1491,14 @@ extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, in
     if ((int64_t)m->size != g->lay.size[i]) return fail(MOEINF_ERR_INVALID, "tensor %u is %llu bytes on disk, blob slot %d needs %lld", tensor_ids[i], (unsigned long long)m->size, i, (long long)g->lay.size[i]);
   }
   HIPCHK(hipSetDevice(g->cfg.device_id));
-  Node& nd = g->nodes[node_index(g, layer, expert)];
-  if (!nd.host) CHK(arena_alloc(g, g->lay.total, &nd.host));
-  for (int i = 0; i < n; ++i) {
-    // each tensor's region in the blob is 4 KiB aligned and padded -> eligible for O_DIRECT
-    const uint64_t room = (uint64_t)((i + 1 < n ? g->lay.off[i + 1] : g->lay.total) - g->lay.off[i]);
-    const std::string err = st->s.get(tensor_ids[i], (char*)nd.host + g->lay.off[i], room);
-    if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-  }
+  const int idx = node_index(g, layer, expert);
+  Node& nd = g->nodes[idx];
+  nd.store = &st->s;  // the store must stay open for as long as the engine may re-read this expert
+  for (int i = 0; i < n; ++i) nd.store_ids[i] = tensor_ids[i];
+  // disk -> pinned host now while the arena has room; once the cap is reached the expert stays on disk and is read on
+  // its first miss (the host tier then works as an LRU cache over the offload directory)
+  const bool room = g->cfg.host_memory_bytes <= 0 || !g->host_free.empty() || g->arena_total + g->lay.total <= g->cfg.host_memory_bytes;
+  if (!nd.host && room) CHK(ensure_host(g, idx));
   return MOEINF_OK;
 }
 
@@ -1255,6 +1526,59 @@ extern "C" int moeinf_cache_sim_protect(moeinf_cache_sim* s, const int64_t* ids,
 extern "C" int moeinf_cache_sim_clear_counts(moeinf_cache_sim* s) {
   if (!s) return fail(MOEINF_ERR_INVALID, "sim is NULL");
   s->sim->clear_counts();
+  return MOEINF_OK;
+}
+
+// ---- pending-transfer queue, standalone (host only) -----------------------------------------
+struct moeinf_pq { PrefetchQueue q; };
+extern "C" int moeinf_pq_create(moeinf_pq** out) {
+  if (!out) return fail(MOEINF_ERR_INVALID, "out is NULL");
+  *out = new moeinf_pq();
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_destroy(moeinf_pq* q) { delete q; return MOEINF_OK; }
+extern "C" int moeinf_pq_enqueue(moeinf_pq* q, int64_t node, int layer, int priority, int remove_layer, int32_t* dropped) {
+  if (!q || node < 0) return fail(MOEINF_ERR_INVALID, "bad pq_enqueue arguments");
+  const int d = q->q.enqueue(node, layer, priority, remove_layer != 0);
+  if (dropped) *dropped = d;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_on_demand(moeinf_pq* q, int64_t node, int layer, int32_t* dropped) {
+  if (!q) return fail(MOEINF_ERR_INVALID, "queue is NULL");
+  const int d = q->q.on_demand(node, layer);
+  if (dropped) *dropped = d;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_fetch(moeinf_pq* q, int64_t node, int layer, int already_there, int32_t* dropped) {
+  if (!q || node < 0) return fail(MOEINF_ERR_INVALID, "bad pq_fetch arguments");
+  const int d = q->q.fetch(node, layer, already_there != 0);
+  if (dropped) *dropped = d;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_clear_prefetch(moeinf_pq* q, int32_t* dropped) {
+  if (!q) return fail(MOEINF_ERR_INVALID, "queue is NULL");
+  const int d = q->q.clear_prefetch();
+  if (dropped) *dropped = d;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_pop(moeinf_pq* q, int64_t* node, int32_t* layer, int32_t* priority, int32_t* found) {
+  if (!q || !found) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  QueuedTask t;
+  *found = q->q.pop(&t) ? 1 : 0;
+  if (*found) { if (node) *node = t.node; if (layer) *layer = t.layer; if (priority) *priority = t.priority; }
+  return MOEINF_OK;
+}
+extern "C" int moeinf_pq_snapshot(const moeinf_pq* q, int64_t* nodes, int32_t* layers, int32_t* priorities, int capacity, int32_t* n) {
+  if (!q || !n) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const auto v = q->q.snapshot();
+  if ((int)v.size() > capacity) return fail(MOEINF_ERR_INVALID, "snapshot needs room for %zu tasks", v.size());
+  for (size_t i = 0; i < v.size(); ++i) { if (nodes) nodes[i] = v[i].node; if (layers) layers[i] = v[i].layer; if (priorities) priorities[i] = v[i].priority; }
+  *n = (int32_t)v.size();
+  return MOEINF_OK;
+}
+extern "C" int moeinf_priority_from_score(float score, int32_t* level) {
+  if (!level) return fail(MOEINF_ERR_INVALID, "level is NULL");
+  *level = priority_from_score(&score, 0);
   return MOEINF_OK;
 }
 
@@ -1303,7 +1627,7 @@ extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* e
 
 // ---- expert-parallel helpers ---------------------------------------------------------------
 static int ep_alloc(moeinf_engine* g, int cap_rows) {
-  if (g->d_ep_key && g->ep_cap_rows >= cap_rows) return MOEINF_OK;
+  if (g->d_ep_key && g->ep_alloc_cap >= cap_rows) { g->ep_cap_rows = cap_rows; return MOEINF_OK; }
   void* olds[] = {g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active, g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* p : olds) if (p) hipFree(p);
   const size_t np = (size_t)g->cfg.max_tokens * g->K;
@@ -1313,6 +1637,7 @@ static int ep_alloc(moeinf_engine* g, int cap_rows) {
   CHK(dmalloc(&g->d_ep_nactive, 1)); CHK(dmalloc(&g->d_ep_pair_slot, nr)); CHK(dmalloc(&g->d_ep_slot_token, nr + 1)); CHK(dmalloc(&g->d_ep_slot_pair, nr + 1));
   CHK(dmalloc(&g->d_ep_pair_pos, np));
   g->ep_cap_rows = cap_rows;
+  g->ep_alloc_cap = cap_rows;
   return MOEINF_OK;
 }
 
@@ -1357,12 +1682,48 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   return MOEINF_OK;
 }
 
-extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream) {
-  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
+extern "C" int moeinf_ep_pack_compact(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, void* stream) {
+  if (!g || !x_dev || !send_dev || !send_counts_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack_compact needs a preceding ROUTE_ONLY forward");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
-  const int ep = g->cfg.ep_size, nrows = ep * cap_rows, E = g->E;
+  const int np = g->last_T * g->K, ep = g->cfg.ep_size;
+  CHK(ep_alloc(g, std::max(1, np)));
+  g->ep_cap_rows = 0;  // compact mode: ep_combine takes cap_rows == 0
+  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
+  IndexArgs ia;
+  memset(&ia, 0, sizeof ia);
+  ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
+  ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
+  ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
+  HIPCHK(launch_dispatch_index(ia, st));
+  EpPackArgs pa;
+  memset(&pa, 0, sizeof pa);
+  pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
+  pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
+  pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = 0; pa.dtype = g->dt;
+  HIPCHK(launch_ep_pack_compact(pa, np, st));
+  HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
+  return MOEINF_OK;
+}
+
+static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st);
+
+extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream) {
+  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (cap_rows <= 0) return fail(MOEINF_ERR_INVALID, "cap_rows must be > 0");
+  return ep_expert_ffn_rows(g, layer, recv_dev, y_dev, g->cfg.ep_size * cap_rows, (hipStream_t)stream);
+}
+extern "C" int moeinf_ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, void* stream) {
+  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (nrows < 0) return fail(MOEINF_ERR_INVALID, "nrows must be >= 0");
+  if (nrows == 0) return MOEINF_OK;  // nothing was routed to this rank
+  return ep_expert_ffn_rows(g, layer, recv_dev, y_dev, nrows, (hipStream_t)stream);
+}
+static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st) {
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  const int E = g->E;
   if ((int64_t)nrows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "ep rows %d exceed workspace (max_tokens*K = %d): create the engine with max_tokens >= ep_size*cap_rows/K", nrows, g->cfg.max_tokens * g->K);
   const int64_t ld = ep_row_elems(g);
   IndexArgs ia;
@@ -1373,6 +1734,7 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
   ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
   MirrorPlan mp;
+  drop_stale_prefetches(g, layer);
   CHK(plan_mirror(g, layer, mp));
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
   HIPCHK(launch_dispatch_index(ia, st));
@@ -1395,12 +1757,12 @@ extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* rec
   g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-  return MOEINF_OK;
+  return pump_if_pending(g);
 }
 
 extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream) {
   if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows");
+  if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows (0 after ep_pack_compact)");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
   if (g->has_shared) {

@@ -104,6 +104,7 @@ struct IndexArgs {
   int32_t* pair_slot;       // [T,K]
   int32_t* slot_token;      // [T*K + T] expert-sorted row -> token id
   int32_t* slot_pair;       // [T*K + T] expert-sorted row -> pair id t*K+k (shared rows: -1)
+  int slot_cap;             // mask_index: rows the slot_token/slot_pair buffers hold (<= 0: unchecked)
   int32_t* mirror;          // pinned HOST buffer {n_active, counts[E+1], active[E+1]} written by the kernel itself
                             // (counts pre-zeroed by the host; only active experts' counts are guaranteed written)
 };
@@ -114,6 +115,8 @@ hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+// out[i] = valid[i] ? idx[i] : -1
+hipError_t launch_masked_idx(const int32_t* idx, const int32_t* valid, int32_t* out, int n, hipStream_t st);
 // index arrays for "only the shared pseudo-expert E is active, with T rows" (expert-parallel path)
 hipError_t launch_shared_only_index(const IndexArgs& a, hipStream_t st);
 
@@ -144,6 +147,8 @@ struct EpPackArgs {
   int K, H, ep_size, cap_rows, dtype;
 };
 hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
+// compact, destination-sorted send rows (variable-split exchange): row r = r-th pair in destination order
+hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st);
 // n_pairs <= 64: dest keys + stable ranks + row copy in one launch (counts/offsets/slot_pair of `a` unused);
 // send_counts (optional, [ep_size]) receives the rows per destination
 hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st);

@@ -1634,8 +1634,12 @@ __global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __res
       const uint64_t b = __ballot(on);
       if (on) {
         const int slot = base + __popcll(b & lanes_below(lane));
-        a.slot_token[slot] = t;
-        a.slot_pair[slot] = t * E + e;
+        // a dense mask may route a token to more than K experts: rows past the workspace capacity are counted (the
+        // host rejects the call from the counts) but never written
+        if (a.slot_cap <= 0 || slot < a.slot_cap) {
+          a.slot_token[slot] = t;
+          a.slot_pair[slot] = t * E + e;
+        }
       }
       base += __popcll(b);
     }
@@ -1645,6 +1649,16 @@ hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E
   if (mask_elem_bytes == 1) hipLaunchKernelGGL(mask_index_kernel<uint8_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const uint8_t*)mask, T, E, a);
   else if (mask_elem_bytes == 4) hipLaunchKernelGGL(mask_index_kernel<int32_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int32_t*)mask, T, E, a);
   else hipLaunchKernelGGL(mask_index_kernel<int64_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int64_t*)mask, T, E, a);
+  return hipGetLastError();
+}
+
+// topk_idx with capacity-dropped / unrouted pairs reported as -1 (what moeinf_get_routing returns on the host)
+__global__ void masked_idx_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ valid, int32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = valid[i] ? idx[i] : -1;
+}
+hipError_t launch_masked_idx(const int32_t* idx, const int32_t* valid, int32_t* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(masked_idx_kernel, dim3((n + 255) / 256), dim3(256), 0, st, idx, valid, out, n);
   return hipGetLastError();
 }
 
@@ -1760,6 +1774,31 @@ __global__ __launch_bounds__(256) void ep_pack_small_kernel(EpPackArgs a, const 
   constexpr int EPV = DT<T>::EPV;
   for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
 }
+// Variable-split exchange (prefill-sized batches): send rows are COMPACT and sorted by destination rank — row r of
+// `send` is the r-th pair in destination order (slot_pair from dispatch_index over the destination keys), so the
+// all-to-all moves exactly the routed rows (split sizes = counts per destination) instead of a fixed capacity per
+// peer.  grid = n_pairs blocks; blocks past the number of dispatched pairs exit.
+template <typename T>
+__global__ __launch_bounds__(256) void ep_pack_compact_kernel(EpPackArgs a, int n_pairs) {
+  const int row = blockIdx.x;
+  const int total = a.offsets[a.ep_size];
+  if (row >= total) return;
+  const int pair = a.slot_pair[row];
+  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
+  if (threadIdx.x == 0) {
+    reinterpret_cast<int32_t*>(dst + a.H)[0] = a.topk_idx[pair];
+    a.pair_pos[pair] = row;
+  }
+  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)(pair / a.K) * a.H;
+  constexpr int EPV = DT<T>::EPV;
+  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
+}
+hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st) {
+  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_compact_kernel<uint16_t>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
+  else hipLaunchKernelGGL(ep_pack_compact_kernel<float>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
+  return hipGetLastError();
+}
+
 hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st) {
   if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_small_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);
   else hipLaunchKernelGGL(ep_pack_small_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);

@@ -42,7 +42,7 @@ class MoEEngine:
                                "there is no CPU fallback")
         self.cfg = cfg
         c = Config()
-        c.abi_version = 1
+        c.abi_version = _lib.ABI_VERSION
         for name, _ in Config._fields_:
             if name in ("abi_version",):
                 continue
@@ -230,6 +230,10 @@ class MoEEngine:
     def sync_copies(self):
         check(self.lib.moeinf_sync_copies(self._h))
 
+    def set_cache_budget(self, device_memory_bytes: int):
+        """SetMemoryRatio at run time, in bytes (shrinking evicts by policy and frees the slots)."""
+        check(self.lib.moeinf_set_cache_budget(self._h, int(device_memory_bytes)))
+
     def expert_counters(self) -> np.ndarray:
         """[L, E, 6] = visit, hit, miss, prefetch, incache_visit_count, resident (get_hit_rate analogue)."""
         a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 6), np.int64)
@@ -267,6 +271,14 @@ class MoEEngine:
     def ep_expert_ffn(self, layer: int, recv: torch.Tensor, y: torch.Tensor, cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(self.lib.moeinf_ep_expert_ffn(self._h, layer, _ptr(recv), _ptr(y), cap_rows, stream))
+
+    def ep_pack_compact(self, x2: torch.Tensor, send: torch.Tensor, send_counts: torch.Tensor):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_pack_compact(self._h, _ptr(x2), _ptr(send), _ptr(send_counts), stream))
+
+    def ep_expert_ffn_rows(self, layer: int, recv: torch.Tensor, y: torch.Tensor, nrows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_expert_ffn_rows(self._h, layer, _ptr(recv), _ptr(y), nrows, stream))
 
     def ep_combine(self, x2: torch.Tensor, ret: torch.Tensor, out: torch.Tensor, cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

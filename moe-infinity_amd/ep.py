@@ -9,8 +9,9 @@ rows travel with one all-to-all each way (RCCL over xGMI; torch.distributed back
     route (local)  ->  pack rows by destination rank  ->  all_to_all  ->  grouped expert FFN on the
     owner  ->  all_to_all back  ->  deterministic combine (local)
 
-Buffers have a fixed per-peer capacity (tokens*K rows: worst case every pair goes to one rank), so
-the exchange needs no host-side size negotiation.  Every exchange row is H activations plus a
+Decode-sized exchanges use a fixed per-peer capacity (tokens*K rows: worst case every pair goes to one rank), so
+they need no host-side size negotiation; prefill-sized exchanges move exactly the routed rows (variable split,
+see ``ExpertParallelMoE``).  Every exchange row is H activations plus a
 16-byte tail holding the row's expert id (-1 = padding), so payload and metadata cross the fabric
 in ONE all-to-all per direction: at decode sizes the exchange is latency-bound (KBs per peer) and the
 number of collectives is what matters.
@@ -26,7 +27,7 @@ import torch.distributed as dist
 
 
 class HipEpOps:
-    """The four EP compute steps on the HIP engine (include/moeinf.h: moeinf_ep_*)."""
+    """The EP compute steps on the HIP engine (include/moeinf.h: moeinf_ep_*)."""
 
     def __init__(self, engine):
         self.engine = engine
@@ -42,28 +43,80 @@ class HipEpOps:
     def pack(self, x2, send, counts, cap_rows):
         self.engine.ep_pack(x2, send, counts, cap_rows)
 
+    def pack_compact(self, x2, send, counts):
+        self.engine.ep_pack_compact(x2, send, counts)
+
     def expert_ffn(self, layer, recv, y, cap_rows):
         self.engine.ep_expert_ffn(layer, recv, y, cap_rows)
+
+    def expert_ffn_rows(self, layer, recv, y, nrows):
+        self.engine.ep_expert_ffn_rows(layer, recv, y, nrows)
 
     def combine(self, x2, ret, out, cap_rows):
         self.engine.ep_combine(x2, ret, out, cap_rows)
 
 
 class ExpertParallelMoE:
+    """Two exchange forms, chosen per call from the number of (token, k) pairs:
+
+    * fixed capacity (decode: pairs <= ``var_threshold``): every peer gets ``cap_rows`` row slots, ONE equal-split
+      all-to-all per direction, no host round trip — the exchange is latency-bound (KBs per peer);
+    * variable split (prefill): rows are packed compactly by destination, the per-destination counts are exchanged
+      first (one tiny all-to-all + the only host read of the path), then exactly the routed rows travel
+      (``all_to_all_single`` with split sizes) — at G ranks the fixed form would move G x the routed bytes.
+    """
+
+    PHASES = ("route_pack", "a2a_dispatch", "owner_ffn", "a2a_combine", "combine")
+
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64):
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.hidden, self.top_k = hidden, top_k
         self.cap_rows = max_tokens * top_k
+        self.var_threshold = var_threshold
         n = self.world * self.cap_rows
         mk = lambda *s, dt=dtype: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
         ld = ops.row_elems()  # H + 16-byte tail (expert id)
         self.send, self.recv = mk(n, ld), mk(n, ld)
         self.y, self.ret = mk(n, hidden), mk(n, hidden)
+        self.send_counts, self.recv_counts = mk(self.world, dt=torch.int32), mk(self.world, dt=torch.int32)
+        self.device = torch.device(device)
+        # per-phase timers (bench.py --gpus N): events on the current stream around the five phases of a layer
+        self.profile = False
+        self._marks = []
+        self.last_form = None
 
+    # -- timers ---------------------------------------------------------------------------------
+    def _mark(self):
+        if not self.profile:
+            return
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._marks.append(ev)
+        else:
+            import time
+
+            self._marks.append(time.perf_counter())
+
+    def phase_times_us(self):
+        """Mean microseconds per layer call of each phase since profiling was switched on."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        n = len(self.PHASES) + 1
+        calls = len(self._marks) // n
+        tot = [0.0] * len(self.PHASES)
+        for c in range(calls):
+            m = self._marks[c * n:(c + 1) * n]
+            for i in range(len(self.PHASES)):
+                tot[i] += (m[i].elapsed_time(m[i + 1]) * 1e3) if self.device.type == "cuda" else (m[i + 1] - m[i]) * 1e6
+        self._marks = []
+        return {"calls": calls, **{p: round(t / max(1, calls), 2) for p, t in zip(self.PHASES, tot)}}
+
+    # -- forward --------------------------------------------------------------------------------
     def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, out: Optional[torch.Tensor] = None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
@@ -71,12 +124,47 @@ class ExpertParallelMoE:
             raise ValueError("more tokens than the exchange buffers were sized for")
         if out is None:
             out = torch.empty_like(x2)
+        if x2.shape[0] * self.top_k > self.var_threshold and self.world > 1:
+            self._forward_variable(layer, x2, gate_w, out)
+        else:
+            self._forward_fixed(layer, x2, gate_w, out)
+        return out.reshape(shape)
+
+    def _forward_fixed(self, layer, x2, gate_w, out):
+        self.last_form = "fixed"
+        self._mark()
         self.ops.route(layer, x2, gate_w)
         self.ops.pack(x2, self.send, None, self.cap_rows)
+        self._mark()
         # dispatch all-to-all: rows with their expert ids in the tail, equal splits of cap_rows per peer
         dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self._mark()
         self.ops.expert_ffn(layer, self.recv, self.y, self.cap_rows)
+        self._mark()
         # combine all-to-all: expert outputs return to the rows' home rank, same row positions
         dist.all_to_all_single(self.ret, self.y, group=self.group)
+        self._mark()
         self.ops.combine(x2, self.ret, out, self.cap_rows)
-        return out.reshape(shape)
+        self._mark()
+
+    def _forward_variable(self, layer, x2, gate_w, out):
+        self.last_form = "variable"
+        self._mark()
+        self.ops.route(layer, x2, gate_w)
+        self.ops.pack_compact(x2, self.send, self.send_counts)
+        # counts first (world int32 each way), then the one host read of this form: the split sizes
+        dist.all_to_all_single(self.recv_counts, self.send_counts, group=self.group)
+        sc = self.send_counts.cpu().tolist()
+        rc = self.recv_counts.cpu().tolist()
+        n_out, n_in = sum(sc), sum(rc)
+        if n_in > self.recv.shape[0]:
+            raise ValueError("received more rows than the exchange buffers hold")
+        self._mark()
+        dist.all_to_all_single(self.recv[:n_in], self.send[:n_out], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        self._mark()
+        self.ops.expert_ffn_rows(layer, self.recv, self.y, n_in)
+        self._mark()
+        dist.all_to_all_single(self.ret[:n_out], self.y[:n_in], output_split_sizes=sc, input_split_sizes=rc, group=self.group)
+        self._mark()
+        self.ops.combine(x2, self.ret, out, 0)
+        self._mark()

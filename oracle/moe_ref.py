@@ -363,6 +363,9 @@ def block_nllb(x3d, wg, experts, layer_id=0, **router_kw) -> BlockResult:
         wts = combining[..., idx]
         next_states[tok] += torch.einsum("b,be->be", wts[tok], output)
         r.expert_out[idx] = output
+    # kept for the parity bar: the `== 0` passthrough below is a discontinuity (oracle/parity.py)
+    r.extra["pre_passthrough"] = next_states.clone()
+    r.extra["x"] = x3d
     zero = next_states == 0
     next_states[zero] = x3d[zero]
     r.extra["top_1_mask"] = top_1_mask

@@ -41,6 +41,25 @@ class OracleEpOps:
         if counts is not None:
             counts.copy_(torch.tensor(cnt, dtype=counts.dtype))
 
+    def pack_compact(self, x2, send, counts):
+        """rows sorted by destination rank (stable: pair order inside a destination), compact"""
+        T, H = x2.shape
+        meta = self._meta(send, H)
+        pairs = [(int(self.sel[t, k]) % self.world, t, k) for t in range(T) for k in range(self.K)]
+        order = sorted(range(len(pairs)), key=lambda i: pairs[i][0])  # Python's sort is stable
+        self.pair_pos = torch.full((T, self.K), -1, dtype=torch.int64)
+        cnt = [0] * self.world
+        for row, i in enumerate(order):
+            d, t, k = pairs[i]
+            send[row, :H] = x2[t]
+            meta[row] = int(self.sel[t, k])
+            self.pair_pos[t, k] = row
+            cnt[d] += 1
+        counts.copy_(torch.tensor(cnt, dtype=counts.dtype))
+
+    def expert_ffn_rows(self, layer, recv, y, nrows):
+        self.expert_ffn(layer, recv[:nrows], y[:nrows], None)
+
     def expert_ffn(self, layer, recv, y, cap_rows):
         y.zero_()
         H = y.shape[1]

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(PROTOTYPES), declared ^ set(PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), f"libmoeinf_hip.so does not export {name}"
-    assert lib.moeinf_abi_version() == 1
+    assert lib.moeinf_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
@@ -39,7 +39,7 @@ def test_struct_sizes_match_header():
 
     # 17 int32/float fields + alignment + double + 2 int64 + 4 int32 (see include/moeinf.h)
     assert C.sizeof(Config) == 17 * 4 + 4 + 8 + 16 + 16
-    assert C.sizeof(Stats) == 13 * 8
+    assert C.sizeof(Stats) == 21 * 8
 
 
 def test_no_gpu_fails_loudly():
@@ -96,3 +96,64 @@ def test_tracer_matches_reference_golden(lib):
                 assert np.array_equal(ls * E + es, want), (name, call)
                 call += 1
         np.testing.assert_array_equal(tr.get_eam(seq), z["eam"])
+
+
+def test_prefetch_queue_matches_the_restated_task_pool(lib):
+    """csrc/prefetch_queue.h (the engine's pending-transfer queue) against oracle/prefetch_queue_ref.py (the reference's
+    ArcherTaskPool queue discipline), operation by operation on random traces: identical displaced counts, pop order
+    and queue content."""
+    import ctypes as C
+    import random
+
+    from oracle.prefetch_queue_ref import RefTaskQueue
+
+    rng = random.Random(7)
+    for trial in range(20):
+        h = C.c_void_p()
+        assert lib.moeinf_pq_create(C.byref(h)) == 0
+        ref = RefTaskQueue()
+        d = C.c_int32()
+        for step in range(300):
+            op = rng.random()
+            node, layer = rng.randrange(24), 0
+            layer = node // 4  # 4 experts per layer
+            if op < 0.45:
+                pr, rl = rng.choice([1, 1, 1, 2, 5, 19]), rng.random() < 0.15
+                assert lib.moeinf_pq_enqueue(h, node, layer, pr, int(rl), C.byref(d)) == 0
+                assert d.value == ref.enqueue(node, layer, pr, rl)
+            elif op < 0.6:
+                nd = node if rng.random() < 0.7 else -1
+                assert lib.moeinf_pq_on_demand(h, nd, layer, C.byref(d)) == 0
+                assert d.value == ref.on_demand(nd, layer)
+            elif op < 0.7:
+                there = rng.random() < 0.3
+                assert lib.moeinf_pq_fetch(h, node, layer, int(there), C.byref(d)) == 0
+                assert d.value == ref.fetch(node, layer, there)
+            elif op < 0.73:
+                assert lib.moeinf_pq_clear_prefetch(h, C.byref(d)) == 0
+                assert d.value == ref.clear_prefetch()
+            else:
+                n, l, p, f = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+                assert lib.moeinf_pq_pop(h, C.byref(n), C.byref(l), C.byref(p), C.byref(f)) == 0
+                want = ref.pop()
+                assert bool(f.value) == (want is not None)
+                if want is not None:
+                    assert (n.value, l.value, p.value) == want
+            nodes = (C.c_int64 * 512)()
+            layers = (C.c_int32 * 512)()
+            prios = (C.c_int32 * 512)()
+            cnt = C.c_int32()
+            assert lib.moeinf_pq_snapshot(h, nodes, layers, prios, 512, C.byref(cnt)) == 0
+            assert [(nodes[i], layers[i], prios[i]) for i in range(cnt.value)] == ref.snapshot()
+        lib.moeinf_pq_destroy(h)
+
+
+def test_priority_from_score_orders_levels(lib):
+    import ctypes as C
+
+    lv = C.c_int32()
+    levels = []
+    for s in (1.0, 0.9, 0.5, 0.2, 0.05, 0.0, -1.0):
+        assert lib.moeinf_priority_from_score(C.c_float(s), C.byref(lv)) == 0
+        levels.append(lv.value)
+    assert levels == sorted(levels) and levels[0] == 1 and levels[-1] == 19 and all(1 <= v <= 19 for v in levels)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, var_threshold=64):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -35,7 +35,8 @@ def _worker(rank, world, port, q):
         h, f, e, k, t, L = 128, 256, 8, 2, 6, 2
         ws = [make_weights("mixtral", h, f, e, 50 + l, torch.bfloat16) for l in range(L)]
         ops = OracleEpOps([w[1] for w in ws], rank, world, k, e, h)
-        ep = ExpertParallelMoE(ops, h, k, t, torch.bfloat16, "cpu")
+        ep = ExpertParallelMoE(ops, h, k, t, torch.bfloat16, "cpu", var_threshold=var_threshold)
+        ep.profile = True
         worst = 0.0
         for step in range(3):
             for l in range(L):
@@ -43,6 +44,9 @@ def _worker(rank, world, port, q):
                 out = ep.forward(l, x, ws[l][0])
                 ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k).out[0]
                 worst = max(worst, float((out.float() - ref.float()).abs().max()))
+                assert ep.last_form == ("variable" if (t - rank) * k > var_threshold else "fixed")
+        ph = ep.phase_times_us()
+        assert ph["calls"] == 3 * L and all(p in ph for p in ep.PHASES)
         q.put((rank, worst))
     finally:
         dist.destroy_process_group()
@@ -62,3 +66,21 @@ def test_ep_gloo_matches_single_process_oracle(world):
         assert p.exitcode == 0
     for rank, worst in res:
         assert worst == 0.0, f"rank {rank}: EP result differs from the oracle block by {worst}"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ep_gloo_variable_split_exchange(world):
+    """The prefill form: counts exchanged first, then exactly the routed rows with split sizes (forced here by a
+    threshold of 0 pairs).  Ragged token counts per rank, same oracle equality."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 0)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in res:
+        assert worst == 0.0, f"rank {rank}: variable-split EP result differs from the oracle block by {worst}"

@@ -99,6 +99,7 @@ def test_deepseek_and_switch_and_nllb_blocks():
     ref = R.block_switch(x, gate, experts, expert_capacity=3)
     assert logits.shape == (2, 12, e) and expert_index.shape == (2, 12)
     assert int((ref.router_mask.sum(-1) == 0).sum()) > 0, "the case must exercise capacity drops"
+    assert torch.equal(expert_index.cpu().reshape(-1), ref.topk_idx.reshape(-1)), "argmax(router_mask): dropped tokens report 0"
     assert_block_close(out, ref, torch.float32, "switch block")
     eng.close()
     # nllb

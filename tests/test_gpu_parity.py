@@ -530,3 +530,55 @@ def test_deepseek_many_tokens_shared_expert_through_the_gemm_kernels():
     ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
     assert_block_close(out, ref, torch.bfloat16, "deepseek 300-token block")
     eng.close()
+
+
+def test_ep_two_ranks_variable_split_emulated_on_one_gpu():
+    """The prefill form of the exchange (compact destination-sorted send rows + per-destination counts, owner FFN over
+    exactly the received rows, combine with cap_rows = 0): two engines on one GPU, the test moves the row ranges the
+    split-size all-to-all would move."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd.engine import FWD_ROUTE_ONLY
+
+    h, f, e, k, world = 256, 512, 8, 2, 2
+    ts = [40, 33]
+    gate, experts, _ = make_weights("mixtral", h, f, e, 430, torch.bfloat16)
+    engs = []
+    for r in range(world):
+        eng = MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f,
+                                        top_k=k, router_kind=Cf.ROUTER_MIXTRAL, device_memory_ratio=0.25,
+                                        ep_rank=r, ep_size=world, max_tokens=world * max(ts)))
+        for i in range(e):
+            if i % world == r:
+                eng.register_expert(0, i, experts[i])
+        engs.append(eng)
+    g = gate.to(DEV)
+    xs = [acts(t, h, torch.bfloat16, 440 + r).to(DEV) for r, t in enumerate(ts)]
+    ld = engs[0].ep_row_elems()
+    send = [torch.zeros(ts[r] * k, ld, dtype=torch.bfloat16, device=DEV) for r in range(world)]
+    cnts = [torch.zeros(world, dtype=torch.int32, device=DEV) for _ in range(world)]
+    for r in range(world):
+        engs[r].forward(0, xs[r], g, flags=FWD_ROUTE_ONLY)
+        engs[r].ep_pack_compact(xs[r], send[r], cnts[r])
+    torch.cuda.synchronize()
+    sc = [c.cpu().tolist() for c in cnts]  # sc[src][dst]
+    assert all(sum(sc[r]) == ts[r] * k for r in range(world))
+    off = [[sum(sc[s][:d]) for d in range(world)] for s in range(world)]
+    recv = [torch.cat([send[s][off[s][d]:off[s][d] + sc[s][d]] for s in range(world)]).contiguous() for d in range(world)]
+    ys = []
+    for d in range(world):
+        ids = recv[d][:, h:h + 2].contiguous().view(torch.int32).reshape(-1)
+        assert bool((ids % world == d).all()) and bool((ids >= 0).all())
+        y = torch.zeros(recv[d].shape[0], h, dtype=torch.bfloat16, device=DEV)
+        engs[d].ep_expert_ffn_rows(0, recv[d], y, recv[d].shape[0])
+        ys.append(y)
+    torch.cuda.synchronize()
+    roff = [[sum(sc[s2][d] for s2 in range(s)) for s in range(world)] for d in range(world)]  # roff[d][s]: rows of s inside recv[d]
+    for r in range(world):
+        ret = torch.cat([ys[d][roff[d][r]:roff[d][r] + sc[r][d]] for d in range(world)]).contiguous()
+        out = torch.empty_like(xs[r])
+        engs[r].ep_combine(xs[r], ret, out, 0)
+        ref = R.block_mixtral(xs[r].cpu()[None], gate, experts, top_k=k)
+        assert_block_close(out, ref, torch.bfloat16, f"variable-split EP rank {r} output")
+    for eng in engs:
+        eng.close()

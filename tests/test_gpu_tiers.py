@@ -1,0 +1,194 @@
+"""The memory tiers under stress, through the C ABI on an MI355X (-m gpu): demand misses racing speculative copies
+(no sync in between), the pending-transfer queue (demand overtakes queued prefetches, stale-layer cancellation,
+protected set), run-time cache budget changes, the pinned arena as an LRU cache over the offload directory."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import R, acts, assert_block_close, make_weights, register_all
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mixtral_engine(L, e, h, f, k, slots, t, **kw):
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    slot = 3 * f * h * 2
+    return MoEEngine(Cf.EngineConfig(num_layers=L, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f, top_k=k,
+                                     router_kind=Cf.ROUTER_MIXTRAL, device_memory_bytes=slots * slot, max_tokens=t, **kw))
+
+
+def test_demand_misses_while_prefetches_are_in_flight_without_any_sync():
+    """a prefetched expert is evictable from the moment its copy is issued; a demand miss that takes
+    its slot must not start writing while the prefetch is still landing there (write-after-write across lanes).
+    Hammer it: tiny cache, prefetch everything speculatively before every forward, never call sync_copies()."""
+    h, f, e, k, t, L = 1024, 2048, 8, 2, 4, 3  # 12 MiB blobs: copies take long enough to overlap the next calls
+    ws = [make_weights("mixtral", h, f, e, 1200 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, 4, t)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    gates = [w[0].to(DEV) for w in ws]
+    for step in range(8):
+        for l in range(L):
+            nxt = (l + 1) % L
+            eng.prefetch(nxt, list(range(e)))  # protects nothing, evicts whatever is coldest — often in-flight prefetches
+            x = acts(t, h, torch.bfloat16, 13000 + 10 * step + l)
+            out = eng.forward(l, x.to(DEV), gates[l])
+            ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
+            assert_block_close(out, ref, torch.bfloat16, f"step {step} layer {l} under prefetch pressure")
+    st = eng.stats()
+    assert st["prefetch_issued"] > 0 and st["evictions"] > 0 and st["expert_misses"] > 0
+    eng.close()
+
+
+def test_a_demand_miss_overtakes_queued_prefetches():
+    """8 speculative transfers are queued for LATER layers; a forward on layer 0 misses.  The miss
+    is served at once on the demand lane: when the forward has finished, most of the speculative queue is still
+    waiting (at most MOEINF_PREFETCH_WINDOW = 2 copies were allowed in flight ahead of it)."""
+    h, f, e, k, t, L = 2048, 4096, 8, 2, 2, 3  # 48 MiB blobs, ~1 ms each on the link
+    ws = [make_weights("mixtral", h, f, e, 1300 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, 24, t)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    eng.prefetch(1, list(range(e)))  # 8 requests for layer 1
+    st0 = eng.stats()
+    assert st0["prefetch_queued"] + st0["prefetch_issued"] == e and st0["prefetch_issued"] <= 2
+    x = acts(t, h, torch.bfloat16, 1310)
+    out = eng.forward(0, x.to(DEV), ws[0][0].to(DEV))  # misses on layer 0
+    torch.cuda.synchronize()
+    st1 = eng.stats()
+    assert st1["expert_misses"] >= 2
+    # the demand copies did not wait for the 8 speculative ones: most of them have not even been issued yet
+    assert st1["prefetch_issued"] <= 4, st1
+    assert_block_close(out, R.block_mixtral(x[None], ws[0][0], ws[0][1], top_k=k), torch.bfloat16, "demand-missed layer")
+    eng.sync_copies()  # serves the rest of the queue
+    st2 = eng.stats()
+    assert st2["prefetch_queued"] == 0 and st2["prefetch_issued"] == e
+    assert all(eng.is_resident(1, i) for i in range(e))
+    # a queued request for an expert that is then DEMANDED is overtaken, not copied twice
+    eng.set_cache_budget(4 * 3 * f * h * 2)
+    eng.prefetch(2, list(range(e)), scores=[0.9, 0.1, 0.8, 0.2, 0.7, 0.3, 0.6, 0.4])
+    x2 = acts(t, h, torch.bfloat16, 1311)
+    before = eng.stats()["h2d_bytes"]
+    out2 = eng.forward(2, x2.to(DEV), ws[2][0].to(DEV))
+    assert_block_close(out2, R.block_mixtral(x2[None], ws[2][0], ws[2][1], top_k=k), torch.bfloat16, "layer 2")
+    eng.sync_copies()
+    st3 = eng.stats()
+    assert st3["prefetch_queued"] == 0
+    copied = (st3["h2d_bytes"] - before) // st3["slot_bytes"]
+    assert copied <= e, "no expert of the layer was transferred twice"
+    eng.close()
+
+
+def test_stale_layer_requests_are_cancelled_and_scores_order_the_queue():
+    h, f, e, k, t, L = 1024, 2048, 8, 2, 2, 4
+    ws = [make_weights("mixtral", h, f, e, 1400 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, 32, t)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    for l in range(L):  # make every layer resident so forwards take the sync-free path
+        eng.prefetch(l, list(range(e)))
+    eng.sync_copies()
+    eng.set_cache_budget(20 * 3 * f * h * 2)  # evicts 12 experts by policy
+    missing = [(l, i) for l in range(L) for i in range(e) if not eng.is_resident(l, i)]
+    assert len(missing) == 12
+    l1 = [i for (l, i) in missing if l == 1]
+    eng.reset_stats()
+    if l1:
+        eng.prefetch(1, l1)  # requests for layer 1 ...
+    x = acts(t, h, torch.bfloat16, 1410)
+    eng.forward(3, x.to(DEV), ws[3][0].to(DEV))  # ... but the pass is already at layer 3: they are stale
+    st = eng.stats()
+    assert st["prefetch_queued"] == 0
+    if len(l1) > 2:
+        assert st["prefetch_cancelled"] >= len(l1) - 2
+    eng.close()
+
+
+def test_cache_budget_can_shrink_and_grow_at_run_time():
+    h, f, e, k, t, L = 256, 512, 8, 2, 4, 2
+    ws = [make_weights("mixtral", h, f, e, 1500 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, 16, t)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    slot = eng.stats()["slot_bytes"]
+
+    def run(tag):
+        for step in range(3):
+            for l in range(L):
+                x = acts(t, h, torch.bfloat16, 1510 + 10 * step + l)
+                out = eng.forward(l, x.to(DEV), ws[l][0].to(DEV))
+                assert_block_close(out, R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k), torch.bfloat16, f"{tag} step {step} layer {l}")
+
+    run("16 slots")
+    eng.set_cache_budget(3 * slot)
+    st = eng.stats()
+    assert st["slots_total"] == 3 and st["slots_used"] <= 3
+    eng.reset_stats()
+    run("3 slots")
+    st = eng.stats()
+    assert st["expert_misses"] > 0 and st["slots_used"] <= 3
+    eng.set_cache_budget(16 * slot)
+    run("16 slots again")
+    assert eng.stats()["slots_total"] == 16
+    from moe_infinity_amd import MoeInfError
+    with pytest.raises(MoeInfError):
+        eng.set_cache_budget(slot - 1)
+    eng.close()
+
+
+def test_pinned_arena_is_a_cache_over_the_offload_directory(tmp_path):
+    """with host_memory_bytes set, a model larger than the pinned arena still runs — experts stay
+    on disk until their first miss, a full arena drops the least recently needed blob, and results do not change."""
+    from moe_infinity_amd.offload_store import OffloadStore
+
+    h, f, e, k, t = 256, 512, 8, 2, 6
+    gate, experts, _ = make_weights("mixtral", h, f, e, 1600, torch.bfloat16)
+    st = OffloadStore(str(tmp_path))
+    ids, tid = {}, 100
+    for i, ex in enumerate(experts):
+        ids[i] = []
+        for w in ex:
+            st.offload(w, tid)
+            ids[i].append(tid)
+            tid += 1
+    st.close()
+    st = OffloadStore(str(tmp_path))
+    blob = 3 * f * h * 2
+    eng = _mixtral_engine(1, e, h, f, k, 2, t, host_memory_bytes=3 * blob)  # arena: 3 of 8 experts; HBM: 2
+    for i in range(e):
+        st.register_expert(eng, 0, i, ids[i])
+    assert eng.stats()["host_arena_bytes"] <= 3 * blob
+    for step in range(6):
+        x = acts(t, h, torch.bfloat16, 1610 + step)
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        assert_block_close(out, R.block_mixtral(x[None], gate, experts, top_k=k), torch.bfloat16, f"step {step}, model larger than host arena")
+    s = eng.stats()
+    assert s["host_arena_bytes"] <= 3 * blob
+    assert s["disk_reads"] > 3 and s["host_evictions"] > 0 and s["disk_bytes"] == s["disk_reads"] * blob
+    eng.close()
+    st.close()
+
+
+def test_dense_mask_with_more_than_k_experts_per_token_is_rejected_without_overrun():
+    """the mask-index kernel bounds its writes by the workspace capacity; the host then reports
+    the overflow."""
+    from moe_infinity_amd import MoeInfError
+    from helpers import engine_for
+
+    h, f, e, k, t = 256, 512, 8, 2, 8
+    gate, experts, _ = make_weights("mixtral", h, f, e, 1700, torch.bfloat16)
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    x = acts(t, h, torch.bfloat16, 1701).to(DEV)
+    full = torch.ones(t, e, dtype=torch.bool, device=DEV)  # 8 experts per token, workspace holds t*k = 16 rows
+    with pytest.raises(MoeInfError, match="workspace"):
+        eng.dispatch_mask(0, x, full)
+    ok = torch.zeros(t, e, dtype=torch.bool, device=DEV)
+    ok[:, 1] = True
+    ok[:, 5] = True
+    y, counts, hit = eng.dispatch_mask(0, x, ok)  # the engine is still healthy
+    assert int(counts.sum()) == 2 * t and y.shape[0] == 2 * t
+    eng.close()
