@@ -44,36 +44,44 @@ def test_demand_misses_while_prefetches_are_in_flight_without_any_sync():
 
 
 def test_a_demand_miss_overtakes_queued_prefetches():
-    """8 speculative transfers are queued for LATER layers; a forward on layer 0 misses.  The miss
+    """8 speculative transfers are queued for a LATER layer; a forward on layer 0 misses.  The miss
     is served at once on the demand lane: when the forward has finished, most of the speculative queue is still
-    waiting (at most MOEINF_PREFETCH_WINDOW = 2 copies were allowed in flight ahead of it)."""
-    h, f, e, k, t, L = 2048, 4096, 8, 2, 2, 3  # 48 MiB blobs, ~1 ms each on the link
-    ws = [make_weights("mixtral", h, f, e, 1300 + l, torch.bfloat16) for l in range(L)]
-    eng = _mixtral_engine(L, e, h, f, k, 24, t)
-    for l in range(L):
-        register_all(eng, ws[l][1], layer=l)
+    waiting (at most MOEINF_PREFETCH_WINDOW = 2 copies were allowed in flight ahead of it).  Full-size Mixtral
+    experts (336 MiB, ~6 ms on the link each) so that host-call latencies cannot blur the order."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from helpers import fill_layer_on_gpu
+
+    L, t = 3, 2
+    cfg = Cf.mixtral_8x7b(max_tokens=t, device_memory_bytes=24 * 352321536)
+    cfg.num_layers = L
+    eng = MoEEngine(cfg)
+    e, k, h = cfg.num_experts, cfg.top_k, cfg.hidden
+    ws = [fill_layer_on_gpu(eng, "mixtral", l, 1300 + 100 * l)[0] for l in range(L)]
+    g = torch.Generator().manual_seed(1309)
+    gates = [(torch.randn(e, h, generator=g) * 0.02).to(torch.bfloat16) for _ in range(L)]
     eng.prefetch(1, list(range(e)))  # 8 requests for layer 1
     st0 = eng.stats()
     assert st0["prefetch_queued"] + st0["prefetch_issued"] == e and st0["prefetch_issued"] <= 2
     x = acts(t, h, torch.bfloat16, 1310)
-    out = eng.forward(0, x.to(DEV), ws[0][0].to(DEV))  # misses on layer 0
+    out = eng.forward(0, x.to(DEV), gates[0].to(DEV))  # misses on layer 0
     torch.cuda.synchronize()
     st1 = eng.stats()
     assert st1["expert_misses"] >= 2
     # the demand copies did not wait for the 8 speculative ones: most of them have not even been issued yet
     assert st1["prefetch_issued"] <= 4, st1
-    assert_block_close(out, R.block_mixtral(x[None], ws[0][0], ws[0][1], top_k=k), torch.bfloat16, "demand-missed layer")
+    assert_block_close(out, R.block_mixtral(x[None], gates[0], ws[0], top_k=k), torch.bfloat16, "demand-missed layer")
     eng.sync_copies()  # serves the rest of the queue
     st2 = eng.stats()
     assert st2["prefetch_queued"] == 0 and st2["prefetch_issued"] == e
     assert all(eng.is_resident(1, i) for i in range(e))
     # a queued request for an expert that is then DEMANDED is overtaken, not copied twice
-    eng.set_cache_budget(4 * 3 * f * h * 2)
+    eng.set_cache_budget(4 * st2["slot_bytes"])
     eng.prefetch(2, list(range(e)), scores=[0.9, 0.1, 0.8, 0.2, 0.7, 0.3, 0.6, 0.4])
     x2 = acts(t, h, torch.bfloat16, 1311)
     before = eng.stats()["h2d_bytes"]
-    out2 = eng.forward(2, x2.to(DEV), ws[2][0].to(DEV))
-    assert_block_close(out2, R.block_mixtral(x2[None], ws[2][0], ws[2][1], top_k=k), torch.bfloat16, "layer 2")
+    out2 = eng.forward(2, x2.to(DEV), gates[2].to(DEV))
+    assert_block_close(out2, R.block_mixtral(x2[None], gates[2], ws[2], top_k=k), torch.bfloat16, "layer 2")
     eng.sync_copies()
     st3 = eng.stats()
     assert st3["prefetch_queued"] == 0
