@@ -582,3 +582,26 @@ def test_ep_two_ranks_variable_split_emulated_on_one_gpu():
         assert_block_close(out, ref, torch.bfloat16, f"variable-split EP rank {r} output")
     for eng in engs:
         eng.close()
+
+
+@pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch")
+                                        for d, t in ((torch.bfloat16, "bf16"), (torch.float32, "f32"))])
+def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
+    """R6 pinned to real reference code: tests/golden/ffn_ref_*.npz hold y = <module>.forward(x) computed by the
+    reference's core/parallel/expert_module.cpp (oracle/_ref, oracle/gen_golden_ref.py).  The HIP grouped FFN
+    (through expert_dispatcher's mask dispatch) must match within one ulp per rounding point."""
+    z = load_golden(f"ffn_ref_{fam}_{tag}.npz")
+    h, f, e, seed = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights(fam, h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch") else {}))
+    np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
+    eng = engine_for(fam, h, f, e, 1 if fam == "switch" else 2, dt, max_tokens=64)
+    register_all(eng, experts)
+    for i in range(3):
+        x = tt(z[f"x{i}"], dt)
+        mask = torch.zeros(x.shape[0], e, dtype=torch.bool)
+        mask[:, i] = True
+        y, counts, _ = eng.dispatch_mask(0, x.to(DEV), mask.to(DEV))
+        assert int(counts[i]) == x.shape[0] and int(counts.sum()) == x.shape[0]
+        assert_model_close(y, tt(z[f"y{i}"], torch.float32), dt, f"{fam} {tag} case {i} vs the reference module",
+                           ulps=2.0 if fam == "nllb" else 1.0)
+    eng.close()
