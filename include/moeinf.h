@@ -225,6 +225,9 @@ int moeinf_sync_copies(moeinf_engine* eng);
 /* DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink (evicting by
  * the replacement policy, freeing the slots' memory) or grow the expert cache.  Synchronises the device. */
 int moeinf_set_cache_budget(moeinf_engine* eng, int64_t device_memory_bytes);
+/* Grow the token-sized workspace to hold forwards of up to max_tokens tokens (the reference's dispatcher allocates per
+ * call and has no such limit; expert_dispatcher.set_inputs grows it on demand).  Only grows; synchronises the device. */
+int moeinf_reserve_tokens(moeinf_engine* eng, int max_tokens);
 
 /* prefetch_handle.get_hit_rate() (archer_prefetch_handle.cpp:281-297): per-expert counters,
  * out[L*E][6] = {visit_cnt, hit_cnt, miss_cnt, prefetch_cnt, incache_visit_count, resident} */
@@ -294,6 +297,12 @@ int moeinf_store_meta(const moeinf_store* st, uint32_t tensor_id, int32_t* found
 /* ReadTensor (archer_tensor_handle.cpp:189-201): payload -> dst (O_DIRECT when dst is 4 KiB-aligned and
  * has room for the 4 KiB-padded size) */
 int moeinf_store_get(const moeinf_store* st, uint32_t tensor_id, void* dst, uint64_t capacity);
+/* DENSE (non-expert) tensors: disk -> device in one call — the data movement behind prefetch_handle.begin /
+ * fetch_tensors / set_topology for dense nodes (AcquireTensor, FetchTensors, InitializeTopology:
+ * archer_prefetch_handle.cpp:83-130,220-227, model_topology.cpp:402-548; Node::SetDevice :76-119).  The payload of
+ * `tensor_id` is read in pinned pieces and copied with hipMemcpyAsync on `stream` into dst_dev (caller-owned device
+ * memory, e.g. a slice of the node's slab).  Device data is stream-ordered after the call. */
+int moeinf_store_get_device(moeinf_store* st, uint32_t tensor_id, void* dst_dev, uint64_t capacity, void* stream);
 /* Node::SetDevice disk->host leg (model_topology.cpp:76-100, SetModuleMemoryFromDisk :647-674):
  * read the n tensors of one expert (tensor_ids in blob order, as expert_dispatcher.register_expert
  * receives them) from the store straight into the expert's pinned arena blob. */

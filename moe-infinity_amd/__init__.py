@@ -9,5 +9,6 @@ from ._lib import MoeInfError, lib_path, load_library  # noqa: F401
 from .config import ArcherConfig, EngineConfig  # noqa: F401
 from .engine import CacheSim, ExpertTracerNative, MoEEngine  # noqa: F401
 from .prefetch_handle import PrefetchHandle  # noqa: F401
+from . import prefetch_op  # noqa: F401  (drop-in for the reference's pybind module)
 
 __version__ = "0.1.0"

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "moeinf_is_resident": (C.c_int, [_P, C.c_int, C.c_int, _I32P]),
     "moeinf_sync_copies": (C.c_int, [_P]),
     "moeinf_set_cache_budget": (C.c_int, [_P, C.c_int64]),
+    "moeinf_reserve_tokens": (C.c_int, [_P, C.c_int]),
     "moeinf_get_expert_counters": (C.c_int, [_P, _I64P, C.c_int64]),
     "moeinf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "moeinf_reset_stats": (C.c_int, [_P]),
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "moeinf_store_ids": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int64]),
     "moeinf_store_meta": (C.c_int, [_P, C.c_uint32, _I32P, C.POINTER(C.c_uint64), _I64P, _I32P, _I64P, _I32P]),
     "moeinf_store_get": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64]),
+    "moeinf_store_get_device": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P]),
     "moeinf_register_expert_from_store": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_uint32), C.c_int]),
     "moeinf_cache_sim_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "moeinf_cache_sim_destroy": (C.c_int, [_P]),

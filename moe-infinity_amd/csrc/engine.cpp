@@ -325,6 +325,24 @@ static int dmalloc(T** p, size_t n) {
   return MOEINF_OK;
 }
 
+// the part of the device workspace that is sized by max_tokens (re-allocated by moeinf_reserve_tokens)
+static void free_token_workspace(moeinf_engine* g) {
+  void** bufs[] = {(void**)&g->d_logits, (void**)&g->d_topk_idx, (void**)&g->d_pair_valid, (void**)&g->d_pair_order, (void**)&g->d_pair_slot,
+                   (void**)&g->d_topk_w, (void**)&g->d_router_prob, (void**)&g->d_slot_token, (void**)&g->d_slot_pair, &g->d_h, &g->d_y};
+  for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+}
+static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
+  const size_t T = (size_t)max_tokens, K = (size_t)g->K;
+  const size_t rows = T * K + (g->has_shared ? T : 0);
+  CHK(dmalloc(&g->d_logits, T * g->E));
+  CHK(dmalloc(&g->d_topk_idx, T * K)); CHK(dmalloc(&g->d_pair_valid, T * K)); CHK(dmalloc(&g->d_pair_order, T * K));
+  CHK(dmalloc(&g->d_pair_slot, T * K)); CHK(dmalloc(&g->d_topk_w, T * K)); CHK(dmalloc(&g->d_router_prob, T));
+  CHK(dmalloc(&g->d_slot_token, rows)); CHK(dmalloc(&g->d_slot_pair, rows));
+  HIPCHK(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
+  HIPCHK(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
   hipSetDevice(g->cfg.device_id);
@@ -335,9 +353,9 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& n : g->nodes) { if (n.ready) hipEventDestroy(n.ready); if (n.ready1) hipEventDestroy(n.ready1); }
   for (auto e : g->event_pool) hipEventDestroy(e);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-  void* bufs[] = {g->d_wptr, g->d_logits, g->d_topk_idx, g->d_pair_valid, g->d_pair_order, g->d_pair_slot, g->d_topk_w,
-                  g->d_router_prob, g->d_counts, g->d_offsets, g->d_active, g->d_n_active, g->d_slot_token, g->d_slot_pair,
-                  g->d_arrive, g->d_miss, g->d_h, g->d_y, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+  free_token_workspace(g);
+  void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
+                  g->d_arrive, g->d_miss, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -412,23 +430,17 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipEventCreateWithFlags(&g->route_ev, hipEventDisableTiming));
   for (int i = 0; i < kFenceRing; ++i) TRYHIP(hipEventCreateWithFlags(&g->fence_ev[i], hipEventDisableTiming));
 
-  const size_t T = (size_t)cfg->max_tokens, K = (size_t)g->K, E1 = (size_t)g->E + 1;
-  const size_t rows = T * K + (g->has_shared ? T : 0);
+  const size_t E1 = (size_t)g->E + 1;
   g->ldh = std::max(g->F, g->Fs);
   TRY(dmalloc(&g->d_wptr, (size_t)g->L * E1));
   TRYHIP(hipMemset(g->d_wptr, 0, (size_t)g->L * E1 * sizeof(uint64_t)));
-  TRY(dmalloc(&g->d_logits, T * g->E));
-  TRY(dmalloc(&g->d_topk_idx, T * K)); TRY(dmalloc(&g->d_pair_valid, T * K)); TRY(dmalloc(&g->d_pair_order, T * K));
-  TRY(dmalloc(&g->d_pair_slot, T * K)); TRY(dmalloc(&g->d_topk_w, T * K)); TRY(dmalloc(&g->d_router_prob, T));
   TRY(dmalloc(&g->d_counts, E1)); TRY(dmalloc(&g->d_offsets, E1 + 1)); TRY(dmalloc(&g->d_active, E1)); TRY(dmalloc(&g->d_n_active, 1));
-  TRY(dmalloc(&g->d_slot_token, rows)); TRY(dmalloc(&g->d_slot_pair, rows));
   TRY(dmalloc(&g->d_arrive, (g->H + 15) / 16)); TRY(dmalloc(&g->d_miss, 1));
   TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_active, 0, (size_t)E1 * sizeof(int32_t)));  // the FFN kernels read active[u] before they know n_active
   TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
-  TRYHIP(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
-  TRYHIP(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
+  TRY(alloc_token_workspace(g, cfg->max_tokens));
   for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i], kAioAlignment)));
   for (CopyLane* ln : {&g->demand, &g->prefetch}) {
     for (auto& b : ln->ring) {
@@ -1424,8 +1436,35 @@ extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_b
   return MOEINF_OK;
 }
 
+// Grow the token-sized workspace (the reference's dispatcher has no such limit: it allocates per call).  Only grows;
+// synchronises the device.
+extern "C" int moeinf_reserve_tokens(moeinf_engine* g, int max_tokens) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (max_tokens <= g->cfg.max_tokens) return MOEINF_OK;
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  drain_mirrors(g, true);
+  HIPCHK(hipDeviceSynchronize());
+  free_token_workspace(g);
+  const int rc = alloc_token_workspace(g, max_tokens);
+  if (rc != MOEINF_OK) {  // fall back to the old size so the engine stays usable
+    free_token_workspace(g);
+    const std::string keep = g_err;
+    if (alloc_token_workspace(g, g->cfg.max_tokens) != MOEINF_OK) return fail(MOEINF_ERR_OOM, "workspace lost: %s", keep.c_str());
+    g_err = keep;
+    return rc;
+  }
+  g->cfg.max_tokens = max_tokens;
+  g->last_layer = -1;  // routing results of the previous forward lived in the old buffers
+  return MOEINF_OK;
+}
+
 // ---- disk tier -------------------------------------------------------------------------------
-struct moeinf_store { OffloadStore s; };
+struct moeinf_store {
+  OffloadStore s;
+  void* bounce[2] = {nullptr, nullptr};  // pinned pieces of moeinf_store_get_device
+  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+  bool bounce_used[2] = {false, false};
+};
 extern "C" int moeinf_store_open(const char* path, moeinf_store** out) {
   if (!path || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
   moeinf_store* st = new moeinf_store();
@@ -1438,6 +1477,7 @@ extern "C" int moeinf_store_close(moeinf_store* st) {
   if (!st) return MOEINF_OK;
   int rc = MOEINF_OK;
   if (st->s.dirty()) { const std::string err = st->s.flush(); if (!err.empty()) rc = fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
+  for (int i = 0; i < 2; ++i) { if (st->bounce[i]) hipHostFree(st->bounce[i]); if (st->bounce_ev[i]) hipEventDestroy(st->bounce_ev[i]); }
   delete st;
   return rc;
 }
@@ -1480,6 +1520,38 @@ extern "C" int moeinf_store_get(const moeinf_store* st, uint32_t id, void* dst, 
   const std::string err = st->s.get(id, dst, capacity);
   return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
 }
+// disk -> device for a DENSE tensor (Node::SetDevice's disk->host->device legs for non-expert nodes,
+// model_topology.cpp:76-119; AcquireTensor / FetchTensors, archer_prefetch_handle.cpp:83-130,220-227): the payload is
+// read in 32 MiB pieces into two pinned bounce buffers and copied with hipMemcpyAsync on `stream`, the read of piece
+// i+1 overlapping the copy of piece i.  Returns when the last copy has been ENQUEUED and the bounce buffers are free
+// again (the device data is stream-ordered after the call).
+extern "C" int moeinf_store_get_device(moeinf_store* st, uint32_t id, void* dst_dev, uint64_t capacity, void* stream) {
+  if (!st || !dst_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const TensorMeta* m = st->s.find(id);
+  if (!m) return fail(MOEINF_ERR_INVALID, "tensor %u is not in the offload index", id);
+  if (m->size > capacity) return fail(MOEINF_ERR_INVALID, "tensor %u is %llu bytes, destination holds %llu", id, (unsigned long long)m->size, (unsigned long long)capacity);
+  constexpr uint64_t kPiece = 32ull << 20;
+  if (!st->bounce[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipHostMalloc(&st->bounce[i], kPiece, hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&st->bounce_ev[i], hipEventDisableTiming));
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int b = 0;
+  for (uint64_t off = 0; off < m->size; off += kPiece, b ^= 1) {
+    const uint64_t n = std::min<uint64_t>(kPiece, m->size - off);
+    if (st->bounce_used[b]) HIPCHK(hipEventSynchronize(st->bounce_ev[b]));
+    const std::string err = st->s.get_range(id, off, st->bounce[b], n);
+    if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+    HIPCHK(hipMemcpyAsync((char*)dst_dev + off, st->bounce[b], n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(st->bounce_ev[b], s));
+    st->bounce_used[b] = true;
+  }
+  for (int i = 0; i < 2; ++i) if (st->bounce_used[i]) HIPCHK(hipEventSynchronize(st->bounce_ev[i]));
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, int expert, const moeinf_store* st, const uint32_t* tensor_ids, int n) {
   CHK(check_le(g, layer, expert));
   if (!st || !tensor_ids) return fail(MOEINF_ERR_INVALID, "NULL argument");

@@ -206,6 +206,24 @@ class OffloadStore {
     return "";
   }
 
+  // bytes [off, off+n) of a tensor's payload -> dst (buffered pread; used for piecewise disk -> device transfers)
+  std::string get_range(uint32_t id, uint64_t off, void* dst, uint64_t n) const {
+    const TensorMeta* m = find(id);
+    if (!m) return "tensor " + std::to_string(id) + " not in archer_index";
+    if (off + n > m->size) return "range beyond the end of tensor " + std::to_string(id);
+    const std::string fn = param_path(m->file_id);
+    const int fd = ::open(fn.c_str(), O_RDONLY);
+    if (fd < 0) return "open " + fn + ": " + strerror(errno);
+    uint64_t done = 0;
+    while (done < n) {
+      const ssize_t r = pread(fd, static_cast<char*>(dst) + done, n - done, m->offset + (int64_t)(off + done));
+      if (r <= 0) { const std::string e = r < 0 ? strerror(errno) : "unexpected end of file"; ::close(fd); return "pread " + fn + ": " + e; }
+      done += (uint64_t)r;
+    }
+    ::close(fd);
+    return "";
+  }
+
   const std::string& prefix() const { return prefix_; }
   bool dirty() const { return dirty_; }
 

@@ -230,6 +230,11 @@ class MoEEngine:
     def sync_copies(self):
         check(self.lib.moeinf_sync_copies(self._h))
 
+    def reserve_tokens(self, max_tokens: int):
+        """grow the workspace so that forwards of up to max_tokens tokens fit"""
+        check(self.lib.moeinf_reserve_tokens(self._h, int(max_tokens)))
+        self.cfg.max_tokens = max(self.cfg.max_tokens, int(max_tokens))
+
     def set_cache_budget(self, device_memory_bytes: int):
         """SetMemoryRatio at run time, in bytes (shrinking evicts by policy and frees the slots)."""
         check(self.lib.moeinf_set_cache_budget(self._h, int(device_memory_bytes)))

@@ -74,6 +74,14 @@ class OffloadStore:
         check(self.lib.moeinf_store_get(self._h, tensor_id, C.c_void_p(t.data_ptr()), m["nbytes"]))
         return t
 
+    def load_to_device(self, tensor_id: int, dst: torch.Tensor):
+        """disk -> device for a dense tensor: dst is a contiguous CUDA tensor (any dtype) with room for the payload;
+        the copy is ordered on the current stream."""
+        if not dst.is_cuda or not dst.is_contiguous():
+            raise ValueError("dst must be a contiguous CUDA tensor")
+        stream = C.c_void_p(torch.cuda.current_stream(dst.device).cuda_stream)
+        check(self.lib.moeinf_store_get_device(self._h, tensor_id, C.c_void_p(dst.data_ptr()), dst.numel() * dst.element_size(), stream))
+
     def register_expert(self, engine, layer: int, expert: int, tensor_ids: Sequence[int]):
         """disk -> pinned host arena for one expert (tensor ids in the reference's blob order)."""
         a = (C.c_uint32 * len(tensor_ids))(*tensor_ids)

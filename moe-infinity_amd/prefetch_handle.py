@@ -10,9 +10,10 @@ reference's ``ExpertPrefetcher`` can drive the engine **unmodified**:
     prefetcher.set_archer_engine(PrefetchHandle(engine, expert_tensor_map))
     prefetcher.expert_tensor_map = expert_tensor_map
 
-Methods of ``prefetch_handle`` that belong to the loader / dense-layer side of the boundary (``offload``,
-``register``, ``begin``/``end``, ``set_topology``, ``update_tensor_map``, ``fetch_tensors`` ...) are
-not part of this path and raise ``NotImplementedError`` naming the row.
+This adapter covers the expert-cache methods only (an engine that was built directly from tensors has no offload
+directory or topology).  The FULL pybind surface — ``prefetch_handle(prefix, device_memory_ratio)`` with ``offload``,
+``register``, ``begin``/``end``, ``set_topology``, ``update_tensor_map``, ``fetch_tensors`` ... and
+``expert_dispatcher(num_experts, num_layers, dtype, expert_type, num_threads)`` — is ``moe_infinity_amd.prefetch_op``.
 """
 from typing import Dict, Iterable, List, Sequence, Tuple
 
@@ -102,21 +103,6 @@ class PrefetchHandle:
 
     def clean_up_resources(self):
         self.engine.close()
-
-    # -- the other side of the boundary: not on this path
-    def _next_row(self, name):
-        raise NotImplementedError(f"prefetch_handle.{name} belongs to the loader / dense-layer residency side "
-                                  "(SURVEY.md section 8f-2), which this engine does not replace")
-
-    def offload(self, *a, **k): self._next_row("offload")
-    def register(self, *a, **k): self._next_row("register")
-    def set_tensor_device(self, *a, **k): self._next_row("set_tensor_device")
-    def begin(self, *a, **k): self._next_row("begin")
-    def end(self, *a, **k): self._next_row("end")
-    def set_topology(self, *a, **k): self._next_row("set_topology")
-    def set_trace(self, *a, **k): self._next_row("set_trace")
-    def update_tensor_map(self, *a, **k): self._next_row("update_tensor_map")
-    def fetch_tensors(self, *a, **k): self._next_row("fetch_tensors")
 
     def prefetch_tensors(self, request_id, tensor_ids):
         """A no-op in the reference too (archer_prefetch_handle.cpp:182-193)."""
