@@ -125,6 +125,7 @@ struct Node {
   hipEvent_t ready = nullptr;  // recorded once the whole expert is in the slot
   bool waited1 = true;         // compute stream already ordered after `ready1`
   bool ready_waited = true;    // compute stream already ordered after `ready`
+  bool copy_inflight = false;  // an H2D transfer out of `host` was issued and has not been OBSERVED complete yet
   bool prefetched = false;     // resident because of a prefetch, not yet dispatched
   int64_t visit = 0, hit = 0, miss = 0, prefetch_cnt = 0;
   // disk tier (register_expert_from_store): where the host blob can be re-read from when the arena evicted it
@@ -139,6 +140,7 @@ struct Slot {
 };
 
 static constexpr int kFenceRing = 64;
+static constexpr int kHideSharedMaxTokens = 16;  // forwards up to this many tokens hide the shared expert under the router
 
 // One H2D lane = a copy stream (hipMemcpyAsync, served by an SDMA engine) + a re-tile stream (kernels) + a ring of two
 // staging buffers, each large enough for the biggest tensor of a blob.  Tensor i+1 is copied into the other
@@ -206,6 +208,7 @@ struct moeinf_engine {
   int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_miss = nullptr;
   int32_t* d_arrive = nullptr;  // [ceil(H/16)] zeroed arrival counters of the fused combine's column tiles
   void *d_h = nullptr, *d_y = nullptr;
+  void *d_h_sh = nullptr, *d_y_sh = nullptr;  // decode-sized DeepSeek: shared expert's h / y (its FFN rides with the router)
   int64_t ldh = 0;
   int32_t* h_mirror = nullptr;  // pinned, written by the index kernels themselves: {n_active, counts[E+1], active[E+1]}
   int32_t* h_miss = nullptr;
@@ -232,6 +235,7 @@ struct moeinf_engine {
   const int32_t* ovr_map = nullptr;
 
   // last forward
+  bool last_hidden_shared = false;
   int last_T = 0, last_layer = -1;
   hipStream_t last_stream = nullptr;
   int last_rows = 0;
@@ -355,7 +359,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_miss, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_miss, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -441,6 +445,10 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMemset(g->d_active, 0, (size_t)E1 * sizeof(int32_t)));  // the FFN kernels read active[u] before they know n_active
   TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
   TRY(alloc_token_workspace(g, cfg->max_tokens));
+  if (g->has_shared) {
+    TRYHIP(hipMalloc(&g->d_h_sh, (size_t)kHideSharedMaxTokens * g->Fs * g->es));
+    TRYHIP(hipMalloc(&g->d_y_sh, (size_t)kHideSharedMaxTokens * g->H * g->es));
+  }
   for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i], kAioAlignment)));
   for (CopyLane* ln : {&g->demand, &g->prefetch}) {
     for (auto& b : ln->ring) {
@@ -667,6 +675,7 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   n.slot = slot;
   n.ready_waited = false;
   n.waited1 = false;
+  n.copy_inflight = true;
   n.host_clock = ++g->host_clock;
   s.node = idx;
   g->pol[idx].resident = true;
@@ -730,7 +739,10 @@ static int ensure_host(moeinf_engine* g, int idx) {
     for (int i = 0; i < (int)g->nodes.size(); ++i) {
       Node& v = g->nodes[i];
       if (i == idx || !v.host || !v.store) continue;
-      if (v.slot >= 0 && !v.ready_waited && v.ready && hipEventQuery(v.ready) != hipSuccess) { (void)hipGetLastError(); continue; }  // its H2D copy still reads the blob
+      if (v.copy_inflight) {  // its H2D copy may still be reading the blob (ready_waited only says the compute stream is ORDERED after it)
+        if (hipEventQuery(v.ready) != hipSuccess) { (void)hipGetLastError(); continue; }
+        v.copy_inflight = false;
+      }
       if (victim < 0 || v.host_clock < g->nodes[victim].host_clock) victim = i;
     }
     if (victim < 0) return fail(MOEINF_ERR_OOM, "pinned host arena cap (%lld bytes) reached and no host blob can be dropped", (long long)g->cfg.host_memory_bytes);
@@ -797,12 +809,16 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   const int E = g->E, K = g->K;
   int64_t U = 0, rows = 0;
   for (int e = 0; e < E; ++e) { if (mirror[1 + e] > 0) { ++U; rows += mirror[1 + e]; } }
-  const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = (g->has_shared && local) ? T : 0;
+  const bool hidden = g->has_shared && local && g->last_hidden_shared;  // the shared expert ran inside the router launches
+  const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = (g->has_shared && local && !hidden) ? T : 0;
+  if (hidden) g->prof.route_bytes += 3 * Fs * H * es + (int64_t)T * (2 * Fs + 2 * H) * es;
   const int et = g->cfg.expert_type;
   const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
   const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
-  g->prof.ffn1_bytes += U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
-  g->prof.ffn2_bytes += U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
+  const int64_t b1 = U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
+  const int64_t b2 = U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;
+  g->prof.ffn1_bytes += b1;
+  g->prof.ffn2_bytes += b2;
   if (local) {
     g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
     g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
@@ -1089,12 +1105,29 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   ia.shared = g->has_shared ? 1 : 0;
   ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
-  HIPCHK(launch_gate_logits(ra, st));
-  if (T <= 64) {
-    HIPCHK(launch_route_index(ra, ia, st));  // decode: top-k + dispatch index in one launch
+  // decode-sized DeepSeek forwards: the shared expert (routing-independent, always resident) runs INSIDE the two router
+  // launches instead of behind them
+  static const bool hide_env = getenv("MOEINF_HIDE_SHARED") ? atoi(getenv("MOEINF_HIDE_SHARED")) != 0 : true;
+  const bool hide_shared = hide_env && g->has_shared && !route_only && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * K <= 64 &&
+                           g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
+  g->last_hidden_shared = hide_shared;
+  if (hide_shared) {
+    FfnStage sh1, sh2;
+    fill_stage(g, layer, 1, sh1);
+    sh1.in = x_dev; sh1.row_map = nullptr; sh1.out = g->d_h_sh; sh1.ld_out = g->Fs;
+    fill_stage(g, layer, 2, sh2);
+    sh2.in = g->d_h_sh; sh2.ld_in = g->Fs; sh2.out = g->d_y_sh; sh2.out_map = nullptr;
+    ia.shared = 0;  // the index lists routed experts only
+    HIPCHK(launch_gate_shared1(ra, sh1, st));
+    HIPCHK(launch_route_shared2(ra, ia, sh2, st));
   } else {
-    HIPCHK(launch_route_topk(ra, st));
-    HIPCHK(launch_dispatch_index(ia, st));
+    HIPCHK(launch_gate_logits(ra, st));
+    if (T <= 64) {
+      HIPCHK(launch_route_index(ra, ia, st));  // decode: top-k + dispatch index in one launch
+    } else {
+      HIPCHK(launch_route_topk(ra, st));
+      HIPCHK(launch_dispatch_index(ia, st));
+    }
   }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
@@ -1107,8 +1140,8 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   ca.x = x_dev; ca.y = g->d_y; ca.out = out_dev;
   ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
   ca.router_prob = g->d_router_prob;
-  ca.y_shared = g->has_shared ? g->d_y : nullptr;
-  ca.shared_offsets = g->has_shared ? g->d_offsets : nullptr;  // shared rows start at offsets[E]
+  ca.y_shared = g->has_shared ? (hide_shared ? g->d_y_sh : g->d_y) : nullptr;
+  ca.shared_offsets = (g->has_shared && !hide_shared) ? g->d_offsets : nullptr;  // shared rows start at offsets[E] (hidden: row 0 of y_shared)
   ca.shared_E = E;
   ca.T = T; ca.H = g->H; ca.K = K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
   // decode-sized Mixtral/DeepSeek forwards (every token keeps K experts, so stage 2 always runs): the combine
@@ -1117,7 +1150,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool can_fuse = fuse_combine && want_combine && T <= 16 &&
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK);
   bool fused = false;
-  CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + (g->has_shared ? 1 : 0),
+  CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused));
   if (want_combine && !fused) HIPCHK(launch_combine(ca, st));
@@ -1236,6 +1269,15 @@ extern "C" int moeinf_get_expert_outputs(moeinf_engine* g, void* host_out, int64
   const int64_t rows = (int64_t)g->last_T * g->K + (g->has_shared ? g->last_T : 0);
   const int64_t need = rows * g->H * g->es;
   if (!host_out || nbytes > need || nbytes <= 0) return fail(MOEINF_ERR_INVALID, "nbytes must be in 1..%lld", (long long)need);
+  if (g->has_shared && g->last_hidden_shared) {
+    // routed rows sit in y, the shared expert's rows (computed inside the router launches) in their own buffer
+    int32_t routed = 0;
+    HIPCHK(hipMemcpy(&routed, g->d_offsets + g->E, sizeof routed, hipMemcpyDeviceToHost));
+    const int64_t rb = std::min<int64_t>(nbytes, (int64_t)routed * g->H * g->es);
+    if (rb > 0) HIPCHK(hipMemcpy(host_out, g->d_y, (size_t)rb, hipMemcpyDeviceToHost));
+    if (nbytes > rb) HIPCHK(hipMemcpy((char*)host_out + rb, g->d_y_sh, (size_t)std::min<int64_t>(nbytes - rb, (int64_t)g->last_T * g->H * g->es), hipMemcpyDeviceToHost));
+    return MOEINF_OK;
+  }
   HIPCHK(hipMemcpy(host_out, g->d_y, (size_t)nbytes, hipMemcpyDeviceToHost));
   return MOEINF_OK;
 }

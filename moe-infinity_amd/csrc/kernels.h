@@ -113,6 +113,13 @@ hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
 hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st);
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
+// Decode-sized DeepSeek forwards (bf16, T*K <= 64): the shared expert's FFN rides along with the router.
+//   gate_shared1: gate logits + stage 1 of the shared expert (s = its stage-1 descriptor: in = x, row_map = nullptr,
+//                 out = h_shared [T, R_sh]);
+//   route_shared2: top-k + dispatch index (a.shared must be 0) + stage 2 of the shared expert (s: in = h_shared,
+//                 out = y_shared [T, R_sh == H]).
+hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_t st);
+hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
 // out[i] = valid[i] ? idx[i] : -1

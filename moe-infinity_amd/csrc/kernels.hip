@@ -177,51 +177,47 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u
 // (ceil(H/(256*4)), T)) and by the fused epilogue of the decode-sized FFN stage 2.
 // ------------------------------------------------------------------------------------------------
 // columns [h0, h0+4) of token t; H % 4 == 0 (moeinf_create checks), rows 8/16-byte aligned
+struct CombineMeta {  // a token's combine order resolved to row slots and weights
+  int slot[8];
+  float w[8];
+};
+__device__ __forceinline__ void combine_meta(const CombineArgs& a, const int t, CombineMeta& m) {
+  // two dependent rounds (order -> slot/weight), each issued back to back: entries kk >= K repeat entry K-1 (ignored
+  // by the caller) so the rounds stay branch-free
+  const int K = a.K;
+  const size_t p0 = (size_t)t * K;
+  int ko[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ko[kk] = a.pair_order[p0 + min(kk, K - 1)];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    m.slot[kk] = a.pair_slot[p0 + ko[kk]];
+    m.w[kk] = a.topk_w[p0 + ko[kk]];
+  }
+}
 template <typename T, bool COH = false>  // COH: y / y_shared were written by other workgroups of THIS launch
-__device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, const int h0) {
+__device__ __forceinline__ void combine_apply(const CombineArgs& a, const int t, const int h0, const CombineMeta& m) {
   const int K = a.K;
   const T* y = reinterpret_cast<const T*>(a.y);
   T* out = reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.kind == 2 /*SWITCH*/) {
-    const int slot = a.pair_slot[t];
-    const T* src = (slot >= 0) ? y + (size_t)slot * a.H : reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
-    const float pr = a.router_prob[t];
-    float v[4];
-    DT<T>::load4(src + h0, v);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = DT<T>::round(pr * v[j]);
-    DT<T>::store4(out, acc);
-    return;
-  }
-  // Three dependent rounds of loads (order -> slot/weight -> rows), each round issued back to back: entries
-  // kk >= K repeat entry K-1 and absent slots fetch row 0 (both ignored below) so the rounds stay branch-free.
-  int ko[8], slot[8];
-  float w[8];
-  const size_t p0 = (size_t)t * K;
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) ko[kk] = a.pair_order[p0 + min(kk, K - 1)];
   const bool has_sh = (a.kind == 1 && a.y_shared);
   const int row0 = (has_sh && a.shared_offsets) ? a.shared_offsets[a.shared_E] : 0;
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    slot[kk] = a.pair_slot[p0 + ko[kk]];
-    w[kk] = a.topk_w[p0 + ko[kk]];
-  }
   typename DT<T>::Raw4 rsh, ry[8];
+  // absent slots fetch row 0 (ignored below) so the round stays branch-free
   rsh = DT<T>::template fetch4<COH>(reinterpret_cast<const T*>(has_sh ? a.y_shared : a.y) + (size_t)(row0 + (has_sh ? t : 0)) * a.H + h0);
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) ry[kk] = DT<T>::template fetch4<COH>(y + (size_t)max(slot[kk], 0) * a.H + h0);
+  for (int kk = 0; kk < 8; ++kk) ry[kk] = DT<T>::template fetch4<COH>(y + (size_t)max(m.slot[kk], 0) * a.H + h0);
   float sh[4] = {0.f, 0.f, 0.f, 0.f};
   if (has_sh) DT<T>::unpack4(rsh, sh);
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
-    if (kk < K && slot[kk] >= 0) {
+    if (kk < K && m.slot[kk] >= 0) {
       float yv[4];
       DT<T>::unpack4(ry[kk], yv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float prod = yv[j] * w[kk];
+        float prod = yv[j] * m.w[kk];
         // Mixtral/NLLB multiply in the model dtype (weights were cast to it); DeepSeek keeps the
         // product in fp32 (fp32 gate weights promote the bf16 expert output)
         if (a.kind != 1) prod = DT<T>::round(prod);
@@ -242,40 +238,45 @@ __device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, 
   }
   DT<T>::store4(out, acc);
 }
+template <typename T, bool COH = false>
+__device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, const int h0) {
+  if (a.kind == 2 /*SWITCH*/) {
+    const T* y = reinterpret_cast<const T*>(a.y);
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)t * a.H + h0;
+    const int slot = a.pair_slot[t];
+    const T* src = (slot >= 0) ? y + (size_t)slot * a.H : reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
+    const float pr = a.router_prob[t];
+    float v[4], acc[4];
+    DT<T>::load4(src + h0, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = DT<T>::round(pr * v[j]);
+    DT<T>::store4(out, acc);
+    return;
+  }
+  CombineMeta m;
+  combine_meta(a, t, m);
+  combine_apply<T, COH>(a, t, h0, m);
+}
 
+// One work item of ffn_rows: 16 output rows [16*bx, 16*bx+16) of one expert (blob W, rows off..off+cnt of the
+// expert-sorted activations).  Shared by ffn_rows_kernel and by the router kernels that carry the always-resident
+// shared expert's FFN along (gate_shared1_kernel / route_shared2_kernel).
 template <typename T, int NMAT, int NW, int U, int NT>
-__global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
+__device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, const char* W, const bool sh, const int cnt, const int off,
+                                              float (*red)[NMAT][256]) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
-  __shared__ float red[NW][NMAT][256];
-
-  // Prologue loads in two dependent rounds instead of three: active[u] is fetched together with n_active (entries
-  // past n_active hold stale but valid expert ids — the array is zero-initialised and only ever written with ids).
-  const int u = blockIdx.y;
-  const int e = s.active[u];
-  const int nact_dev = *s.n_active;
-  asm volatile("" ::"s"(e), "s"(nact_dev));  // keep both loads ahead of the exit branch (the compiler would sink active[u] below it)
-  const int nact = s.n_active_host >= 0 ? s.n_active_host : nact_dev;
-  if (u >= nact) return;
-  const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
-  const int r0 = blockIdx.x * 16;
-  if (r0 >= R) return;
-  const int off = s.offsets[e];
-  const int cnt_e = s.counts[e];  // loaded alongside wptr[e], not after it: one dependent round trip less per block
-  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
-  // an absent expert (never on the sync-free path) computes nothing but still reports its arrival below
-  if (W == nullptr && threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
-  const int cnt = W ? cnt_e : 0;
+  const int r0 = bx * 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int KB = (K + EPT - 1) / EPT;  // tiles per row group (last one zero-padded)
   const int KBfull = K / EPT;
-  const char* a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)blockIdx.x * KB * 1024 + lane * 16;
-  const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)blockIdx.x * KB * 1024 + lane * 16 : nullptr;
+  const char* a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)bx * KB * 1024 + lane * 16;
+  const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)bx * KB * 1024 + lane * 16 : nullptr;
   const int kq = q * EPV;  // this lane's k offset inside a tile
 
   // NT token tiles (16 tokens each) share one pass over the weights: experts with many tokens
@@ -292,38 +293,32 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
       acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    int kb = wave;
-    for (; kb + (U - 1) * NW < KBfull; kb += U * NW) {
+    // k-tiles wave, wave+NW, ... in batches of U: every load of a batch is issued before its first MFMA; the last,
+    // shorter batch is predicated (wave-uniform), not peeled into one-tile round trips (DeepSeek stage 2, 11 tiles per
+    // wave: 3 round trips instead of 5, 13.7 -> 11.8 us per launch; issuing the first weight batch ahead of the
+    // row_map round was measured too and bought nothing)
+    for (int kb = wave; kb < KBfull; kb += U * NW) {
       u32x4 av[U], bv[U], xv[U][NT];
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        av[i] = ld16_nt(a0 + (size_t)(kb + i * NW) * 1024);
-        if (NMAT == 2) bv[i] = ld16_nt(a1 + (size_t)(kb + i * NW) * 1024);
+        if (kb + i * NW < KBfull) {
+          av[i] = ld16_nt(a0 + (size_t)(kb + i * NW) * 1024);
+          if (NMAT == 2) bv[i] = ld16_nt(a1 + (size_t)(kb + i * NW) * 1024);
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          if (tt < ntl) xv[i][tt] = ld16(xr[tt] + (size_t)(kb + i * NW) * EPT);
+          for (int tt = 0; tt < NT; ++tt)
+            if (tt < ntl) xv[i][tt] = ld16(xr[tt] + (size_t)(kb + i * NW) * EPT);
+        }
       }
 #pragma unroll
       for (int i = 0; i < U; ++i) {
+        if (kb + i * NW < KBfull) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-          if (tt < ntl) {
-            mma16<T>(acc0[tt], av[i], xv[i][tt]);
-            if (NMAT == 2) mma16<T>(acc1[tt], bv[i], xv[i][tt]);
+          for (int tt = 0; tt < NT; ++tt) {
+            if (tt < ntl) {
+              mma16<T>(acc0[tt], av[i], xv[i][tt]);
+              if (NMAT == 2) mma16<T>(acc1[tt], bv[i], xv[i][tt]);
+            }
           }
-        }
-      }
-    }
-    for (; kb < KBfull; kb += NW) {
-      const u32x4 w0 = ld16_nt(a0 + (size_t)kb * 1024);
-      u32x4 w1 = w0;
-      if (NMAT == 2) w1 = ld16_nt(a1 + (size_t)kb * 1024);
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        if (tt < ntl) {
-          const u32x4 x0 = ld16(xr[tt] + (size_t)kb * EPT);
-          mma16<T>(acc0[tt], w0, x0);
-          if (NMAT == 2) mma16<T>(acc1[tt], w1, x0);
         }
       }
     }
@@ -381,6 +376,32 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
       __syncthreads();
     }
   }
+}
+
+template <typename T, int NMAT, int NW, int U, int NT>
+__global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
+  __shared__ float red[NW][NMAT][256];
+
+  // Prologue loads in two dependent rounds instead of three: active[u] is fetched together with n_active (entries
+  // past n_active hold stale but valid expert ids — the array is zero-initialised and only ever written with ids).
+  const int u = blockIdx.y;
+  const int e = s.active[u];
+  const int nact_dev = *s.n_active;
+  asm volatile("" ::"s"(e), "s"(nact_dev));  // keep both loads ahead of the exit branch (the compiler would sink active[u] below it)
+  const int nact = s.n_active_host >= 0 ? s.n_active_host : nact_dev;
+  if (u >= nact) return;
+  const bool sh = (e == s.E);
+  const int R = sh ? s.R_sh : s.R;
+  const int r0 = blockIdx.x * 16;
+  if (r0 >= R) return;
+  const int off = s.offsets[e];
+  const int cnt_e = s.counts[e];  // loaded alongside wptr[e], not after it: one dependent round trip less per block
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  // an absent expert (never on the sync-free path) computes nothing but still reports its arrival below
+  if (W == nullptr && threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+  const int cnt = W ? cnt_e : 0;
+  const int tid = threadIdx.x;
+  ffn_rows_item<T, NMAT, NW, U, NT>(s, blockIdx.x, W, sh, cnt, off, red);
   if constexpr (NMAT == 1 && NT == 1) {
     if (s.fuse_combine) {
       // this block's y columns [r0, r0+16) are written; the last of the layer's `nact` blocks to arrive for
@@ -1033,9 +1054,7 @@ __device__ __forceinline__ void load8<float>(const float* p, float out[8]) {
 
 template <typename XT, typename WT, int TT>
 __device__ __forceinline__ void gate_body(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
-                                          int T, int H, int E, int round_bf16, double (*red)[TT]) {
-  const int e = blockIdx.x;
-  const int t0 = blockIdx.y * TT;
+                                          int T, int H, int E, int round_bf16, double (*red)[TT], const int e, const int t0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double acc[TT];
 #pragma unroll
@@ -1075,12 +1094,45 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__
                                                           float* __restrict__ logits, int T, int H, int E,
                                                           int round_bf16) {
   __shared__ double red[4][TT];
-  gate_body<XT, WT, TT>(x, wg, logits, T, H, E, round_bf16, red);
+  gate_body<XT, WT, TT>(x, wg, logits, T, H, E, round_bf16, red, blockIdx.x, blockIdx.y * TT);
+}
+
+// Decode-sized DeepSeek forwards: the always-resident SHARED expert does not depend on the routing, so its FFN rides
+// along with the router instead of sitting behind it — stage 1 in the gate launch (this kernel: blocks [0, n_gate) are
+// gate blocks, the rest own 16 rows of the shared gate/up projections), stage 2 in the route/index launch
+// (route_shared2_kernel).  The two router launches are latency-bound and leave HBM idle; the shared expert is a
+// quarter of the layer's weight bytes (34.6 of 138 MB for DeepSeek-V2-Lite).
+template <typename XT, typename WT, int TT, typename T, int U>
+__global__ __launch_bounds__(256) void gate_shared1_kernel(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
+                                                           int T_, int H, int E, int round_bf16, int n_gate, FfnStage s) {
+  __shared__ double redg[4][TT];
+  __shared__ float red[4][2][256];
+  const int b = blockIdx.x;
+  if (b < n_gate) {
+    gate_body<XT, WT, TT>(x, wg, logits, T_, H, E, round_bf16, redg, b % E, (b / E) * TT);
+  } else {
+    const char* W = reinterpret_cast<const char*>(s.wptr[s.E]);
+    ffn_rows_item<T, 2, 4, U, 1>(s, b - n_gate, W, true, T_, 0, red);
+  }
 }
 
 // Mixtral's gate is an nn.Linear in the model dtype (mixtral.py:46): its output is rounded to
 // that dtype.  The other routers compute fp32 logits from (exactly) up-cast inputs.
 static inline int gate_rounds_bf16(const RouteArgs& a) { return (a.kind == 0 /*MIXTRAL*/ && a.x_dtype == DT_BF16) ? 1 : 0; }
+
+hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_t st) {
+  constexpr int TT = 4;
+  const int n_gate = a.E * ((a.T + TT - 1) / TT);
+  dim3 grid(n_gate + (s.R_sh + 15) / 16);
+  const int rb = gate_rounds_bf16(a);
+  // bf16 model (DeepSeek): activations bf16, gate bf16 or fp32
+  static const int u8 = env_int("MOEINF_SH1_U", 4) == 8;
+#define GS1(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU>), grid, dim3(256), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
+  if (a.gate_dtype == DT_BF16) { if (u8) GS1(uint16_t, 8); else GS1(uint16_t, 4); }
+  else { if (u8) GS1(float, 8); else GS1(float, 4); }
+#undef GS1
+  return hipGetLastError();
+}
 
 hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
   constexpr int TT = 4;
@@ -1575,6 +1627,34 @@ __global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, I
   } else {
     index_body(a, wave_cnt, running, offs, scan_tmp);
   }
+}
+
+// block 0: softmax/top-k of every token (4 waves) + the one-wave dispatch index (T*K <= 64); blocks 1..: 16 rows each of
+// the shared expert's down projection over h_shared (written by gate_shared1_kernel)
+template <typename T, int NW, int U>
+__global__ __launch_bounds__(NW * 64) void route_shared2_kernel(RouteArgs r, IndexArgs a, FfnStage s) {
+  __shared__ int running[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  __shared__ float red[NW][1][256];
+  if (blockIdx.x == 0) {
+    for (int t = threadIdx.x >> 6; t < r.T; t += NW) route_token(r, t, threadIdx.x & 63);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64) index_small(a, running, offs);
+  } else {
+    const char* W = reinterpret_cast<const char*>(s.wptr[s.E]);
+    ffn_rows_item<T, 1, NW, U, 1>(s, (int)blockIdx.x - 1, W, true, r.T, 0, red);
+  }
+}
+hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st) {
+  static const int nw = env_int("MOEINF_SH2_NW", 8), u = env_int("MOEINF_SH2_U", 4);
+  const dim3 grid(1 + (s.R_sh + 15) / 16);
+#define RS2(NWV, UU) hipLaunchKernelGGL((route_shared2_kernel<uint16_t, NWV, UU>), grid, dim3(NWV * 64), 0, st, r, a, s)
+  if (nw == 16) { if (u == 8) RS2(16, 8); else RS2(16, 4); }
+  else if (nw == 4) { if (u == 8) RS2(4, 8); else RS2(4, 4); }
+  else { if (u == 8) RS2(8, 8); else RS2(8, 4); }
+#undef RS2
+  return hipGetLastError();
 }
 
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st) {
