@@ -588,6 +588,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_gemm_kernel(FfnStage s) {
 // DMA writes LDS linearly (base + lane*16), so the bank swizzle is applied to the SOURCE: lane (r = lane/8,
 // c = lane%8) fetches 16-byte chunk (c ^ r) of row r; a fragment read of (token n, chunk ch) then goes to piece
 // n/8, byte r*128 + ((ch ^ r) << 4), r = n%8 — conflict-free for ds_read_b128.
+// (A 3-buffer variant — stage ks+2 issued while stage ks is multiplied, counted s_waitcnt + raw s_barrier so that one
+// stage stays in flight across the barrier — was built and measured: Mixtral's down projection 242-272 -> 346-368 us
+// at 512 tokens, 808 -> 970-1005 us at 2048; DeepSeek +-10 % either way.  Not kept.)
 template <typename T, int NMAT, int RGB, int NWV, bool XL>
 __global__ __launch_bounds__(NWV * 64) void ffn_gemm_lds_kernel(FfnStage s) {
   constexpr int EPV = DT<T>::EPV;
@@ -936,6 +939,191 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ffn_gemm_ring: the GATED stage (x -> silu(x W1^T) * (x W3^T)) for experts with ~64..1000 tokens (prefill), bf16,
+// long reductions (K >= 4096).
+// What bounds ffn_gemm_lds / ffn_gemm_hyb at ~128 tokens per expert is WEIGHT BYTES IN FLIGHT: one stage ahead,
+// drained by `vmcnt(0)` + `__syncthreads()` every k-step, leaves 16-32 KiB of weights outstanding per CU against a
+// ~2 us HBM round trip = ~4 TB/s chip-wide (measured 3.4-3.9).  Here
+//   * block = 8 waves, ONE block per CU; wave w owns the same 16 rows of BOTH matrices against NTB token groups
+//     (128 or 256 tokens): 16 / 32 accumulator tiles, SiLU*mul in registers;
+//   * weights go HBM -> VGPRs directly (the tiled layout IS the MFMA A fragment) through a ring of D register stages
+//     (a stage = 2 k-tiles = 4 one-KiB tiles per wave); D = 4: 12 KiB per wave = 96 KiB per CU in flight (D = 3 for
+//     the 256-token variant, which needs the registers for accumulators).  The loads are inline asm so that the
+//     compiler's vmcnt bookkeeping cannot drain the ring;
+//   * activations go L2 -> LDS by global_load_lds in full 128-byte lines (source-side XOR swizzle, as ffn_gemm_lds
+//     XL) through a ring of 3 LDS stages;
+//   * ONE raw s_barrier per stage and a COUNTED s_waitcnt: every wave issues the same VM ops in the same order
+//     (... W(k) X(k) W(k+1) X(k+1) ..., 4 weight loads and XPW activation DMAs per stage; pieces of absent token
+//     groups are still issued, clamped, so the count never varies).
+// Mixtral stage 1 at 512 tokens (128 rows per expert): 565 -> 420-450 us per layer (3.4 -> 4.4 TB/s); at 2048 tokens
+// 1490 -> 1250-1420 us.  The same structure for the PLAIN stage (two row groups per wave, or one row group with the
+// k-tiles of a 4-tile stage split over two partial accumulators) was built and measured too: Mixtral's down
+// projection 250 -> 300-380 us at 512 tokens, 805 -> 840-1180 us at 2048 — slower than ffn_gemm_lds there (a matrix
+// with H = 4096 rows gives 128-256 eight-wave blocks for 256 CUs), so the plain stage stays on ffn_gemm_lds.
+// Requires K % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ring_load(u32x4& dst, const char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  // the counted wait carries the stage's registers as in/out operands: no MFMA that reads them can be scheduled above it
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+template <int NTB, int D>
+__global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
+  static_assert(D == 3 || D == 4, "register ring of 3 or 4 stages");
+  typedef uint16_t T;
+  constexpr int EPT = 32, EPV = 8;
+  constexpr int NWV = 8;
+  constexpr int XPW = 2 * NTB / NWV;        // activation DMA pieces (8 rows x 128 B) per wave and stage
+  constexpr int XSTAGE = 2 * NTB * 1024;    // activation bytes per stage (2 k-tiles)
+  constexpr int NX = 3;                     // LDS ring
+  __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
+
+  const int u = blockIdx.y;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int nrg_total = (R + 15) / 16;
+  if ((int)blockIdx.x * NWV >= nrg_total) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int KB = K / EPT;
+  const int KS = KB / 2;
+  const size_t rg_stride = (size_t)KB * 1024;
+  // this wave's two weight-tile streams (a row group past the end re-reads the last one; its results are dropped)
+  const int rg = min((int)blockIdx.x * NWV + wave, nrg_total - 1);
+  const bool rg_live = (int)blockIdx.x * NWV + wave < nrg_total;
+  const char* ap[2];
+  ap[0] = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg * rg_stride + lane * 16;
+  ap[1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg * rg_stride + lane * 16;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
+    const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);  // token groups present in this pass (block-uniform)
+    const T* xrp[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const int trow = tile0 * 16 + (wave + NWV * i) * 8 + (lane >> 3);
+      const int srow = off + min(trow, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (((lane & 7) ^ (lane >> 3)) * EPV);
+    }
+    f32x4 acc[NTB][2];
+#pragma unroll
+    for (int b = 0; b < NTB; ++b) { acc[b][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    u32x4 wr[D][4];  // [ring stage][k-tile * 2 + matrix]
+    auto issue_w = [&](int ks, u32x4 (&dst)[4]) {
+      const int kb = min(ks, KS - 1) * 2;  // past the end: re-read the last stage (never multiplied), the count stays fixed
+      ring_load(dst[0], ap[0] + (size_t)kb * 1024);
+      ring_load(dst[1], ap[1] + (size_t)kb * 1024);
+      ring_load(dst[2], ap[0] + (size_t)(kb + 1) * 1024);
+      ring_load(dst[3], ap[1] + (size_t)(kb + 1) * 1024);
+    };
+    auto issue_x = [&](int ks) {
+      char* base = smem + (ks % NX) * XSTAGE;
+      const int kc = min(ks, KS - 1);
+#pragma unroll
+      for (int i = 0; i < XPW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kc * 2 * EPT), (lptr_t)(base + (wave + NWV * i) * 1024), 16, 0, 0);
+    };
+    // token groups are multiplied in chunks of 4 (absent groups of a partly filled chunk hold clamped copies of the last
+    // row and are dropped by the epilogue): one wave-uniform branch per chunk instead of one per group, so the LDS
+    // fragment reads of a chunk are issued together and its 8 MFMAs run back to back (a branch per group serialised
+    // ds_read -> wait -> 2 MFMAs)
+    auto compute = [&](int ks, const u32x4 (&w)[4]) {
+      const char* base = smem + (ks % NX) * XSTAGE;
+      const int r = n & 7;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = kk * 4 + q;
+#pragma unroll
+        for (int c = 0; c < NTB / 4; ++c) {
+          if (c * 4 < ntl) {
+            u32x4 bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const u32x4*>(base + ((c * 4 + i) * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int b = c * 4 + i;
+              acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kk * 2 + 0]), __builtin_bit_cast(bf16x8, bf[i]), acc[b][0], 0, 0, 0);
+              acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kk * 2 + 1]), __builtin_bit_cast(bf16x8, bf[i]), acc[b][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    // Issue order of every wave: ... W(k) X(k) W(k+1) X(k+1) ...
+    //   D == 4: prologue W0 X0 W1 X1 W2, step S issues X(S+2) W(S+3); before stage S is consumed W(S+1) X(S+1) W(S+2) may
+    //           be outstanding: vmcnt(8 + XPW);
+    //   D == 3: prologue W0 X0 W1 X1,    step S issues W(S+2) X(S+2); outstanding W(S+1) X(S+1): vmcnt(4 + XPW).
+    // Unrolled by D so that the register ring is indexed statically.  Past the end the issues are clamped re-reads
+    // (count-preserving); the final wait below drains them.
+    issue_w(0, wr[0]); issue_x(0);
+    issue_w(1, wr[1]); issue_x(1);
+    if (D == 4) issue_w(2, wr[2]);
+#define RING_STEP(S, CUR, NXT)                                                                   \
+    if ((S) < KS) {                                                                              \
+      ring_wait<(D - 2) * 4 + XPW>(wr[CUR][0], wr[CUR][1], wr[CUR][2], wr[CUR][3]); /* this wave's W(S), X(S) landed */ \
+      __builtin_amdgcn_s_barrier();              /* everybody's X(S) landed; LDS buffer (S+2)%3 is free */        \
+      if (D == 4) { issue_x((S) + 2); issue_w((S) + 3, wr[NXT]); }                                \
+      else { issue_w((S) + 2, wr[NXT]); issue_x((S) + 2); }                                      \
+      compute((S), wr[CUR]);                                                                     \
+    }
+    if (D == 4) {
+      for (int ks = 0; ks < KS; ks += 4) {
+        RING_STEP(ks, 0, 3)
+        RING_STEP(ks + 1, 1, 0)
+        RING_STEP(ks + 2, 2, 1)
+        RING_STEP(ks + 3, 3, 2)
+      }
+    } else {
+      for (int ks = 0; ks < KS; ks += 3) {
+        RING_STEP(ks, 0, 2)
+        RING_STEP(ks + 1, 1, 0)
+        RING_STEP(ks + 2, 2, 1)
+      }
+    }
+#undef RING_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail issues
+    // epilogue straight from the accumulators: lane holds 4 consecutive rows of one token
+#pragma unroll
+    for (int b = 0; b < NTB; ++b) {
+      const int tok = (tile0 + b) * 16 + n;
+      if (tok < cnt && rg_live) {
+        const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
+        const int r0 = rg * 16 + q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (r0 + j < R) {
+            float v = DT<T>::round(acc[b][0][j]);
+            const float bb = DT<T>::round(acc[b][1][j]);
+            const float sl = DT<T>::round(v / (1.0f + expf(-v)));
+            v = DT<T>::round(sl * bb);
+            DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out + r0 + j, v);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next pass re-uses the LDS ring from stage 0
+  }
+}
+
 // tuning knobs (overridable for sweeps: MOEINF_FFN_NW=4|8, MOEINF_FFN_U=2|4|8)
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -953,6 +1141,21 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
     // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
     // amortise staging the weights in LDS -> the hybrid kernel (measured -15 % on that shape, sweep in profiles/)
     static const int hyb_rows = env_int("MOEINF_GEMM_HYB_ROWS", 64);
+    static const int ring_env = env_int("MOEINF_GEMM_RING", 1);
+    if constexpr (sizeof(T) == 2 && NMAT == 2) {
+      // bf16 gated stage, more than hyb_rows rows per expert, long reduction: the register-ring kernel.  With a short K
+      // (DeepSeek: 32 stages) filling and draining the ring costs more than it hides (297 vs 287 us at 512 tokens).
+      static const int ring_min_k = env_int("MOEINF_RING_MIN_K", 4096);
+      const bool ring_ok = (s.K % 64) == 0 && (s.K_sh % 64) == 0 && s.K >= ring_min_k && (s.K_sh == 0 || s.K_sh >= ring_min_k);
+      if ((use_gemm == 4 || (use_gemm == 2 && ring_env && max_rows > hyb_rows)) && ring_ok) {
+        static const int ring_wide = env_int("MOEINF_RING_WIDE", -1);
+        const bool wide = ring_wide >= 0 ? ring_wide != 0 : max_rows > 128;
+        const dim3 g2((grid.x + 7) / 8, grid.y);
+        if (wide) hipLaunchKernelGGL((ffn_gemm_ring_kernel<16, 3>), g2, dim3(512), 0, st, s);
+        else hipLaunchKernelGGL((ffn_gemm_ring_kernel<8, 4>), g2, dim3(512), 0, st, s);
+        return;
+      }
+    }
     if ((use_gemm == 3 || (use_gemm == 2 && max_rows <= hyb_rows)) && k_ok) {  // weights -> registers, activations -> LDS
       static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
       static const int hxl_env = env_int("MOEINF_GEMM_XL", 1);
