@@ -207,6 +207,7 @@ struct moeinf_engine {
   int32_t *d_counts = nullptr, *d_offsets = nullptr, *d_active = nullptr, *d_n_active = nullptr;
   int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_miss = nullptr;
   int32_t* d_arrive = nullptr;  // [ceil(H/16)] zeroed arrival counters of the fused combine's column tiles
+  int32_t* d_chunk = nullptr;   // [ceil(rows/1024) * E] scratch of the many-workgroup dispatch index
   void *d_h = nullptr, *d_y = nullptr;
   void *d_h_sh = nullptr, *d_y_sh = nullptr;  // decode-sized DeepSeek: shared expert's h / y (its FFN rides with the router)
   int64_t ldh = 0;
@@ -332,7 +333,7 @@ static int dmalloc(T** p, size_t n) {
 // the part of the device workspace that is sized by max_tokens (re-allocated by moeinf_reserve_tokens)
 static void free_token_workspace(moeinf_engine* g) {
   void** bufs[] = {(void**)&g->d_logits, (void**)&g->d_topk_idx, (void**)&g->d_pair_valid, (void**)&g->d_pair_order, (void**)&g->d_pair_slot,
-                   (void**)&g->d_topk_w, (void**)&g->d_router_prob, (void**)&g->d_slot_token, (void**)&g->d_slot_pair, &g->d_h, &g->d_y};
+                   (void**)&g->d_topk_w, (void**)&g->d_router_prob, (void**)&g->d_slot_token, (void**)&g->d_slot_pair, (void**)&g->d_chunk, &g->d_h, &g->d_y};
   for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
 }
 static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
@@ -342,6 +343,7 @@ static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
   CHK(dmalloc(&g->d_topk_idx, T * K)); CHK(dmalloc(&g->d_pair_valid, T * K)); CHK(dmalloc(&g->d_pair_order, T * K));
   CHK(dmalloc(&g->d_pair_slot, T * K)); CHK(dmalloc(&g->d_topk_w, T * K)); CHK(dmalloc(&g->d_router_prob, T));
   CHK(dmalloc(&g->d_slot_token, rows)); CHK(dmalloc(&g->d_slot_pair, rows));
+  CHK(dmalloc(&g->d_chunk, ((T * K + 1023) / 1024 + 1) * (size_t)std::max(g->E, g->cfg.ep_size)));
   HIPCHK(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   HIPCHK(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
   return MOEINF_OK;
@@ -735,15 +737,24 @@ static int ensure_host(moeinf_engine* g, int idx) {
   } else if (g->cfg.host_memory_bytes <= 0 || g->arena_total + g->lay.total <= g->cfg.host_memory_bytes) {
     CHK(arena_alloc(g, g->lay.total, &blk));
   } else {
-    int victim = -1;
+    int victim = -1, busy = -1;
     for (int i = 0; i < (int)g->nodes.size(); ++i) {
       Node& v = g->nodes[i];
       if (i == idx || !v.host || !v.store) continue;
       if (v.copy_inflight) {  // its H2D copy may still be reading the blob (ready_waited only says the compute stream is ORDERED after it)
-        if (hipEventQuery(v.ready) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventQuery(v.ready) != hipSuccess) {
+          (void)hipGetLastError();
+          if (busy < 0 || v.host_clock < g->nodes[busy].host_clock) busy = i;
+          continue;
+        }
         v.copy_inflight = false;
       }
       if (victim < 0 || v.host_clock < g->nodes[victim].host_clock) victim = i;
+    }
+    if (victim < 0 && busy >= 0) {  // every droppable blob is still being copied: wait for the oldest transfer
+      HIPCHK(hipEventSynchronize(g->nodes[busy].ready));
+      g->nodes[busy].copy_inflight = false;
+      victim = busy;
     }
     if (victim < 0) return fail(MOEINF_ERR_OOM, "pinned host arena cap (%lld bytes) reached and no host blob can be dropped", (long long)g->cfg.host_memory_bytes);
     blk = g->nodes[victim].host;
@@ -1126,7 +1137,10 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
       HIPCHK(launch_route_index(ra, ia, st));  // decode: top-k + dispatch index in one launch
     } else {
       HIPCHK(launch_route_topk(ra, st));
-      HIPCHK(launch_dispatch_index(ia, st));
+      // long prefills: the index over many workgroups (one workgroup walks 1024-pair chunks serially, ~12 us each)
+      static const int wide_pairs = getenv("MOEINF_INDEX_WIDE_PAIRS") ? atoi(getenv("MOEINF_INDEX_WIDE_PAIRS")) : 4096;
+      if (ia.capacity <= 0 && (int64_t)T * K > wide_pairs) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
+      else HIPCHK(launch_dispatch_index(ia, st));
     }
   }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
@@ -1740,6 +1754,11 @@ extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* e
 }
 
 // ---- expert-parallel helpers ---------------------------------------------------------------
+static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st) {
+  if (ia.capacity <= 0 && (int64_t)ia.T * ia.K > 4096) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
+  else HIPCHK(launch_dispatch_index(ia, st));
+  return MOEINF_OK;
+}
 static int ep_alloc(moeinf_engine* g, int cap_rows) {
   if (g->d_ep_key && g->ep_alloc_cap >= cap_rows) { g->ep_cap_rows = cap_rows; return MOEINF_OK; }
   void* olds[] = {g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active, g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
@@ -1810,7 +1829,7 @@ extern "C" int moeinf_ep_pack_compact(moeinf_engine* g, const void* x_dev, void*
   ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
   ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
   ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
-  HIPCHK(launch_dispatch_index(ia, st));
+  CHK(launch_index_auto(g, ia, st));
   EpPackArgs pa;
   memset(&pa, 0, sizeof pa);
   pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
@@ -1851,7 +1870,7 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
   drop_stale_prefetches(g, layer);
   CHK(plan_mirror(g, layer, mp));
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
-  HIPCHK(launch_dispatch_index(ia, st));
+  CHK(launch_index_auto(g, ia, st));
   const int owned = std::max(1, g->owned_experts);
   // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
   // row), so the reply needs no un-sort pass

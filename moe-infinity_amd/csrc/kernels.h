@@ -109,6 +109,9 @@ struct IndexArgs {
                             // (counts pre-zeroed by the host; only active experts' counts are guaranteed written)
 };
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
+// the same index over many workgroups (3 launches) for long prefills; chunk_scratch: [ceil(T*K/1024) * E] ints.
+// Not for a.capacity > 0 (Switch per-row capacity is a sequential pass).
+hipError_t launch_dispatch_index_wide(const IndexArgs& a, int32_t* chunk_scratch, hipStream_t st);
 // dispatch index from a dense router_mask[T,E] (element size 1, 4 or 8 bytes, non-zero = routed)
 hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st);
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)

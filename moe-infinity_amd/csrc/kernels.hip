@@ -1735,6 +1735,97 @@ __global__ __launch_bounds__(IDX_THREADS) void dispatch_index_kernel(IndexArgs a
   }
 }
 
+// ---- many pairs (long prefill): the same stable counting sort over MANY workgroups --------------------------------
+// One workgroup ranks 1024 pairs in ~5 us and walks the chunks serially: 36 us at 3 072 pairs, ~1 ms at T = 16 k x K = 6.
+//   index_count   grid = chunks: rank of every pair inside (its chunk, its expert) + per-chunk expert counts
+//   index_scan    1 workgroup:   per expert, exclusive scan of the chunk counts; totals -> counts / offsets / active /
+//                                host mirror; chunk bases rebased to expert-sorted rows
+//   index_scatter grid = chunks: slot = chunk base + rank; permutation arrays
+// Same outputs, bit for bit, as index_body (ranks are stable in pair order).  Not for the Switch per-row capacity
+// pass (a sequential cumsum per batch row), which stays on one workgroup.
+__global__ __launch_bounds__(IDX_THREADS) void index_count_kernel(IndexArgs a, int32_t* __restrict__ chunk_cnt) {
+  __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
+  __shared__ int running[IDX_MAXE];
+  const int tid = threadIdx.x, E = a.E, npairs = a.T * a.K;
+  for (int i = tid; i < IDX_MAXE; i += IDX_THREADS) running[i] = 0;
+  __syncthreads();
+  const int p = blockIdx.x * IDX_THREADS + tid;
+  const bool in = p < npairs;
+  const int key = in ? IDX_AT(a, p) : -1;
+  const bool counted = in && key >= 0 && key < E && (a.pair_valid ? a.pair_valid[p] != 0 : true);
+  const int pos = chunk_rank(counted ? key : 0, counted, wave_cnt, running, E);
+  if (in) a.pair_slot[p] = pos;  // rank inside the chunk for now (-1: not dispatched)
+  for (int e = tid; e < E; e += IDX_THREADS) chunk_cnt[(size_t)blockIdx.x * E + e] = running[e];
+}
+__global__ __launch_bounds__(IDX_THREADS) void index_scan_kernel(IndexArgs a, int32_t* __restrict__ chunk_cnt, int nchunks) {
+  __shared__ int tot[IDX_MAXE];
+  __shared__ int offs[IDX_MAXE + 1];
+  const int tid = threadIdx.x, E = a.E, ne = E + 1, T = a.T;
+  if (tid < E) {  // exclusive scan over the chunks, in place
+    int base = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int v = chunk_cnt[(size_t)c * E + tid];
+      chunk_cnt[(size_t)c * E + tid] = base;
+      base += v;
+    }
+    tot[tid] = base;
+  }
+  if (tid == E) tot[E] = a.shared ? T : 0;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, na = 0;
+    for (int e = 0; e < ne; ++e) {
+      offs[e] = acc;
+      acc += tot[e];
+      if (tot[e] > 0) a.active[na++] = e;
+    }
+    offs[ne] = acc;
+    *a.n_active = na;
+    if (a.mirror) {
+      a.mirror[0] = na;
+      for (int i = 0; i < na; ++i) a.mirror[1 + ne + i] = a.active[i];
+      for (int i = na; i < ne; ++i) a.mirror[1 + ne + i] = -1;
+    }
+  }
+  __syncthreads();
+  if (tid < ne) {
+    a.counts[tid] = tot[tid];
+    if (a.mirror) a.mirror[1 + tid] = tot[tid];
+  }
+  if (tid <= ne) a.offsets[tid] = offs[tid];
+  if (tid < E) {
+    const int o = offs[tid];
+    for (int c = 0; c < nchunks; ++c) chunk_cnt[(size_t)c * E + tid] += o;
+  }
+}
+__global__ __launch_bounds__(IDX_THREADS) void index_scatter_kernel(IndexArgs a, const int32_t* __restrict__ chunk_base) {
+  const int npairs = a.T * a.K, E = a.E;
+  const int p = blockIdx.x * IDX_THREADS + threadIdx.x;
+  if (p < npairs) {
+    const int rk = a.pair_slot[p];
+    if (rk >= 0) {
+      const int slot = chunk_base[(size_t)blockIdx.x * E + IDX_AT(a, p)] + rk;
+      a.pair_slot[p] = slot;
+      a.slot_token[slot] = p / a.K;
+      a.slot_pair[slot] = p;
+    }
+  }
+  if (a.shared) {
+    const int base = a.offsets[E];  // written by index_scan (previous launch)
+    for (int t = p; t < a.T; t += gridDim.x * IDX_THREADS) {
+      a.slot_token[base + t] = t;
+      a.slot_pair[base + t] = -1;
+    }
+  }
+}
+hipError_t launch_dispatch_index_wide(const IndexArgs& a, int32_t* chunk_scratch, hipStream_t st) {
+  const int nchunks = (a.T * a.K + IDX_THREADS - 1) / IDX_THREADS;
+  hipLaunchKernelGGL(index_count_kernel, dim3(nchunks), dim3(IDX_THREADS), 0, st, a, chunk_scratch);
+  hipLaunchKernelGGL(index_scan_kernel, dim3(1), dim3(IDX_THREADS), 0, st, a, chunk_scratch, nchunks);
+  hipLaunchKernelGGL(index_scatter_kernel, dim3(nchunks), dim3(IDX_THREADS), 0, st, a, chunk_scratch);
+  return hipGetLastError();
+}
+
 hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(dispatch_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, a);
   return hipGetLastError();

@@ -605,3 +605,25 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
         assert_model_close(y, tt(z[f"y{i}"], torch.float32), dt, f"{fam} {tag} case {i} vs the reference module",
                            ulps=2.0 if fam == "nllb" else 1.0)
     eng.close()
+
+
+@pytest.mark.parametrize("family,t,e,k", [("mixtral", 5000, 8, 2), ("deepseek", 3000, 64, 6)], ids=["mixtral_10000_pairs", "deepseek_18000_pairs_shared"])
+def test_long_prefill_index_over_many_workgroups(family, t, e, k):
+    """T*K > 4096 pairs: the dispatch index runs as count / scan / scatter over many workgroups.  Same outputs, bit for
+    bit, as the single-workgroup index (stable ranks in pair order)."""
+    h, f, n_shared = 256, 128, (2 if family == "deepseek" else 0)
+    gate, experts, shared = make_weights(family, h, f, e, 1800, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=t)
+    register_all(eng, experts, shared)
+    x = acts(t, h, torch.bfloat16, 1801)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    if family == "mixtral":
+        ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+        r = _check_routing_exact(eng, ref)
+    else:
+        ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+        r = _check_routing_exact(eng, ref, k_sorted=False)
+    _check_dispatch_index(r, ref)
+    assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block")
+    eng.close()
