@@ -491,13 +491,17 @@ def main():
             try:
                 o = run_workload(args, wl, b, world, rank, local_rank, dev, False, False, dist)
                 k1, k2 = o["kernels"].get("ffn_stage1"), o["kernels"].get("ffn_stage2")
+                # algorithmic bytes of one step: every interval of the layer (a DeepSeek decode step carries the shared
+                # expert's bytes in the router interval: its FFN rides inside the router launches)
+                kr, kc = o["kernels"].get("route(gate+topk+index)"), o["kernels"].get("combine")
+                step_bytes = sum(k["bytes_per_launch"] for k in (k1, k2, kr, kc) if k) * o["L"]
                 others.append({"workload": f"{o['label']} MoE layers: L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}"
                                            + (f" +shared F={o['cfg'].shared_inter}" if o["cfg"].shared_inter else "")
                                            + f", decode batch {b}, device_memory_ratio={args.ratio}",
                                "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2),
                                "windows_ms": o["windows_ms"],
-                               "algorithmic_GB_per_step": None if not (k1 and k2) else round((k1["bytes_per_launch"] + k2["bytes_per_launch"]) * o["L"] / 1e9, 3),
-                               "frac_of_hbm_peak_whole_step": None if not (k1 and k2) else round((k1["bytes_per_launch"] + k2["bytes_per_launch"]) * o["L"] / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_GB_per_step": None if not (k1 and k2) else round(step_bytes / 1e9, 3),
+                               "frac_of_hbm_peak_whole_step": None if not (k1 and k2) else round(step_bytes / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "ffn_stage1": k1, "ffn_stage2": k2, "route": o["kernels"].get("route(gate+topk+index)"),
                                "parity": o["parity"], "cpu_baseline": o["cpu"]})
             except Exception as ex:  # an extra leg must not take the measured line down

@@ -1138,7 +1138,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     } else {
       HIPCHK(launch_route_topk(ra, st));
       // long prefills: the index over many workgroups (one workgroup walks 1024-pair chunks serially, ~12 us each)
-      static const int wide_pairs = getenv("MOEINF_INDEX_WIDE_PAIRS") ? atoi(getenv("MOEINF_INDEX_WIDE_PAIRS")) : 4096;
+      static const int wide_pairs = getenv("MOEINF_INDEX_WIDE_PAIRS") ? atoi(getenv("MOEINF_INDEX_WIDE_PAIRS")) : 2048;
       if (ia.capacity <= 0 && (int64_t)T * K > wide_pairs) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
       else HIPCHK(launch_dispatch_index(ia, st));
     }
@@ -1755,7 +1755,7 @@ extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* e
 
 // ---- expert-parallel helpers ---------------------------------------------------------------
 static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st) {
-  if (ia.capacity <= 0 && (int64_t)ia.T * ia.K > 4096) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
+  if (ia.capacity <= 0 && (int64_t)ia.T * ia.K > 2048) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
   else HIPCHK(launch_dispatch_index(ia, st));
   return MOEINF_OK;
 }

@@ -609,7 +609,7 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
 
 @pytest.mark.parametrize("family,t,e,k", [("mixtral", 5000, 8, 2), ("deepseek", 3000, 64, 6)], ids=["mixtral_10000_pairs", "deepseek_18000_pairs_shared"])
 def test_long_prefill_index_over_many_workgroups(family, t, e, k):
-    """T*K > 4096 pairs: the dispatch index runs as count / scan / scatter over many workgroups.  Same outputs, bit for
+    """T*K > 2048 pairs: the dispatch index runs as count / scan / scatter over many workgroups.  Same outputs, bit for
     bit, as the single-workgroup index (stable ranks in pair order)."""
     h, f, n_shared = 256, 128, (2 if family == "deepseek" else 0)
     gate, experts, shared = make_weights(family, h, f, e, 1800, torch.bfloat16, n_shared=n_shared)
