@@ -209,6 +209,8 @@ struct moeinf_engine {
   int32_t* d_arrive = nullptr;  // [ceil(H/16)] zeroed arrival counters of the fused combine's column tiles
   int32_t* d_chunk = nullptr;   // [ceil(rows/1024) * E] scratch of the many-workgroup dispatch index
   void *d_h = nullptr, *d_y = nullptr;
+  uint64_t* d_dec_w = nullptr;  // [8] batch-1 decode records written by the self-routing FFN stage 1 (kernels.h FfnStage::dec_w)
+  float* d_dec_cw = nullptr;    // [8]
   void *d_h_sh = nullptr, *d_y_sh = nullptr;  // decode-sized DeepSeek: shared expert's h / y (its FFN rides with the router)
   int64_t ldh = 0;
   int32_t* h_mirror = nullptr;  // pinned, written by the index kernels themselves: {n_active, counts[E+1], active[E+1]}
@@ -237,6 +239,7 @@ struct moeinf_engine {
 
   // last forward
   bool last_hidden_shared = false;
+  bool last_selfroute = false;      // the last forward used the self-routing FFN stage 1 (batch-1 decode)
   int last_T = 0, last_layer = -1;
   hipStream_t last_stream = nullptr;
   int last_rows = 0;
@@ -361,7 +364,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_miss, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -444,6 +447,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRY(dmalloc(&g->d_arrive, (g->H + 15) / 16)); TRY(dmalloc(&g->d_miss, 1));
   TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
+  TRY(dmalloc(&g->d_dec_w, 8)); TRY(dmalloc(&g->d_dec_cw, 8));
+  TRYHIP(hipMemset(g->d_dec_w, 0, 8 * sizeof(uint64_t))); TRYHIP(hipMemset(g->d_dec_cw, 0, 8 * sizeof(float)));
   TRYHIP(hipMemset(g->d_active, 0, (size_t)E1 * sizeof(int32_t)));  // the FFN kernels read active[u] before they know n_active
   TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
   TRY(alloc_token_workspace(g, cfg->max_tokens));
@@ -791,6 +796,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   s.wptr = g->d_wptr + (size_t)layer * (g->E + 1);
   s.active = g->d_active; s.n_active = g->d_n_active; s.counts = g->d_counts; s.offsets = g->d_offsets;
   s.miss_flag = g->d_miss;
+  s.dec_w = g->d_dec_w; s.dec_cw = g->d_dec_cw;
   s.n_active_host = -1;
   s.E = g->E;
   s.dtype = g->dt;
@@ -822,7 +828,10 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   for (int e = 0; e < E; ++e) { if (mirror[1 + e] > 0) { ++U; rows += mirror[1 + e]; } }
   const bool hidden = g->has_shared && local && g->last_hidden_shared;  // the shared expert ran inside the router launches
   const int64_t es = g->es, H = g->H, F = g->F, Fs = g->Fs, Tsh = (g->has_shared && local && !hidden) ? T : 0;
-  if (hidden) g->prof.route_bytes += 3 * Fs * H * es + (int64_t)T * (2 * Fs + 2 * H) * es;
+  // a self-routing forward carries the hidden shared expert's stage 2 inside the FFN stage-1 launch
+  const bool sr2 = hidden && g->last_selfroute;
+  if (hidden) g->prof.route_bytes += (sr2 ? 2 : 3) * Fs * H * es + (int64_t)T * ((sr2 ? 1 : 2) * Fs + (sr2 ? 1 : 2) * H) * es;
+  if (sr2) g->prof.ffn1_bytes += Fs * H * es + (int64_t)T * (Fs + H) * es;
   const int et = g->cfg.expert_type;
   const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
   const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
@@ -1035,9 +1044,14 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
 //   does not wait for the routing result (the reference blocks on a D2H sum every layer,
 //   expert_executor.py:34-43).  The mirror is applied to the counters lazily.
 //   Decision path: some expert may be missing: small pinned D2H + event wait, then fetch/evict.
+struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn1_selfroute)
+  const RouteArgs* ra;
+  const IndexArgs* ia;
+  const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
+};
 static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
                             hipStream_t st, bool prof, moeinf_engine::ProfRec* pr, const MirrorPlan& mp,
-                            const CombineArgs* fuse, bool* fused) {
+                            const CombineArgs* fuse, bool* fused, const SelfRoute* sr = nullptr) {
   const int E = g->E, E1 = E + 1;
   if (fused) *fused = false;
   if (mp.fast) {
@@ -1055,9 +1069,11 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = 1; s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
-    HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
+    if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
+    else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
-    HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
+    if (sr && fuse) HIPCHK(launch_ffn2_decode1(s2, st));
+    else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[4], st));
   } else {
     // the index kernel wrote h_mirror itself (pinned, device-visible): wait for it, no copy
@@ -1122,13 +1138,26 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool hide_shared = hide_env && g->has_shared && !route_only && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * K <= 64 &&
                            g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
   g->last_hidden_shared = hide_shared;
+  // batch-1 decode on the sync-free path (gated families, bf16): no top-k/index launch at all — FFN stage 1 routes for
+  // itself from the gate logits (ffn1_selfroute_kernel) and one extra block of it writes the routing outputs
+  static const bool selfroute_env = getenv("MOEINF_SELFROUTE") ? atoi(getenv("MOEINF_SELFROUTE")) != 0 : true;
+  const int et_ = g->cfg.expert_type;
+  const bool selfroute = selfroute_env && !route_only && mp.fast && T == 1 && K <= 8 && E <= 64 && g->dt == DT_BF16 && !g->ovr_out &&
+                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
+                         (et_ == MOEINF_EXPERT_MIXTRAL || et_ == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || hide_shared);
+  g->last_selfroute = selfroute;
+  FfnStage sh1, sh2;
   if (hide_shared) {
-    FfnStage sh1, sh2;
     fill_stage(g, layer, 1, sh1);
     sh1.in = x_dev; sh1.row_map = nullptr; sh1.out = g->d_h_sh; sh1.ld_out = g->Fs;
     fill_stage(g, layer, 2, sh2);
     sh2.in = g->d_h_sh; sh2.ld_in = g->Fs; sh2.out = g->d_y_sh; sh2.out_map = nullptr;
     ia.shared = 0;  // the index lists routed experts only
+  }
+  if (selfroute) {
+    if (hide_shared) HIPCHK(launch_gate_shared1(ra, sh1, st));
+    else HIPCHK(launch_gate_logits(ra, st));
+  } else if (hide_shared) {
     HIPCHK(launch_gate_shared1(ra, sh1, st));
     HIPCHK(launch_route_shared2(ra, ia, sh2, st));
   } else {
@@ -1164,9 +1193,10 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool can_fuse = fuse_combine && want_combine && T <= 16 &&
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK);
   bool fused = false;
+  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr,
-                       mp, can_fuse ? &ca : nullptr, &fused));
+                       mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));
   if (want_combine && !fused) HIPCHK(launch_combine(ca, st));
   if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
   // fence: slots used by this forward may be recycled only after this point of the stream

@@ -63,6 +63,9 @@ struct FfnStage {
   int fuse_combine;
   int32_t* tile_done;      // [ceil(R/16)] arrival counters, zero between launches (the last block resets its own)
   CombineArgs comb;
+  // batch-1 decode records (self-routing path): written by the meta block of ffn1_selfroute, read by ffn2_decode1
+  uint64_t* dec_w;         // [8] blob pointer of the u-th active expert (ascending expert id)
+  float* dec_cw;           // [8] the token's combine weight of that expert
 };
 // max_rows_per_expert: upper bound of rows any one expert receives (selects the multi-token-tile variant)
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
@@ -123,6 +126,14 @@ hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_
 //                 out = y_shared [T, R_sh == H]).
 hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_t st);
 hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st);
+
+// Batch-1 decode of the gated families (bf16, T == 1, K <= 8, T*K <= 64, every owned expert resident): FFN stage 1 that
+// routes for itself from the gate logits (no top-k/index launch).  r/a as for launch_route_index (a.shared must be 0),
+// s1 = the routed stage-1 descriptor, sh2 = the hidden shared expert's stage-2 descriptor or nullptr.
+hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st);
+// ... and its stage 2 (s2.fuse_combine set, K = s2.comb.K active experts, one token): blob pointers and combine weights
+// come from the records the self-routing launch left in s2.dec_w / s2.dec_cw
+hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
 // out[i] = valid[i] ? idx[i] : -1

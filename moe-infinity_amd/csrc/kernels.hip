@@ -263,7 +263,7 @@ __device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, 
 // shared expert's FFN along (gate_shared1_kernel / route_shared2_kernel).
 template <typename T, int NMAT, int NW, int U, int NT>
 __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, const char* W, const bool sh, const int cnt, const int off,
-                                              float (*red)[NMAT][256]) {
+                                              float (*red)[NMAT][256], const int xrow_fixed = -1) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
   const int K = sh ? s.K_sh : s.K;
@@ -288,7 +288,9 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int srow = off + min((tile0 + tt) * 16 + n, cnt - 1);
-      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      // xrow_fixed >= 0: every row of this item is token xrow_fixed (the self-routing decode kernel: the row map is
+      // being written by another block of the same launch)
+      const int64_t xrow = xrow_fixed >= 0 ? (int64_t)xrow_fixed : (s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow);
       xr[tt] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
       acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1429,7 +1431,15 @@ __device__ __forceinline__ void pick_best(const float key[4], uint32_t taken, in
   wave_argmax(bv, bi);
 }
 
-__device__ __forceinline__ void route_token(const RouteArgs& a, const int t, const int lane) {
+// what the router decides for one token, in registers (every entry wave-uniform)
+struct Routed {
+  int sel[8];     // chosen experts in the router's own order (-1 = nothing selected)
+  float w[8];     // combine weights
+  int valid[8];   // 0: the pair is dropped (NLLB zero weight)
+  float val0;     // Switch: probability of the top-1 expert
+};
+
+__device__ __forceinline__ void route_core(const RouteArgs& a, const int t, const int lane, Routed& o) {
   const int E = a.E, K = a.K;
   const float* lg = a.logits + (size_t)t * E;
   float l[4], p[4];
@@ -1561,23 +1571,38 @@ __device__ __forceinline__ void route_token(const RouteArgs& a, const int t, con
     valid[0] = (w[0] != 0.f); valid[1] = (w[1] != 0.f);  // router_mask = combining_weights.bool()
   }
 
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { o.sel[k] = sel[k]; o.w[k] = w[k]; o.valid[k] = valid[k]; }
+  o.val0 = val[0];
+}
+
+__device__ __forceinline__ void route_store(const RouteArgs& a, const int t, const int lane, const Routed& o, int* sel_out = nullptr,
+                                            float* w_out = nullptr, int* rank_out = nullptr) {
+  const int K = a.K;
   // lane k (< K) owns entry k: its rank among the token's experts by ascending id is its place in the
   // (deterministic) combine order.  Stable for repeated ids (-1 = nothing selected).
   int my_sel = -1, my_valid = 0, rank = 0;
   float my_w = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (lane == k) { my_sel = sel[k]; my_w = w[k]; my_valid = valid[k]; }
+    if (lane == k) { my_sel = o.sel[k]; my_w = o.w[k]; my_valid = o.valid[k]; }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (j < K) rank += (sel[j] < my_sel || (sel[j] == my_sel && j < lane)) ? 1 : 0;
+    if (j < K) rank += (o.sel[j] < my_sel || (o.sel[j] == my_sel && j < lane)) ? 1 : 0;
   if (lane < K) {
     a.topk_idx[(size_t)t * K + lane] = my_sel;
     a.topk_w[(size_t)t * K + lane] = my_w;
     a.pair_valid[(size_t)t * K + lane] = (my_sel >= 0) ? my_valid : 0;
     a.pair_order[(size_t)t * K + rank] = lane;
   }
-  if (lane == 0 && a.router_prob) a.router_prob[t] = val[0];
+  if (lane == 0 && a.router_prob) a.router_prob[t] = o.val0;
+  if (sel_out) { *sel_out = my_sel; *w_out = my_w; *rank_out = rank; }
+}
+
+__device__ __forceinline__ void route_token(const RouteArgs& a, const int t, const int lane) {
+  Routed o;
+  route_core(a, t, lane, o);
+  route_store(a, t, lane, o);
 }
 
 __global__ __launch_bounds__(256) void route_topk_kernel(RouteArgs a) {
@@ -1948,6 +1973,167 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
   else if (nw == 4) { if (u == 8) RS2(4, 8); else RS2(4, 4); }
   else { if (u == 8) RS2(8, 8); else RS2(8, 4); }
 #undef RS2
+  return hipGetLastError();
+}
+
+// The SET of experts route_core picks for one token of a greedy softmax top-K router (Mixtral; DeepSeek with
+// n_group <= 1), E <= 64 (one logit per lane), as a bit mask.  Same arithmetic as route_core on that path — p =
+// expf(l - max) / sum with the same wave reductions, K rounds of (largest p, ties -> lowest id) — in ~100-200
+// instructions: p >= 0, so its bit pattern orders like an unsigned integer; a round is one DPP max-reduction, one
+// ballot of the lanes that hold the maximum, and the lowest such lane wins.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define STEP(C) v = max(v, dpp_mov<C>(v));
+  MOEINF_ROW_REDUCE(STEP)
+#undef STEP
+  uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+  r = max(r, (uint32_t)__builtin_amdgcn_readlane((int)v, 16));
+  r = max(r, (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
+  r = max(r, (uint32_t)__builtin_amdgcn_readlane((int)v, 48));
+  return r;
+}
+__device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ logits, const int E, const int K, const int lane) {
+  const bool in = lane < E;
+  const float l = in ? logits[lane] : -INFINITY;
+  const float m = wave_max(l);
+  float p = in ? expf(l - m) : 0.f;
+  const float ssum = wave_sum(p);
+  p = p / ssum;
+  const uint32_t key = in ? __float_as_uint(p) : 0u;
+  uint64_t chosen = 0, avail = __ballot(in);
+  for (int k = 0; k < K && avail; ++k) {
+    const uint64_t mine = 1ull << lane;
+    const uint32_t best = wave_max_u32((avail & mine) ? key : 0u);
+    const uint64_t at = __ballot(key == best) & avail;
+    if (!at) break;
+    const uint64_t win = at & (~at + 1);  // lowest lane holding the maximum
+    chosen |= win;
+    avail &= ~win;
+  }
+  return chosen;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ffn1_selfroute: batch-1 decode (T == 1) of the gated families (Mixtral, DeepSeek), sync-free path.  FFN stage 1
+// ROUTES FOR ITSELF: every wave of every block repeats the token's softmax/top-k from the E gate logits (a few
+// hundred VALU instructions on registers, bit-identical by construction: the same route_core) and picks "its" expert
+// = the blockIdx-th smallest chosen id — so the top-k/index launch and its kernel boundary leave the layer's critical
+// path (Mixtral: gate 4.6 + route_index 5.9 us of a 125 us layer; DeepSeek: 7.9 of 47 us).  The logits and EVERY
+// expert's blob pointer are fetched in one round of independent loads (lane j holds wptr[j]; the chosen pointer is a
+// v_readlane away), so the weight stream starts two dependent round trips after the launch instead of four.
+// Requires E <= 64 and a greedy softmax top-K router (route_set_lean).
+// One extra block ("meta") writes what the later launches and the host read: top-k ids/weights/order, the dispatch
+// index (counts, offsets, active list, slots) and the pinned routing mirror.  With a DeepSeek shared expert hidden
+// under the router, the first n_sh2 blocks are its stage 2 (its stage 1 rode in the gate launch).
+// grid = 1 (meta) + n_sh2 + K * ceil(R/16) blocks of NW waves.
+// ------------------------------------------------------------------------------------------------
+// amdgpu_num_sgpr: the router's wave-uniform arrays would otherwise push the kernel past 96 SGPRs, and 256-thread
+// blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) (MI355X_MICROARCH.md): 106 SGPRs = 6 blocks per CU,
+// but Mixtral's stage 1 needs 7 (1792 blocks on 256 CUs) to be one resident wave of blocks
+template <typename T, int NW, int U>
+__global__ __launch_bounds__(NW * 64, 7) __attribute__((amdgpu_num_sgpr(80))) void ffn1_selfroute_kernel(RouteArgs r, IndexArgs a, FfnStage s, FfnStage sh2, int n_rg, int n_sh2) {
+  __shared__ float red[NW][2][256];
+  __shared__ unsigned long long sh_w;
+  __shared__ int sh_rank_ok;
+  static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
+  const int lane = threadIdx.x & 63;
+  const int K = r.K, E = r.E;
+  // block 0 is the meta block: it must be dispatched FIRST — when the grid exceeds one resident wave of blocks
+  // (Mixtral: 1793 blocks, 6 per CU) a meta block at the end of the grid would start only when a slot frees up and
+  // put its ~5 us of serial work (generic router, index, PCIe mirror writes) behind the weight stream's tail
+  int b = (int)blockIdx.x - 1;
+  if (b >= 0 && b < n_sh2) {  // shared expert, stage 2 (h_shared was written by the gate launch)
+    const char* Wsh = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
+    ffn_rows_item<T, 1, NW, U, 1>(sh2, b, Wsh, true, 1, 0, reinterpret_cast<float (*)[1][256]>(&red[0][0][0]));
+    return;
+  }
+  b -= n_sh2;
+  if (b < 0) {  // meta block: one wave
+    if (threadIdx.x < 64) {
+      int* scratch = reinterpret_cast<int*>(&red[0][0][0]);
+      Routed o;
+      route_core(r, 0, lane, o);
+      int my_sel, rank;
+      float my_w;
+      route_store(r, 0, lane, o, &my_sel, &my_w, &rank);
+      if (lane < K && s.dec_w) {  // batch-1 records for stage 2: blob pointer and combine weight by ascending expert id
+        s.dec_w[rank] = my_sel >= 0 ? s.wptr[my_sel] : 0ull;
+        s.dec_cw[rank] = my_w;
+      }
+      __threadfence_block();
+      index_small(a, scratch, scratch + IDX_MAXE);
+    }
+    return;
+  }
+  const int u = b / n_rg, rg = b - u * n_rg;
+  // ONE wave per block routes; the blob pointer travels through LDS.  (The generic route_core is > 1000 instructions
+  // on this path — every router family, four experts per lane — and cost ~5 us in front of the weight stream;
+  // route_set_lean is ~100-200.)
+  if (threadIdx.x < 64) {
+    // independent first round: the token's logits and all blob pointers
+    uint64_t wp = 0;
+    if (lane < E) wp = s.wptr[lane];
+    uint64_t chosen = route_set_lean(r.logits, E, K, lane);
+    for (int i = 0; i < u; ++i) chosen &= chosen - 1;  // drop the u smallest ids
+    const int e = chosen ? (int)__builtin_ctzll(chosen) : -1;
+    uint64_t wsel = 0;
+    if (e >= 0) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wp, e);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wp >> 32), e);
+      wsel = ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) { sh_w = wsel; sh_rank_ok = e >= 0; }
+  }
+  __syncthreads();
+  if (!sh_rank_ok) return;  // fewer than K experts selected (never with the supported routers)
+  const char* W = reinterpret_cast<const char*>(sh_w);
+  if (W == nullptr) {  // never on the sync-free path
+    if (threadIdx.x == 0 && rg == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  // T == 1: expert-sorted row of (token 0, expert e) = its rank u; the B operand is token 0
+  ffn_rows_item<T, 2, NW, U, 1>(s, rg, W, false, 1, u, red, 0);
+}
+
+hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st) {
+  const int n_rg = (s1.R + 15) / 16;
+  const int n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
+  const dim3 grid(n_sh2 + r.K * n_rg + 1);
+  hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+  return hipGetLastError();
+}
+
+// Stage 2 of a batch-1 self-routed forward, with the combine in its tail.  Differences from ffn_rows_kernel's fused
+// form: one scalar round in the prologue (blob pointer dec_w[u] instead of active[u] -> {wptr, counts, offsets}); the
+// combine weights (dec_cw, ascending expert id = rows 0..K-1 of y) are fetched at kernel START, so the last-arriving
+// block's tail is one round of row loads instead of three dependent rounds (order -> slot/weight -> rows).
+template <typename T, int NW, int U>
+__global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
+  __shared__ float red[NW][1][256];
+  __shared__ int is_last;
+  const int u = blockIdx.y, tid = threadIdx.x;
+  const int K = s.comb.K;
+  const char* W = reinterpret_cast<const char*>(s.dec_w[u]);
+  CombineMeta m;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) { m.slot[kk] = min(kk, K - 1); m.w[kk] = s.dec_cw[min(kk, K - 1)]; }
+  const int r0 = blockIdx.x * 16;
+  if (W == nullptr && tid == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+  ffn_rows_item<T, 1, NW, U, 1>(s, blockIdx.x, W, false, W ? 1 : 0, u, red);
+  wait_stores_acked();  // this thread's (write-through) y stores have reached device-coherent memory
+  __syncthreads();
+  if (tid == 0) is_last = (__hip_atomic_fetch_add(&s.tile_done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == K - 1);
+  __syncthreads();
+  if (is_last) {
+    if (tid < 4) combine_apply<T, true>(s.comb, 0, r0 + tid * 4, m);
+    if (tid == 0) s.tile_done[blockIdx.x] = 0;
+  }
+}
+
+hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
+  const dim3 grid((s2.R + 15) / 16, s2.comb.K);
+  const size_t kbytes = (size_t)s2.K * 2;
+  if (kbytes >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);
+  else hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, s2);
   return hipGetLastError();
 }
 

@@ -627,3 +627,67 @@ def test_long_prefill_index_over_many_workgroups(family, t, e, k):
     _check_dispatch_index(r, ref)
     assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block")
     eng.close()
+
+
+@pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 64, 6, 2), ("deepseek", 16, 4, 0), ("mixtral", 128, 8, 0)],
+                         ids=["mixtral_e8k2", "deepseek_e64k6_shared", "deepseek_e16k4", "mixtral_e128k8"])
+def test_batch1_decode_selfrouting_stage1(family, e, k, n_shared):
+    """Batch-1 decode on the sync-free path (every expert resident): FFN stage 1 routes for itself from the gate
+    logits (no top-k/index launch; ffn1_selfroute_kernel) and one extra block of that launch writes the routing
+    outputs.  Checked against the oracle: routing, dispatch index, routing weights, expert rows, block output; a
+    repeated forward must be bit-identical.  e = 128 takes the dependent blob-pointer load (more experts than lanes)."""
+    h, f = 512, 384
+    gate, experts, shared = make_weights(family, h, f, e, 4100 + e, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=4)
+    register_all(eng, experts, shared)
+    g = gate.to(DEV)
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    for seed in range(6):
+        x = acts(1, h, torch.bfloat16, 4200 + seed)
+        if family == "mixtral":
+            ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+        else:
+            ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+        outs = []
+        for rep in range(2):
+            out = eng.forward(0, x.to(DEV), g)
+            r = _check_routing_exact(eng, ref, k_sorted=(family == "mixtral"))
+            _check_dispatch_index(r, ref)
+            got = {int(i): float(w) for i, w in zip(r["topk_idx"][0], r["topk_w"][0])}
+            want = {int(i): float(w) for i, w in zip(ref.topk_idx[0], ref.topk_w[0])}
+            for i in want:
+                assert abs(got[i] - want[i]) <= 2e-6 * max(1.0, abs(want[i])), (i, got[i], want[i])
+            rows = oracle_expert_rows(ref, e)
+            assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+            assert_block_close(out, ref, torch.bfloat16, f"{family} batch-1 block output")
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1])
+    assert eng.stats()["expert_misses"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("family,e,k", [("mixtral", 8, 2), ("deepseek", 16, 6)])
+def test_batch1_selfrouting_ties_lowest_index(family, e, k):
+    """Exact ties in front of the self-routing kernel's own top-k (route_set_lean): identical gate rows -> identical
+    probabilities -> the lowest expert id wins, in every block of the launch alike (a disagreement between blocks would
+    stream the wrong expert's rows)."""
+    h, f = 256, 256
+    gate, experts, _ = make_weights(family, h, f, e, 77, torch.bfloat16)
+    for dup in (1, 3, e - 1, e - 3):
+        gate[dup] = gate[2]
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, max_tokens=2)
+    register_all(eng, experts)
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    hits = 0
+    for seed in range(24):
+        x = acts(1, h, torch.bfloat16, 5000 + seed)
+        ref = R.block_mixtral(x[None], gate, experts, top_k=k) if family == "mixtral" else R.block_deepseek(x[None], gate, experts, k)
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        r = _check_routing_exact(eng, ref, k_sorted=(family == "mixtral"))
+        _check_dispatch_index(r, ref)
+        assert_block_close(out, ref, torch.bfloat16, "block output with tied experts")
+        hits += int(2 in set(int(v) for v in ref.topk_idx[0]))
+    assert hits > 0, "the tied group never reached the top-k: the test exercises nothing"
+    eng.close()
