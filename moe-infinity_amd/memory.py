@@ -84,3 +84,31 @@ class ExpertPrefetcher:
             self.archer_engine.prefetch(int(ls[i]), es[i:j].tolist(), sc[i:j].tolist())
             i = j
         return ls, es, sc
+
+    def prefetch_experts_by_priority(self, layer_id, expert_freq, eam, max_experts=None):
+        """Speculative requests for the layers AFTER ``layer_id`` ordered by the reference's ``priority_score``
+        (expert_priority_score.py:85-172: layer decay x the running sequence's EAM x visit frequency) — the scoring
+        module the reference ships but never calls.  Scores travel to the engine with the request, where they pick
+        the queue level (csrc/prefetch_queue.h), so a later, better-scored request overtakes a waiting one.
+        ``expert_freq``: {(expert, layer): visits} (e.g. from get_hit_rate); ``eam``: the running sequence's [L, E]
+        activation matrix (ExpertTracer.get_entry_matrix)."""
+        from . import priority_score as PS
+
+        entry = PS.ExpertTraceEntry("running", np.array(eam, dtype=np.float64, copy=True), 1, 0)
+        scored = [c for c in PS.priority_score(expert_freq, set(), set(), entry, layer_id, self.num_layers, inplace=False)
+                  if c.layer_idx > layer_id]
+        scored.sort(key=lambda c: (-c.r, c.layer_idx, c.expert_idx))
+        if max_experts is not None:
+            scored = scored[:max_experts]
+        if not scored:
+            return []
+        top = scored[0].r
+        self.archer_engine.protect([(c.layer_idx, c.expert_idx) for c in scored])
+        i = 0
+        while i < len(scored):  # one layer per C-ABI call, global order kept
+            j = i
+            while j < len(scored) and scored[j].layer_idx == scored[i].layer_idx:
+                j += 1
+            self.archer_engine.prefetch(scored[i].layer_idx, [c.expert_idx for c in scored[i:j]], [float(c.r / top) for c in scored[i:j]])
+            i = j
+        return scored
