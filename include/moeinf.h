@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MOEINF_ABI_VERSION 2
+#define MOEINF_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -122,6 +122,7 @@ typedef struct moeinf_stats {
   int64_t host_evictions;     /* host blobs dropped from the pinned arena (re-readable from the offload directory) */
   int64_t disk_reads;         /* experts read disk -> pinned host */
   int64_t disk_bytes;
+  int64_t disk_reads_async;   /* of those, started in the background at low priority by a speculative request */
 } moeinf_stats;
 
 /* ---- errors ------------------------------------------------------------------------------ */
@@ -344,6 +345,25 @@ int moeinf_pq_pop(moeinf_pq* q, int64_t* node, int32_t* layer, int32_t* priority
 int moeinf_pq_snapshot(const moeinf_pq* q, int64_t* nodes, int32_t* layers, int32_t* priorities, int capacity, int32_t* n);
 /* prefetch score in (0,1] -> queue level 1..19 (moeinf_prefetch with scores) */
 int moeinf_priority_from_score(float score, int32_t* level);
+
+/* ---- two-priority block reader of the disk tier, standalone (host only, no GPU) ----------------
+ * ArcherPrioAioHandle::Read(filename, buffer, high_prio, num_bytes, offset) (core/aio/archer_prio_aio_handle.cpp:37-71):
+ * reads are cut into blocks (the reference: 1 MiB, :13); worker threads serve HIGH-priority blocks before any LOW one
+ * (:123-169), so an on-demand read waits for at most the low blocks already in flight.  submit never blocks (the
+ * reference's Read does: call moeinf_aio_wait right after it for that behaviour); promote moves a low request's
+ * unstarted blocks to the high queue (a speculative read whose expert is demanded).  try_direct: O_DIRECT when dst and
+ * offset are 4 KiB-aligned (the read is then rounded up to 4 KiB: dst must have room), buffered where the filesystem
+ * refuses.  The engine reads expert blobs through the same object (experts registered with
+ * moeinf_register_expert_from_store: demand misses HIGH, speculative requests LOW and in the background). */
+typedef struct moeinf_aio moeinf_aio;
+int moeinf_aio_create(int threads, int64_t block_bytes, moeinf_aio** out);
+int moeinf_aio_destroy(moeinf_aio* a);
+int moeinf_aio_submit_read(moeinf_aio* a, const char* path, void* dst, int64_t nbytes, int64_t offset, int high_prio,
+                           int try_direct, int64_t* request);
+int moeinf_aio_promote(moeinf_aio* a, int64_t request);
+int moeinf_aio_done(moeinf_aio* a, int64_t request, int32_t* done);
+int moeinf_aio_wait(moeinf_aio* a, int64_t request); /* blocks; forgets the request; error = first failed block */
+int moeinf_aio_stats(const moeinf_aio* a, int64_t out[5]); /* blocks_high, blocks_low, bytes, promoted, direct_fallbacks */
 
 /* ---- expert-parallel exchange helpers (multi-GPU) ---------------------
  * Pack routed rows for an all-to-all and unpack the replies.  The collective itself (RCCL

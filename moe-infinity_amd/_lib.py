@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 2  # include/moeinf.h MOEINF_ABI_VERSION
+ABI_VERSION = 3  # include/moeinf.h MOEINF_ABI_VERSION
 
 
 class MoeInfError(RuntimeError):
@@ -40,7 +40,7 @@ class Stats(C.Structure):
         ("host_arena_bytes", C.c_int64), ("h2d_busy_ms", C.c_double), ("exposed_wait_ms", C.c_double),
         ("prefetch_queued", C.c_int64), ("prefetch_cancelled", C.c_int64), ("prefetch_dropped", C.c_int64),
         ("prefetch_wasted", C.c_int64), ("inflight_hits", C.c_int64), ("host_evictions", C.c_int64),
-        ("disk_reads", C.c_int64), ("disk_bytes", C.c_int64),
+        ("disk_reads", C.c_int64), ("disk_bytes", C.c_int64), ("disk_reads_async", C.c_int64),
     ]
 
     def as_dict(self):
@@ -116,6 +116,13 @@ PROTOTYPES = {
     "moeinf_cache_sim_access": (C.c_int, [_P, C.c_int64, _I32P, _I64P]),
     "moeinf_cache_sim_protect": (C.c_int, [_P, _I64P, C.c_int]),
     "moeinf_cache_sim_clear_counts": (C.c_int, [_P]),
+    "moeinf_aio_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(_P)]),
+    "moeinf_aio_destroy": (C.c_int, [_P]),
+    "moeinf_aio_submit_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _I64P]),
+    "moeinf_aio_promote": (C.c_int, [_P, C.c_int64]),
+    "moeinf_aio_done": (C.c_int, [_P, C.c_int64, _I32P]),
+    "moeinf_aio_wait": (C.c_int, [_P, C.c_int64]),
+    "moeinf_aio_stats": (C.c_int, [_P, _I64P]),
     "moeinf_pq_create": (C.c_int, [C.POINTER(_P)]),
     "moeinf_pq_destroy": (C.c_int, [_P]),
     "moeinf_pq_enqueue": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _I32P]),

@@ -22,6 +22,9 @@
 #include "../../include/moeinf.h"
 #include "cache_policy.h"
 #include "kernels.h"
+#include <map>
+#include <mutex>
+#include "aio_pool.h"
 #include "offload_store.h"
 #include "prefetch_queue.h"
 #include "tracer.h"
@@ -132,6 +135,10 @@ struct Node {
   const OffloadStore* store = nullptr;
   uint32_t store_ids[4] = {0, 0, 0, 0};
   uint64_t host_clock = 0;     // last time the host blob was needed (host-tier LRU)
+  // a disk -> pinned-host read in flight on the priority block reader (speculative requests read at LOW priority in
+  // the background; a demand promotes and waits): the blob becomes `host` once every tensor's request has finished
+  void* host_pending = nullptr;
+  std::vector<PrioAioPool::Handle> disk_reqs;
 };
 struct Slot {
   void* dev = nullptr;
@@ -186,6 +193,9 @@ struct moeinf_engine {
 
   // pending speculative transfers (reference: ArcherTaskPool's unified_queue_) and the copies in flight
   PrefetchQueue pq;
+  std::unique_ptr<PrioAioPool> aio;   // disk tier reader (created with the first expert registered from a store)
+  std::deque<QueuedTask> disk_inflight;  // speculative tasks whose host blob is being read from disk (low priority)
+  int disk_window = 2;                // such reads in flight at most
   std::deque<int> prefetch_inflight;  // node indices whose copy was issued on the prefetch lane, oldest first
   int prefetch_window = 2;            // experts in flight on the prefetch lane at most
   std::vector<void*> host_free;       // arena blocks returned by host-tier eviction
@@ -356,6 +366,8 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
   hipSetDevice(g->cfg.device_id);
   hipDeviceSynchronize();
+  for (auto& n : g->nodes) { for (auto& h : n.disk_reqs) PrioAioPool::wait(h); n.disk_reqs.clear(); }  // reads into the arena
+  g->aio.reset();
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
   for (auto p : g->arena_chunks) hipHostFree(p);
@@ -730,11 +742,17 @@ static void settle_copy_timers(moeinf_engine* g, bool wait) {
 // (cfg.host_memory_bytes — the reference's host_memory_ratio, memory_pool.cpp:150-158) and full, the least recently
 // needed host blob that can be re-read from disk gives up its arena block (reference: Node::SetDevice(DISK),
 // model_topology.cpp:76-88) and the wanted expert is read disk -> pinned host (-> HBM by the caller).
-static int ensure_host(moeinf_engine* g, int idx) {
-  Node& n = g->nodes[idx];
-  n.host_clock = ++g->host_clock;
-  if (n.host) return MOEINF_OK;
-  if (!n.store) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) has no host copy and no disk copy", idx % g->L, idx / g->L);
+static PrioAioPool* aio_pool(moeinf_engine* g) {
+  if (!g->aio) {
+    const char* t = getenv("MOEINF_AIO_THREADS");
+    g->aio.reset(new PrioAioPool(t ? atoi(t) : 4));
+  }
+  return g->aio.get();
+}
+
+// an arena block for node idx's host blob: free list -> grow under the cap -> drop the least recently needed host blob
+// that can be re-read from disk
+static int alloc_host_block(moeinf_engine* g, int idx, void** out) {
   void* blk = nullptr;
   if (!g->host_free.empty()) {
     blk = g->host_free.back();
@@ -766,16 +784,70 @@ static int ensure_host(moeinf_engine* g, int idx) {
     g->nodes[victim].host = nullptr;
     g->st.host_evictions += 1;
   }
+  *out = blk;
+  return MOEINF_OK;
+}
+
+// submit the reads of every tensor of node idx's blob into `blk` (each tensor's region in the blob is 4 KiB aligned and
+// padded -> eligible for O_DIRECT)
+static int submit_host_read(moeinf_engine* g, int idx, void* blk, bool high) {
+  Node& n = g->nodes[idx];
+  PrioAioPool* pool = aio_pool(g);
+  n.disk_reqs.clear();
   for (int i = 0; i < g->lay.n; ++i) {
-    // each tensor's region in the blob is 4 KiB aligned and padded -> eligible for O_DIRECT
     const uint64_t room = (uint64_t)((i + 1 < g->lay.n ? g->lay.off[i + 1] : g->lay.total) - g->lay.off[i]);
-    const std::string err = n.store->get(n.store_ids[i], (char*)blk + g->lay.off[i], room);
-    if (!err.empty()) { g->host_free.push_back(blk); return fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
+    char* dst = (char*)blk + g->lay.off[i];
+    OffloadStore::ReadPlan rp;
+    const std::string err = n.store->plan_read(n.store_ids[i], dst, room, &rp);
+    if (!err.empty()) {
+      for (auto& h : n.disk_reqs) PrioAioPool::wait(h);
+      n.disk_reqs.clear();
+      return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+    }
+    n.disk_reqs.push_back(pool->submit(rp.path, dst, (int64_t)rp.size, rp.offset, high, rp.direct_ok));
   }
+  n.host_pending = blk;
+  return MOEINF_OK;
+}
+
+// wait for node idx's pending disk read and adopt the blob
+static int finish_host_read(moeinf_engine* g, int idx) {
+  Node& n = g->nodes[idx];
+  std::string err;
+  for (auto& h : n.disk_reqs) {
+    const std::string e = PrioAioPool::wait(h);
+    if (err.empty()) err = e;
+  }
+  n.disk_reqs.clear();
+  void* blk = n.host_pending;
+  n.host_pending = nullptr;
+  if (!err.empty()) { g->host_free.push_back(blk); return fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
   g->st.disk_reads += 1;
   g->st.disk_bytes += g->lay.total;
   n.host = blk;
   return MOEINF_OK;
+}
+static bool host_read_done(const Node& n) {
+  for (auto& h : n.disk_reqs) if (!PrioAioPool::done(h)) return false;
+  return true;
+}
+
+static int ensure_host(moeinf_engine* g, int idx) {
+  Node& n = g->nodes[idx];
+  n.host_clock = ++g->host_clock;
+  if (n.host) return MOEINF_OK;
+  if (!n.store) return fail(MOEINF_ERR_STATE, "expert (layer %d, expert %d) has no host copy and no disk copy", idx % g->L, idx / g->L);
+  if (n.host_pending) {  // a speculative read of this blob is under way: it is needed now
+    for (auto& h : n.disk_reqs) g->aio->promote(h);
+    for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end(); ++it)
+      if ((int)it->node == idx) { g->disk_inflight.erase(it); break; }
+    return finish_host_read(g, idx);
+  }
+  void* blk = nullptr;
+  CHK(alloc_host_block(g, idx, &blk));
+  const int rc = submit_host_read(g, idx, blk, /*high=*/true);  // all tensors at once: the workers read them in parallel
+  if (rc != MOEINF_OK) { g->host_free.push_back(blk); return rc; }
+  return finish_host_read(g, idx);
 }
 
 // ---- the hot path --------------------------------------------------------------------------
@@ -786,7 +858,7 @@ static inline void drop_stale_prefetches(moeinf_engine* g, int layer) {
   if (!g->pq.empty()) g->st.prefetch_cancelled += g->pq.on_demand(-1, layer);
 }
 static inline int pump_if_pending(moeinf_engine* g) {
-  if (g->pq.empty() && g->prefetch_inflight.empty()) return MOEINF_OK;
+  if (g->pq.empty() && g->prefetch_inflight.empty() && g->disk_inflight.empty()) return MOEINF_OK;
   return pump_prefetch(g);
 }
 static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
@@ -1346,10 +1418,39 @@ static int pump_prefetch(moeinf_engine* g) {
   }
   while ((int)g->prefetch_inflight.size() < g->prefetch_window) {
     QueuedTask t;
-    if (!g->pq.pop(&t)) break;
+    bool have = false;
+    // speculative tasks whose host blob has arrived from disk go first (oldest first); unfinished ones stay parked
+    for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end(); ++it) {
+      Node& dn = g->nodes[(int)it->node];
+      if (dn.host) { t = *it; g->disk_inflight.erase(it); have = true; break; }  // adopted by a demand meanwhile
+      if (dn.host_pending && host_read_done(dn)) {
+        t = *it;
+        g->disk_inflight.erase(it);
+        CHK(finish_host_read(g, (int)t.node));
+        have = true;
+        break;
+      }
+    }
+    if (!have && !g->pq.pop(&t)) break;
     const int idx = (int)t.node;
     Node& nd = g->nodes[idx];
     if (nd.slot >= 0) continue;  // became resident (demand fetch) while it waited
+    if (!nd.host && nd.store && !nd.host_pending) {
+      // the blob is on disk only: read it in the background at LOW priority (the reference's prefetch thread does the
+      // disk leg at low priority too, archer_prio_aio_handle.cpp:150-166) instead of stalling this call on a pread;
+      // the H2D copy is issued by a later pump once the blob has landed
+      if ((int)g->disk_inflight.size() >= g->disk_window) { g->pq.enqueue(t.node, t.layer, t.priority); break; }
+      void* blk = nullptr;
+      const int arc = alloc_host_block(g, idx, &blk);
+      if (arc == MOEINF_ERR_OOM) { g->st.prefetch_dropped += 1; continue; }
+      if (arc != MOEINF_OK) return arc;
+      const int src = submit_host_read(g, idx, blk, /*high=*/false);
+      if (src != MOEINF_OK) { g->host_free.push_back(blk); return src; }
+      g->disk_inflight.push_back(t);
+      g->st.disk_reads_async += 1;
+      continue;
+    }
+    if (nd.host_pending) continue;  // already parked in disk_inflight by an earlier request
     // a speculative copy never evicts the protected set (candidates_, task_scheduler.cpp:292-297) nor an expert of
     // the layer being dispatched; if nothing can be freed the task is dropped ("evict failed", :505-510)
     g->pol[idx].pinned = true;
@@ -1421,7 +1522,9 @@ extern "C" int moeinf_sync_copies(moeinf_engine* g) {
       HIPCHK(hipStreamSynchronize(ln->copy));
       HIPCHK(hipStreamSynchronize(ln->retile));
     }
-    if (g->pq.empty()) break;
+    if (g->pq.empty() && g->disk_inflight.empty()) break;
+    // speculative blobs still on their way from disk: wait for the oldest, the next pump issues its H2D copy
+    if (!g->disk_inflight.empty()) { Node& dn = g->nodes[(int)g->disk_inflight.front().node]; for (auto& h : dn.disk_reqs) PrioAioPool::wait(h); }
   }
   CHK(pump_prefetch(g));
   settle_copy_timers(g, true);
@@ -1737,6 +1840,65 @@ extern "C" int moeinf_pq_snapshot(const moeinf_pq* q, int64_t* nodes, int32_t* l
 extern "C" int moeinf_priority_from_score(float score, int32_t* level) {
   if (!level) return fail(MOEINF_ERR_INVALID, "level is NULL");
   *level = priority_from_score(&score, 0);
+  return MOEINF_OK;
+}
+
+// ---- priority block reader, standalone (host only) -------------------------------------------
+struct moeinf_aio {
+  PrioAioPool pool;
+  std::mutex mu;
+  std::map<int64_t, PrioAioPool::Handle> reqs;
+  int64_t next = 1;
+  moeinf_aio(int threads, int64_t block) : pool(threads, block) {}
+};
+extern "C" int moeinf_aio_create(int threads, int64_t block_bytes, moeinf_aio** out) {
+  if (!out || threads <= 0 || block_bytes <= 0) return fail(MOEINF_ERR_INVALID, "bad aio arguments");
+  *out = new moeinf_aio(threads, block_bytes);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_aio_destroy(moeinf_aio* a) { delete a; return MOEINF_OK; }
+extern "C" int moeinf_aio_submit_read(moeinf_aio* a, const char* path, void* dst, int64_t nbytes, int64_t offset, int high_prio, int try_direct, int64_t* request) {
+  if (!a || !path || !dst || !request || nbytes < 0 || offset < 0) return fail(MOEINF_ERR_INVALID, "bad aio read arguments");
+  auto h = a->pool.submit(path, dst, nbytes, offset, high_prio != 0, try_direct != 0);
+  std::lock_guard<std::mutex> lk(a->mu);
+  *request = a->next++;
+  a->reqs[*request] = h;
+  return MOEINF_OK;
+}
+static PrioAioPool::Handle aio_find(moeinf_aio* a, int64_t request, bool take) {
+  std::lock_guard<std::mutex> lk(a->mu);
+  auto it = a->reqs.find(request);
+  if (it == a->reqs.end()) return nullptr;
+  auto h = it->second;
+  if (take) a->reqs.erase(it);
+  return h;
+}
+extern "C" int moeinf_aio_promote(moeinf_aio* a, int64_t request) {
+  if (!a) return fail(MOEINF_ERR_INVALID, "aio is NULL");
+  auto h = aio_find(a, request, false);
+  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
+  a->pool.promote(h);
+  return MOEINF_OK;
+}
+extern "C" int moeinf_aio_done(moeinf_aio* a, int64_t request, int32_t* done) {
+  if (!a || !done) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  auto h = aio_find(a, request, false);
+  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
+  *done = PrioAioPool::done(h) ? 1 : 0;
+  return MOEINF_OK;
+}
+extern "C" int moeinf_aio_wait(moeinf_aio* a, int64_t request) {
+  if (!a) return fail(MOEINF_ERR_INVALID, "aio is NULL");
+  auto h = aio_find(a, request, true);
+  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
+  const std::string err = PrioAioPool::wait(h);
+  if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
+  return MOEINF_OK;
+}
+extern "C" int moeinf_aio_stats(const moeinf_aio* a, int64_t out[5]) {
+  if (!a || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  const auto s = a->pool.stats();
+  out[0] = s.blocks_high; out[1] = s.blocks_low; out[2] = s.bytes; out[3] = s.promoted; out[4] = s.direct_fallbacks;
   return MOEINF_OK;
 }
 

@@ -9,9 +9,9 @@
 //   <prefix>/archer_param_<file_id>   tensor payloads at 4 KiB-aligned offsets, appended in store order
 //        (archer_tensor_handle.cpp:53-86, kAioAlignment = 4096, archer_prio_aio_handle.h:18)
 // Differences in mechanism, not format: the reference funnels every read through one AIO thread
-// with O_DIRECT 1 MiB blocks (archer_prio_aio_handle.cpp:123-169); here reads are plain pread()s in
-// large blocks straight into the (4 KiB-aligned) pinned arena, O_DIRECT when the kernel accepts it,
-// and several experts can be read concurrently by the caller's threads.
+// with O_DIRECT 1 MiB blocks (archer_prio_aio_handle.cpp:123-169).  Here get() is a plain pread() loop in large
+// blocks straight into the (4 KiB-aligned) destination, O_DIRECT when the kernel accepts it; the engine's expert
+// reads go through the two-priority block reader of aio_pool.h (plan_read() tells it where the payload is).
 #pragma once
 #include <errno.h>
 #include <fcntl.h>
@@ -203,6 +203,19 @@ class OffloadStore {
       done += (uint64_t)r;
     }
     ::close(fd);
+    return "";
+  }
+
+  // where a tensor's payload lives, for readers that bring their own I/O (the priority block reader, aio_pool.h)
+  struct ReadPlan { std::string path; int64_t offset = 0; uint64_t size = 0; bool direct_ok = false; };
+  std::string plan_read(uint32_t id, const void* dst, uint64_t capacity, ReadPlan* out) const {
+    const TensorMeta* m = find(id);
+    if (!m) return "tensor " + std::to_string(id) + " not in archer_index";
+    if (capacity < m->size) return "destination too small for tensor " + std::to_string(id);
+    out->path = param_path(m->file_id);
+    out->offset = m->offset;
+    out->size = m->size;
+    out->direct_ok = ((uintptr_t)dst % kAlign == 0) && capacity >= (uint64_t)align_up((int64_t)m->size) && (m->offset % kAlign == 0);
     return "";
   }
 

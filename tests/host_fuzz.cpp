@@ -1,4 +1,4 @@
-// host_fuzz.cpp — drives the host-only components of the engine (cache policy, tracer, offload store)
+// host_fuzz.cpp — drives the host-only components of the engine (cache policy, tracer, offload store, priority reader)
 // under AddressSanitizer + UBSan ("new engine should run its host tests under
 // TSan/ASan").  Built and run by tests/test_host_sanitizers.py; no HIP.
 #include <stdio.h>
@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "aio_pool.h"
 #include "cache_policy.h"
 #include "offload_store.h"
 #include "tracer.h"
@@ -86,6 +87,32 @@ int main(int argc, char** argv) {
       std::vector<char> un(m->size + 1);
       REQUIRE(rd.get(id * 3, un.data() + 1, m->size).empty());
       REQUIRE(memcmp(un.data() + 1, payloads[id].data(), m->size) == 0);
+    }
+    // the same payloads through the two-priority block reader: mixed priorities, promotions, several threads
+    {
+      PrioAioPool pool(3, 8192);
+      struct Pending { PrioAioPool::Handle h; void* buf; uint32_t id; };
+      std::vector<Pending> pend;
+      for (int round = 0; round < 3; ++round) {
+        for (uint32_t id = 0; id < 25; ++id) {
+          const TensorMeta* m = rd.find(id * 3);
+          const uint64_t cap = ((m->size + 4095) / 4096) * 4096;
+          void* al = nullptr;
+          REQUIRE(posix_memalign(&al, 4096, cap) == 0);
+          OffloadStore::ReadPlan rp;
+          REQUIRE(rd.plan_read(id * 3, al, cap, &rp).empty());
+          pend.push_back({pool.submit(rp.path, al, (int64_t)rp.size, rp.offset, (rng() & 3) == 0, rp.direct_ok), al, id});
+          if ((rng() & 7) == 0) pool.promote(pend[rng() % pend.size()].h);
+        }
+      }
+      for (auto& p : pend) {
+        REQUIRE(PrioAioPool::wait(p.h).empty());
+        REQUIRE(memcmp(p.buf, payloads[p.id].data(), payloads[p.id].size()) == 0);
+        free(p.buf);
+      }
+      REQUIRE(pool.stats().blocks_high + pool.stats().blocks_low > 75);
+      char tmp[16];
+      REQUIRE(!PrioAioPool::wait(pool.submit(dir + "/no_such_file", tmp, 16, 0, true, false)).empty());
     }
     REQUIRE(!rd.get(999, payloads[0].data(), 10).empty());
     std::vector<char> small(4);

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(PROTOTYPES), declared ^ set(PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), f"libmoeinf_hip.so does not export {name}"
-    assert lib.moeinf_abi_version() == 2
+    assert lib.moeinf_abi_version() == 3
 
 
 def test_struct_sizes_match_header():
@@ -39,7 +39,7 @@ def test_struct_sizes_match_header():
 
     # 17 int32/float fields + alignment + double + 2 int64 + 4 int32 (see include/moeinf.h)
     assert C.sizeof(Config) == 17 * 4 + 4 + 8 + 16 + 16
-    assert C.sizeof(Stats) == 21 * 8
+    assert C.sizeof(Stats) == 22 * 8
 
 
 def test_no_gpu_fails_loudly():

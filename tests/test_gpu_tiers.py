@@ -180,6 +180,55 @@ def test_pinned_arena_is_a_cache_over_the_offload_directory(tmp_path):
     st.close()
 
 
+def test_speculative_requests_read_disk_only_experts_in_the_background(tmp_path):
+    """A speculative request for an expert whose blob is on disk only must not stall the caller on a pread: the blob is
+    read by the priority block reader at LOW priority (csrc/aio_pool.h), a later pump issues the H2D copy; a demand
+    for an expert whose background read is still under way promotes that read and waits for it instead of reading the
+    bytes twice.  Results never change."""
+    from moe_infinity_amd.offload_store import OffloadStore
+
+    h, f, e, k, t = 256, 512, 8, 2, 6
+    gate, experts, _ = make_weights("mixtral", h, f, e, 1700, torch.bfloat16)
+    st = OffloadStore(str(tmp_path))
+    ids, tid = {}, 10
+    for i, ex in enumerate(experts):
+        ids[i] = []
+        for w in ex:
+            st.offload(w, tid)
+            ids[i].append(tid)
+            tid += 1
+    st.close()
+    st = OffloadStore(str(tmp_path))
+    blob = 3 * f * h * 2
+    eng = _mixtral_engine(1, e, h, f, k, 8, t, host_memory_bytes=5 * blob)  # arena: 5 of 8 blobs; HBM: all 8
+    for i in range(e):
+        st.register_expert(eng, 0, i, ids[i])
+    r0 = eng.stats()["disk_reads"]
+    assert r0 == 5, "registration reads blobs while the arena has room, the rest stay on disk"
+    eng.prefetch(0, [5, 6, 7])  # on disk only: background reads (two at a time), no copy yet
+    s0 = eng.stats()
+    assert s0["disk_reads_async"] >= 1 and s0["prefetch_issued"] == 0 and s0["disk_reads"] == r0, "the caller must not have waited for a pread"
+    # demand every expert right away (background reads finished, running or not started)
+    x = acts(t, h, torch.bfloat16, 1710)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    assert_block_close(out, ref, torch.bfloat16, "demand racing background disk reads")
+    eng.sync_copies()
+    s = eng.stats()
+    assert s["disk_bytes"] == s["disk_reads"] * blob
+    # every read beyond the first 8 is explained by a blob the 5-blob arena had to drop; a blob whose background read was
+    # under way when it was demanded is promoted and adopted, not read a second time
+    assert s["disk_reads"] <= e + s["host_evictions"], (s["disk_reads"], s["host_evictions"])
+    used = sorted(set(int(v) for v in ref.topk_idx.reshape(-1)))
+    for i in set(used) | {5, 6, 7}:
+        assert eng.is_resident(0, i), f"expert {i} (dispatched or speculatively requested) never reached the device"
+    for step in range(3):
+        x = acts(t, h, torch.bfloat16, 1720 + step)
+        assert_block_close(eng.forward(0, x.to(DEV), gate.to(DEV)), R.block_mixtral(x[None], gate, experts, top_k=k), torch.bfloat16, f"step {step}")
+    eng.close()
+    st.close()
+
+
 def test_dense_mask_with_more_than_k_experts_per_token_is_rejected_without_overrun():
     """the mask-index kernel bounds its writes by the workspace capacity; the host then reports
     the overflow."""
