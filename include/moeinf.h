@@ -123,6 +123,7 @@ typedef struct moeinf_stats {
   int64_t disk_reads;         /* experts read disk -> pinned host */
   int64_t disk_bytes;
   int64_t disk_reads_async;   /* of those, started in the background at low priority by a speculative request */
+  int64_t prefetch_throttled; /* speculative requests not started because the governor found speculation unprofitable */
 } moeinf_stats;
 
 /* ---- errors ------------------------------------------------------------------------------ */
@@ -226,6 +227,12 @@ int moeinf_sync_copies(moeinf_engine* eng);
 /* DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink (evicting by
  * the replacement policy, freeing the slots' memory) or grow the expert cache.  Synchronises the device. */
 int moeinf_set_cache_budget(moeinf_engine* eng, int64_t device_memory_bytes);
+/* Speculation governor (no counterpart in the reference, whose prefetcher enqueues everything it predicts).  The engine
+ * keeps a running average of how speculative copies END — dispatched before eviction (1) or evicted unused (0); once 8
+ * have ended and the average is below min_useful_fraction, speculative requests are dropped except one probe in
+ * probe_every.  0 switches it off (default).  Independent of it, a speculative copy is never STARTED while an
+ * on-demand copy is on the link. */
+int moeinf_set_prefetch_governor(moeinf_engine* eng, float min_useful_fraction, int probe_every);
 /* Grow the token-sized workspace to hold forwards of up to max_tokens tokens (the reference's dispatcher allocates per
  * call and has no such limit; expert_dispatcher.set_inputs grows it on demand).  Only grows; synchronises the device. */
 int moeinf_reserve_tokens(moeinf_engine* eng, int max_tokens);

@@ -41,6 +41,7 @@ class Stats(C.Structure):
         ("prefetch_queued", C.c_int64), ("prefetch_cancelled", C.c_int64), ("prefetch_dropped", C.c_int64),
         ("prefetch_wasted", C.c_int64), ("inflight_hits", C.c_int64), ("host_evictions", C.c_int64),
         ("disk_reads", C.c_int64), ("disk_bytes", C.c_int64), ("disk_reads_async", C.c_int64),
+        ("prefetch_throttled", C.c_int64),
     ]
 
     def as_dict(self):
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "moeinf_is_resident": (C.c_int, [_P, C.c_int, C.c_int, _I32P]),
     "moeinf_sync_copies": (C.c_int, [_P]),
     "moeinf_set_cache_budget": (C.c_int, [_P, C.c_int64]),
+    "moeinf_set_prefetch_governor": (C.c_int, [_P, C.c_float, C.c_int]),
     "moeinf_reserve_tokens": (C.c_int, [_P, C.c_int]),
     "moeinf_get_expert_counters": (C.c_int, [_P, _I64P, C.c_int64]),
     "moeinf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),

@@ -196,6 +196,13 @@ struct moeinf_engine {
   std::unique_ptr<PrioAioPool> aio;   // disk tier reader (created with the first expert registered from a store)
   std::deque<QueuedTask> disk_inflight;  // speculative tasks whose host blob is being read from disk (low priority)
   int disk_window = 2;                // such reads in flight at most
+  bool draining = false;              // moeinf_sync_copies: serve the queue even while demand copies are in flight
+  std::deque<int> demand_inflight;    // node indices whose copy was issued on the demand lane and not yet observed complete
+  // speculation governor (moeinf_set_prefetch_governor): running usefulness of finished speculative copies
+  float gov_min_useful = 0.f;         // 0 = off
+  int gov_probe_every = 16;
+  float gov_score = 1.f;              // exponential average of outcomes (1 = dispatched before eviction, 0 = evicted unused)
+  int gov_outcomes = 0, gov_skipped = 0;
   std::deque<int> prefetch_inflight;  // node indices whose copy was issued on the prefetch lane, oldest first
   int prefetch_window = 2;            // experts in flight on the prefetch lane at most
   std::vector<void*> host_free;       // arena blocks returned by host-tier eviction
@@ -602,7 +609,7 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   drop_ready_count(g, (int)v);
   const int slot = vn.slot;
   vn.slot = -1;
-  if (vn.prefetched) g->st.prefetch_wasted += 1;  // brought in speculatively, evicted before any dispatch used it
+  if (vn.prefetched) { g->st.prefetch_wasted += 1; g->gov_score += (0.f - g->gov_score) * 0.125f; g->gov_outcomes += 1; }  // brought in speculatively, evicted before any dispatch used it
   vn.prefetched = false;
   g->pol[v].resident = false;
   g->slots[slot].node = -1;
@@ -943,7 +950,7 @@ static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
       Node& n = g->nodes[idx];
       n.visit += 1; n.hit += 1;
       g->st.expert_hits += 1;
-      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; }
+      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; g->gov_score += (1.f - g->gov_score) * 0.125f; g->gov_outcomes += 1; }
       g->pol[idx].incache += 1;
       g->pol[idx].last_access = ++g->clock;
     }
@@ -1020,7 +1027,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
       n.hit += 1;
       g->st.expert_hits += 1;
       if (!n.ready_waited && hipEventQuery(n.ready) != hipSuccess) { (void)hipGetLastError(); g->st.inflight_hits += 1; }
-      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; }
+      if (n.prefetched) { g->st.prefetch_useful += 1; n.prefetched = false; g->gov_score += (1.f - g->gov_score) * 0.125f; g->gov_outcomes += 1; }
     } else {
       n.miss += 1;
       g->st.expert_misses += 1;
@@ -1028,6 +1035,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
       g->st.prefetch_cancelled += g->pq.remove_node(idx);
       rc = issue_copy(g, idx, g->demand, true);
       if (rc != MOEINF_OK) break;
+      g->demand_inflight.push_back(idx);
     }
     if (!n.waited1) {
       hipError_t he = hipStreamWaitEvent(st, n.ready1, 0);
@@ -1416,7 +1424,15 @@ static int pump_prefetch(moeinf_engine* g) {
     if (n.slot >= 0 && !n.ready_waited && n.ready && hipEventQuery(n.ready) != hipSuccess) { (void)hipGetLastError(); break; }
     g->prefetch_inflight.pop_front();
   }
+  while (!g->demand_inflight.empty()) {  // retire on-demand copies that have landed
+    const Node& dn = g->nodes[g->demand_inflight.front()];
+    if (dn.slot >= 0 && dn.ready && hipEventQuery(dn.ready) != hipSuccess) { (void)hipGetLastError(); break; }
+    g->demand_inflight.pop_front();
+  }
   while ((int)g->prefetch_inflight.size() < g->prefetch_window) {
+    // an on-demand copy is on the link: a speculative copy started now would take half of its bandwidth away — the
+    // queue keeps its tasks (they go stale with the layer counter if the pass moves on), the next pump tries again
+    if (!g->demand_inflight.empty() && !g->draining) break;
     QueuedTask t;
     bool have = false;
     // speculative tasks whose host blob has arrived from disk go first (oldest first); unfinished ones stay parked
@@ -1451,6 +1467,13 @@ static int pump_prefetch(moeinf_engine* g) {
       continue;
     }
     if (nd.host_pending) continue;  // already parked in disk_inflight by an earlier request
+    // speculation governor: once enough speculative copies have finished and too few of them were ever dispatched,
+    // stop issuing — all but one probe in `gov_probe_every`, so that a workload whose predictions become good again
+    // is noticed
+    if (g->gov_min_useful > 0.f && g->gov_outcomes >= 8 && g->gov_score < g->gov_min_useful && (g->gov_skipped++ % g->gov_probe_every) != 0) {
+      g->st.prefetch_throttled += 1;
+      continue;
+    }
     // a speculative copy never evicts the protected set (candidates_, task_scheduler.cpp:292-297) nor an expert of
     // the layer being dispatched; if nothing can be freed the task is dropped ("evict failed", :505-510)
     g->pol[idx].pinned = true;
@@ -1516,6 +1539,8 @@ extern "C" int moeinf_is_resident(moeinf_engine* g, int layer, int expert, int32
 extern "C" int moeinf_sync_copies(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   HIPCHK(hipSetDevice(g->cfg.device_id));
+  g->draining = true;
+  struct Undrain { moeinf_engine* g; ~Undrain() { g->draining = false; } } undrain{g};
   for (;;) {  // serve the whole pending queue, a window at a time
     CHK(pump_prefetch(g));
     for (CopyLane* ln : {&g->demand, &g->prefetch}) {
@@ -1563,6 +1588,15 @@ extern "C" int moeinf_reset_stats(moeinf_engine* g) {
   memset(&g->st, 0, sizeof g->st);
   g->st.slots_total = st; g->st.slots_used = su; g->st.slot_bytes = sb; g->st.host_arena_bytes = ha;
   g->st.prefetch_queued = (int64_t)g->pq.size();
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_set_prefetch_governor(moeinf_engine* g, float min_useful_fraction, int probe_every) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (!(min_useful_fraction >= 0.f && min_useful_fraction <= 1.f) || probe_every < 1) return fail(MOEINF_ERR_INVALID, "min_useful_fraction must be in [0,1], probe_every >= 1");
+  g->gov_min_useful = min_useful_fraction;
+  g->gov_probe_every = probe_every;
+  g->gov_score = 1.f; g->gov_outcomes = 0; g->gov_skipped = 0;
   return MOEINF_OK;
 }
 

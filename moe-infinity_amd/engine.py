@@ -239,6 +239,11 @@ class MoEEngine:
         """SetMemoryRatio at run time, in bytes (shrinking evicts by policy and frees the slots)."""
         check(self.lib.moeinf_set_cache_budget(self._h, int(device_memory_bytes)))
 
+    def set_prefetch_governor(self, min_useful_fraction: float = 0.5, probe_every: int = 16):
+        """Stop issuing speculative copies while fewer than ``min_useful_fraction`` of the finished ones were ever
+        dispatched (one probe in ``probe_every`` keeps watching); 0 switches the governor off."""
+        check(self.lib.moeinf_set_prefetch_governor(self._h, float(min_useful_fraction), int(probe_every)))
+
     def expert_counters(self) -> np.ndarray:
         """[L, E, 6] = visit, hit, miss, prefetch, incache_visit_count, resident (get_hit_rate analogue)."""
         a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 6), np.int64)

@@ -39,7 +39,7 @@ def test_struct_sizes_match_header():
 
     # 17 int32/float fields + alignment + double + 2 int64 + 4 int32 (see include/moeinf.h)
     assert C.sizeof(Config) == 17 * 4 + 4 + 8 + 16 + 16
-    assert C.sizeof(Stats) == 22 * 8
+    assert C.sizeof(Stats) == 23 * 8
 
 
 def test_no_gpu_fails_loudly():

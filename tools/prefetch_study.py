@@ -9,6 +9,7 @@ Policies:
   lru            on-demand fetches only, LRU eviction
   lfu+prefetch_all  the reference's prefetcher as written: enqueue EVERY predicted expert of later layers
   lfu+prefetch   same, but only experts predicted to take >= --min-share of their layer's activations
+  lfu+prefetch+governor  same, with the engine's speculation governor on (moeinf_set_prefetch_governor(0.5, 16))
 Prints one JSON object per policy: ms/token, hit rate, H2D GB/s, exposed copy wait, overlap.
 Usage: python tools/prefetch_study.py [--workload mixtral_8x7b] [--layers 8] [--cache-frac 0.5] [--steps 40]
 """
@@ -65,7 +66,7 @@ def main():
     one = (time.perf_counter() - t0) / 50 * 1e6
     reps = max(1, int(round(args.attn_us / one)))
 
-    for policy_name in ("lfu", "lru", "lfu+prefetch_all", "lfu+prefetch"):
+    for policy_name in ("lfu", "lru", "lfu+prefetch_all", "lfu+prefetch", "lfu+prefetch+governor"):
         cfg = getattr(Cf, args.workload)(device_memory_ratio=0.5, max_tokens=1,
                                          policy=Cf.POLICY_LRU if policy_name == "lru" else Cf.POLICY_LFU_INCACHE)
         cfg.num_layers = L
@@ -119,6 +120,8 @@ def main():
         pred.add_tracer(tracer)
         pf = ExpertPrefetcher(L, E, tracer)
         pf.set_archer_engine(eng)
+        if policy_name.endswith("+governor"):
+            eng.set_prefetch_governor(0.5, 16)
         out = torch.empty(1, H, dtype=eng.dtype, device=dev)
         naive = policy_name.endswith("_all")
 
@@ -157,6 +160,7 @@ def main():
                "zipf": args.zipf, "attn_standin_us": round(one * reps, 1), "ms_per_token": round(el * 1e3 / args.steps, 3),
                "hit_rate": round(st["expert_hits"] / max(1, st["expert_hits"] + st["expert_misses"]), 4),
                "misses": st["expert_misses"], "prefetch_issued": st["prefetch_issued"], "prefetch_useful": st["prefetch_useful"],
+               "prefetch_throttled": st["prefetch_throttled"],
                "h2d_GiB": round(st["h2d_bytes"] / 2**30, 2),
                "h2d_GBps_while_busy": round(st["h2d_bytes"] / st["h2d_busy_ms"] / 1e6, 2) if st["h2d_busy_ms"] > 0 else None,
                "copy_busy_ms": round(st["h2d_busy_ms"], 1), "exposed_wait_ms": round(st["exposed_wait_ms"], 1),
