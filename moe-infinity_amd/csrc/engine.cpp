@@ -1343,10 +1343,12 @@ extern "C" int moeinf_set_profiling(moeinf_engine* g, int enabled) {
   return MOEINF_OK;
 }
 
+static int check_device_flag(moeinf_engine* g);
 extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   if (g->last_stream || g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
+  CHK(check_device_flag(g));
   drain_mirrors(g, true);
   for (auto& r : g->prof_pending) {
     float ms = 0.f;
@@ -1363,12 +1365,22 @@ extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
 }
 
 // ---- getters -------------------------------------------------------------------------------
+// the kernels' error flag (FfnStage::miss_flag): an FFN workgroup found no blob pointer for an active expert.  Read at
+// host sync points only (never on the forward path).
+static int check_device_flag(moeinf_engine* g) {
+  int32_t f = 0;
+  HIPCHK(hipMemcpy(&f, g->d_miss, sizeof f, hipMemcpyDeviceToHost));
+  if (f == 0) return MOEINF_OK;
+  HIPCHK(hipMemset(g->d_miss, 0, sizeof f));
+  return fail(MOEINF_ERR_STATE, "device error flag %d: an FFN workgroup found no resident blob for an active expert, results of the last forwards are invalid", f);
+}
+
 static int sync_last(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "no forward has run yet");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   HIPCHK(hipStreamSynchronize(g->last_stream));
-  return MOEINF_OK;
+  return check_device_flag(g);
 }
 
 extern "C" int moeinf_get_routing(moeinf_engine* g, int32_t* topk_idx, float* topk_w, int32_t* counts, int32_t* offsets, int32_t* slot_token, int32_t* pair_slot) {
