@@ -300,12 +300,21 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                    "host_wait_ms_per_layer": round(p["host_wait_ms"] / max(1, p["forwards"]), 4)})
         k1 = kernels["ffn_stage1"]
         traffic, traffic_src = (None, None)
+        # batch-1 decode of the gated families runs the self-routing form of FFN stage 1
+        selfroute = (B == 1 and not use_ep and family in ("mixtral", "deepseek") and E <= 64
+                     and os.environ.get("MOEINF_SELFROUTE", "1") != "0")
         if B == 1 and not use_ep:
-            traffic, traffic_src = latest_pmc_traffic(workload.replace("-", "").replace(".", ""), "ffn_rows_kernel<unsigned short, 2"
-                                                      if family in ("mixtral", "deepseek") else "ffn_rows_kernel<")
+            wl_key = workload.replace("-", "").replace(".", "")
+            if selfroute:
+                traffic, traffic_src = latest_pmc_traffic(wl_key, "ffn1_selfroute_kernel")
+            if traffic is None:
+                traffic, traffic_src = latest_pmc_traffic(wl_key, "ffn_rows_kernel<unsigned short, 2"
+                                                          if family in ("mixtral", "deepseek") else "ffn_rows_kernel<")
         if k1:
-            roof = {"bound": "hbm", "kernel": "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)"
-                                              + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
+            kname = ("ffn1_selfroute_kernel: FFN stage 1 (gate/up rows of the chosen experts, SiLU*mul) with the token's top-k in its "
+                     "prologue" + (" and the shared expert's stage 2 riding along" if cfg.shared_inter else "")) if selfroute else \
+                    "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)"
+            roof = {"bound": "hbm", "kernel": kname + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
                     "traffic": traffic,
                     "traffic_source": (f"static: {traffic_src} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, NOT measured in this run)"
