@@ -2098,7 +2098,13 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
   const int n_rg = (s1.R + 15) / 16;
   const int n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
   const dim3 grid(n_sh2 + r.K * n_rg + 1);
-  hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+  // Extra dynamic LDS per workgroup = a cap on the workgroups resident per CU.  A grid of several workgroups per CU
+  // (Mixtral: 1793) streams best with FOUR resident per CU (8 + 30 KB of LDS each), the rest dispatched as they retire:
+  // 3.942 / 3.935 / 3.920 / 3.891 / 3.939 ms per token at 7 / 6 / 5 / 4 / 3 per CU — fewer concurrent DRAM streams,
+  // staggered finishes.  Small grids (DeepSeek: 657 workgroups, all resident anyway) are left alone.
+  static const int lds_env = env_int("MOEINF_SR_LDS_KB", -1);
+  const size_t dyn = (size_t)(lds_env >= 0 ? lds_env : (grid.x > 4 * 256 ? 30 : 0)) * 1024;
+  hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
   return hipGetLastError();
 }
 
