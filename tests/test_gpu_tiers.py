@@ -229,6 +229,39 @@ def test_speculative_requests_read_disk_only_experts_in_the_background(tmp_path)
     st.close()
 
 
+def test_speculation_governor_stops_unprofitable_prefetching():
+    """moeinf_set_prefetch_governor: speculative copies that keep being evicted before any dispatch used them switch
+    speculation off (all but one probe in N); results never change, and switching the governor off restores issuing."""
+    h, f, e, k, t, L = 256, 512, 8, 2, 2, 6
+    ws = [make_weights("mixtral", h, f, e, 1800 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, 4, t)  # 4 slots for 48 experts: whatever is prefetched is evicted again
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    eng.set_prefetch_governor(0.5, 8)
+    x = acts(t, h, torch.bfloat16, 1810)
+    for rnd in range(10):
+        for l in range(L):
+            out = eng.forward(l, x.to(DEV), ws[l][0].to(DEV))
+            if rnd == 9:
+                assert_block_close(out, R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k), torch.bfloat16, f"layer {l} under the governor")
+            ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
+            used = set(int(v) for v in ref.topk_idx.reshape(-1))
+            wrong = [i for i in range(e) if i not in used][:2]  # experts this input never routes to
+            eng.prefetch((l + 1) % L, wrong)
+            eng.sync_copies()
+    s = eng.stats()
+    assert s["prefetch_wasted"] >= 8, s
+    assert s["prefetch_throttled"] > 0, "the governor never engaged"
+    assert s["prefetch_issued"] < 2 * 10 * L, "throttled requests must not have been issued"
+    issued = s["prefetch_issued"]
+    eng.set_prefetch_governor(0.0, 8)  # off: every request is issued again
+    for l in range(L):
+        eng.prefetch(l, [0, 1])
+        eng.sync_copies()
+    assert eng.stats()["prefetch_issued"] > issued
+    eng.close()
+
+
 def test_dense_mask_with_more_than_k_experts_per_token_is_rejected_without_overrun():
     """the mask-index kernel bounds its writes by the workspace capacity; the host then reports
     the overflow."""
