@@ -2026,11 +2026,12 @@ __device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ log
 // under the router, the first n_sh2 blocks are its stage 2 (its stage 1 rode in the gate launch).
 // grid = 1 (meta) + n_sh2 + K * ceil(R/16) blocks of NW waves.
 // ------------------------------------------------------------------------------------------------
-// amdgpu_num_sgpr: the router's wave-uniform arrays would otherwise push the kernel past 96 SGPRs, and 256-thread
-// blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) (MI355X_MICROARCH.md): 106 SGPRs = 6 blocks per CU,
-// but Mixtral's stage 1 needs 7 (1792 blocks on 256 CUs) to be one resident wave of blocks
+// amdgpu_num_sgpr: the meta block's generic router keeps its wave-uniform arrays in SGPRs and would push the kernel past
+// 96, and 256-thread blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) (MI355X_MICROARCH.md): 106 SGPRs
+// = 6 blocks per CU.  No VGPR cap: 76 VGPRs = 6 workgroups per CU is more than either model uses (a 72-VGPR cap for 7
+// per CU spilled 12 bytes per thread = 2 MB of scratch writes per launch, for nothing once four per CU proved best).
 template <typename T, int NW, int U>
-__global__ __launch_bounds__(NW * 64, 7) __attribute__((amdgpu_num_sgpr(80))) void ffn1_selfroute_kernel(RouteArgs r, IndexArgs a, FfnStage s, FfnStage sh2, int n_rg, int n_sh2) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void ffn1_selfroute_kernel(RouteArgs r, IndexArgs a, FfnStage s, FfnStage sh2, int n_rg, int n_sh2) {
   __shared__ float red[NW][2][256];
   __shared__ unsigned long long sh_w;
   __shared__ int sh_rank_ok;
