@@ -2136,7 +2136,83 @@ __global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
   }
 }
 
+// The same stage for K = 2 (Mixtral): ONE workgroup owns 16 output columns for BOTH chosen experts — wave group g
+// streams expert slot g's 16 rows (k-tiles interleaved over its NWE waves), the partial sums meet in LDS, and the combine
+// runs inside the workgroup: no write-through stores, no store-ack wait, no arrival counter, no coherent row loads
+// (that tail costs 3.5 us per launch, tools/ffn_micro.hip).  H/16 = 256 workgroups for Mixtral = one per CU.
+// Summation order inside an expert (waves 0..NWE-1, tiles in ascending k inside a wave) and the combine order
+// (ascending expert id) are those of ffn2_decode1_kernel, so the two produce identical bits.  Requires K % 32 == 0.
+template <int NWE, int U>
+__global__ __launch_bounds__(2 * NWE * 64) void ffn2_decode1_pair_kernel(FfnStage s) {
+  typedef uint16_t T;
+  constexpr int EPT = 32, EPV = 8;
+  __shared__ float red[2][NWE][16];
+  __shared__ float yv[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = wave / NWE, wl = wave - g * NWE;
+  const int n = lane & 15, q = lane >> 4;
+  const int rg = blockIdx.x, r0 = rg * 16;
+  const char* W = reinterpret_cast<const char*>(s.dec_w[g]);
+  const float cw0 = s.dec_cw[0], cw1 = s.dec_cw[1];
+  if (W == nullptr) {  // never on the sync-free path
+    if (tid == 0 && rg == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int KB = s.K / EPT;
+  const char* a0 = W + s.off_a + (size_t)rg * KB * 1024 + lane * 16;
+  const T* xr = reinterpret_cast<const T*>(s.in) + (size_t)g * s.ld_in + q * EPV;  // T == 1: h row of slot g
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = wl; kb < KB; kb += U * NWE) {
+    u32x4 av[U], xv[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      if (kb + i * NWE < KB) {
+        av[i] = ld16_nt(a0 + (size_t)(kb + i * NWE) * 1024);
+        xv[i] = ld16(xr + (size_t)(kb + i * NWE) * EPT);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i)
+      if (kb + i * NWE < KB) mma16<T>(acc, av[i], xv[i]);
+  }
+  // every token column of the accumulator holds the same token: lanes n == 0 carry rows q*4 .. q*4+3
+  if (n == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[g][wl][q * 4 + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 32) {  // (expert slot, row): sum the K split in wave order, round once, publish y
+    const int gg = tid >> 4, row = tid & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWE; ++w) v += red[gg][w][row];
+    v = DT<T>::round(v);
+    yv[gg][row] = v;
+    if (r0 + row < s.R) DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)gg * s.ld_out + r0 + row, v);
+  }
+  __syncthreads();
+  if (tid < 16 && r0 + tid < s.R) {  // combine_apply for one column, ascending expert id (kinds 0 / 1 without a shared expert)
+    float p0 = yv[0][tid] * cw0, p1 = yv[1][tid] * cw1;
+    if (s.comb.kind != 1) { p0 = DT<T>::round(p0); p1 = DT<T>::round(p1); }
+    float o = DT<T>::round(0.f + p0);
+    o = DT<T>::round(o + p1);
+    DT<T>::store(reinterpret_cast<T*>(s.comb.out) + r0 + tid, o);
+  }
+}
+
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
+  static const int pair_env = env_int("MOEINF_DEC1_PAIR", 1);  // 0: always the arrival-counter form; 4 / 8: waves per expert
+  if (pair_env && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
+    const dim3 g1((s2.R + 15) / 16);
+    // 4 waves per expert (8 per CU), batches of 4 tiles: 38.9 us per Mixtral launch; 8 waves per expert 40.5; the
+    // arrival-counter form 41.9
+    static const int pu = env_int("MOEINF_DEC1_PAIR_U", 4);
+    if (pair_env == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<8, 4>), g1, dim3(1024), 0, st, s2);
+    else if (pu == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 8>), g1, dim3(512), 0, st, s2);
+    else if (pu == 2) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 2>), g1, dim3(512), 0, st, s2);
+    else hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 4>), g1, dim3(512), 0, st, s2);
+    return hipGetLastError();
+  }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
   const size_t kbytes = (size_t)s2.K * 2;
   if (kbytes >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);

@@ -13,8 +13,8 @@ d=json.load(open(sys.argv[1])); k=d["kernels"]
 print(f"{sys.argv[2]:52s} ms/step {d['ms_per_step']:.4f}", {n:v["avg_launch_us"] for n,v in k.items() if isinstance(v,dict)})
 PY
 }
-run mixtral-8x7b "selfroute" MOEINF_SR_DEBUG=0
-run mixtral-8x7b "selfroute, routing skipped (experts 0..K-1)" MOEINF_SR_DEBUG=1
-run mixtral-8x7b "old path" MOEINF_SELFROUTE=0
-run deepseek-v2-lite "selfroute" MOEINF_SR_DEBUG=0
-run deepseek-v2-lite "selfroute, routing skipped" MOEINF_SR_DEBUG=1
+timeout 300 python -m pytest tests -m gpu -q -x -k "batch1 or fused or decode_b1 or golden" > "$OUT/pytest.log" 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed|^E  " "$OUT/pytest.log" | tail -5
+run mixtral-8x7b "stage 2: pair kernel 4 waves, U=4" MOEINF_DEC1_PAIR_U=4
+run mixtral-8x7b "stage 2: pair kernel 4 waves, U=8" MOEINF_DEC1_PAIR_U=8
+run mixtral-8x7b "stage 2: pair kernel 4 waves, U=2" MOEINF_DEC1_PAIR_U=2
