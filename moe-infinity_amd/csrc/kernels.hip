@@ -974,12 +974,12 @@ __device__ __forceinline__ void ring_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
-template <int NTB, int D, int NWV = 8>
-__global__ __launch_bounds__(NWV * 64) void ffn_gemm_ring_kernel(FfnStage s) {
+template <int NTB, int D>
+__global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
   static_assert(D == 3 || D == 4, "register ring of 3 or 4 stages");
-  static_assert(NTB % 4 == 0 && (2 * NTB) % NWV == 0, "token groups come in chunks of 4; DMA pieces divide evenly over the waves");
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
+  constexpr int NWV = 8;
   constexpr int XPW = 2 * NTB / NWV;        // activation DMA pieces (8 rows x 128 B) per wave and stage
   constexpr int XSTAGE = 2 * NTB * 1024;    // activation bytes per stage (2 k-tiles)
   constexpr int NX = 3;                     // LDS ring
@@ -1153,13 +1153,6 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
         static const int ring_wide = env_int("MOEINF_RING_WIDE", -1);
         const bool wide = ring_wide >= 0 ? ring_wide != 0 : max_rows > 128;
         const dim3 g2((grid.x + 7) / 8, grid.y);
-        // 129-192 rows per expert (a 512-token Mixtral prefill): 192 tokens per pass in TWO independent 4-wave workgroups
-        // per CU (72 KiB of LDS each) instead of 256 token slots in one 8-wave workgroup: 479 -> 466 us per layer.  The same
-        // split at 128 tokens per pass (<8,4,4>) is slower (530 us): the activations are then staged twice per CU for
-        // nothing.
-        static const int split = env_int("MOEINF_RING_SPLIT", 1);
-        const dim3 g4((grid.x + 3) / 4, grid.y);
-        if (split && wide && max_rows <= 192) { hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 3, 4>), g4, dim3(256), 0, st, s); return; }
         if (wide) hipLaunchKernelGGL((ffn_gemm_ring_kernel<16, 3>), g2, dim3(512), 0, st, s);
         else hipLaunchKernelGGL((ffn_gemm_ring_kernel<8, 4>), g2, dim3(512), 0, st, s);
         return;
