@@ -11,6 +11,7 @@ python -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1
 timeout 1100 python -m pytest tests -m gpu -q -rf > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
 grep -E "^(FAILED|ERROR)|passed|failed|pytest exit" "$OUT/pytest_gpu.log" | tail -20
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "bench exit $?"; tail -3 "$OUT/bench_default.err"
 LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1"
