@@ -15,6 +15,9 @@ PY
 }
 timeout 300 python -m pytest tests -m gpu -q -x -k "batch1 or fused or decode_b1 or golden" > "$OUT/pytest.log" 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed|^E  " "$OUT/pytest.log" | tail -5
-run mixtral-8x7b "stage 2: pair kernel 4 waves, U=4" MOEINF_DEC1_PAIR_U=4
-run mixtral-8x7b "stage 2: pair kernel 4 waves, U=8" MOEINF_DEC1_PAIR_U=8
-run mixtral-8x7b "stage 2: pair kernel 4 waves, U=2" MOEINF_DEC1_PAIR_U=2
+# the shipped path against its switches (one line each; edit freely for a sweep)
+run mixtral-8x7b "shipped" MOEINF_SELFROUTE=1
+run mixtral-8x7b "stage 2: arrival-counter form instead of the pair kernel" MOEINF_DEC1_PAIR=0
+run mixtral-8x7b "round-1 path (separate top-k/index launch)" MOEINF_SELFROUTE=0
+run deepseek-v2-lite "shipped" MOEINF_SELFROUTE=1
+run deepseek-v2-lite "round-1 path" MOEINF_SELFROUTE=0
