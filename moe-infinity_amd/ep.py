@@ -116,6 +116,19 @@ class ExpertParallelMoE:
         self._marks = []
         return {"calls": calls, **{p: round(t / max(1, calls), 2) for p, t in zip(self.PHASES, tot)}}
 
+    # -- transport ------------------------------------------------------------------------------
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        """One all-to-all.  RCCL ("nccl") moves device buffers directly.  With a host-side backend (gloo) and device
+        buffers — several ranks sharing ONE GPU, which RCCL refuses ("Duplicate GPU detected") — the rows are staged
+        through host memory: same rows, same order, only the transport differs.  That is how the whole multi-process path
+        (HIP kernels, exchange logic, two real processes) is tested on a one-GPU box."""
+        if out.device.type == "cuda" and dist.get_backend(self.group) != "nccl":
+            ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+            dist.all_to_all_single(ho, hi, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            out.copy_(ho)
+            return
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
     # -- forward --------------------------------------------------------------------------------
     def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, out: Optional[torch.Tensor] = None):
         shape = x.shape
@@ -137,12 +150,12 @@ class ExpertParallelMoE:
         self.ops.pack(x2, self.send, None, self.cap_rows)
         self._mark()
         # dispatch all-to-all: rows with their expert ids in the tail, equal splits of cap_rows per peer
-        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self._a2a(self.recv, self.send)
         self._mark()
         self.ops.expert_ffn(layer, self.recv, self.y, self.cap_rows)
         self._mark()
         # combine all-to-all: expert outputs return to the rows' home rank, same row positions
-        dist.all_to_all_single(self.ret, self.y, group=self.group)
+        self._a2a(self.ret, self.y)
         self._mark()
         self.ops.combine(x2, self.ret, out, self.cap_rows)
         self._mark()
@@ -153,18 +166,18 @@ class ExpertParallelMoE:
         self.ops.route(layer, x2, gate_w)
         self.ops.pack_compact(x2, self.send, self.send_counts)
         # counts first (world int32 each way), then the one host read of this form: the split sizes
-        dist.all_to_all_single(self.recv_counts, self.send_counts, group=self.group)
+        self._a2a(self.recv_counts, self.send_counts)
         sc = self.send_counts.cpu().tolist()
         rc = self.recv_counts.cpu().tolist()
         n_out, n_in = sum(sc), sum(rc)
         if n_in > self.recv.shape[0]:
             raise ValueError("received more rows than the exchange buffers hold")
         self._mark()
-        dist.all_to_all_single(self.recv[:n_in], self.send[:n_out], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        self._a2a(self.recv[:n_in], self.send[:n_out], rc, sc)
         self._mark()
         self.ops.expert_ffn_rows(layer, self.recv, self.y, n_in)
         self._mark()
-        dist.all_to_all_single(self.ret[:n_out], self.y[:n_in], output_split_sizes=sc, input_split_sizes=rc, group=self.group)
+        self._a2a(self.ret[:n_out], self.y[:n_in], sc, rc)
         self._mark()
         self.ops.combine(x2, self.ret, out, 0)
         self._mark()

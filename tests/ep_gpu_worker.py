@@ -1,0 +1,56 @@
+"""Worker of tests/test_gpu_ep_processes.py: one expert-parallel rank (its own process, its own HIP engine) on GPU 0.
+Launched by torch.distributed.run with the gloo backend (RCCL refuses two ranks on one GPU); ExpertParallelMoE then
+stages the exchange through host memory, everything else is the product path: HipEpOps over the C ABI."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import R, acts, assert_block_close, make_weights
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+    from moe_infinity_amd.ep import ExpertParallelMoE, HipEpOps
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    for family, e, k, n_shared in (("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2)):
+        h, f, L, tmax = 256, 512, 2, 40
+        ws = [make_weights(family, h, f, e, 3100 + 10 * l, torch.bfloat16, n_shared=n_shared) for l in range(L)]
+        et, rk = (Cf.EXPERT_MIXTRAL, Cf.ROUTER_MIXTRAL) if family == "mixtral" else (Cf.EXPERT_DEEPSEEK, Cf.ROUTER_DEEPSEEK)
+        eng = MoEEngine(Cf.EngineConfig(num_layers=L, num_experts=e, expert_type=et, hidden=h, inter=f, top_k=k, router_kind=rk,
+                                        dtype=Cf.DTYPE_BF16, shared_inter=f * n_shared, device_memory_ratio=0.25, max_tokens=tmax * world,
+                                        ep_rank=rank, ep_size=world))
+        for l in range(L):
+            for i, ex in enumerate(ws[l][1]):
+                if i % world == rank:
+                    eng.register_expert(l, i, ex)
+            if ws[l][2]:
+                eng.register_shared(l, ws[l][2])
+        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64)
+        for t in (1, 3 + rank, tmax - 3 * rank):  # batch 1, ragged small batches (fixed form), prefill-sized (variable split)
+            for l in range(L):
+                x = acts(t, h, torch.bfloat16, 3200 + 7 * t + l + 1000 * rank)
+                out = ep.forward(l, x.to(dev), ws[l][0].to(dev)).cpu()
+                if family == "mixtral":
+                    ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
+                else:
+                    ref = R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2])
+                assert_block_close(out, ref, torch.bfloat16, f"rank {rank} {family} t={t} layer {l} ({ep.last_form})")
+                assert ep.last_form == ("variable" if t * k > 64 else "fixed")
+        eng.close()
+        dist.barrier()
+    print(f"EP_WORKER_OK rank {rank} of {world}", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

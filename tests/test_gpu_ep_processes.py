@@ -1,0 +1,33 @@
+"""Expert parallelism with REAL processes on the GPU: two (and three) ranks, each its own process with its own HIP
+engine holding the experts e % world == rank, all on GPU 0 of a one-GPU box.  RCCL refuses several ranks per GPU
+("Duplicate GPU detected"), so the ranks talk through gloo and ExpertParallelMoE stages the all-to-all rows through
+host memory — the only difference from the multi-GPU product path (HipEpOps, the moeinf_ep_* kernels, fixed and
+variable-split exchange, the shared expert on the home rank, ragged token counts).  Every rank checks its own tokens
+against the oracle with the block bar."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_expert_parallel_ranks_as_processes_on_one_gpu(world):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ep_gpu_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    # the ranks share one stdout: their lines can run together
+    assert r.returncode == 0 and r.stdout.count("EP_WORKER_OK") == world, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
