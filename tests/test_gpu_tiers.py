@@ -62,14 +62,17 @@ def test_a_demand_miss_overtakes_queued_prefetches():
     gates = [(torch.randn(e, h, generator=g) * 0.02).to(torch.bfloat16) for _ in range(L)]
     eng.prefetch(1, list(range(e)))  # 8 requests for layer 1
     st0 = eng.stats()
-    assert st0["prefetch_queued"] + st0["prefetch_issued"] == e and st0["prefetch_issued"] <= 2
+    # at most MOEINF_PREFETCH_WINDOW = 2 copies are IN FLIGHT; a third may already have been issued if the first one
+    # landed while the second one's HBM slot was being allocated (hipMalloc of 336 MiB can take milliseconds)
+    assert st0["prefetch_queued"] + st0["prefetch_issued"] == e and st0["prefetch_issued"] <= 3
     x = acts(t, h, torch.bfloat16, 1310)
     out = eng.forward(0, x.to(DEV), gates[0].to(DEV))  # misses on layer 0
     torch.cuda.synchronize()
     st1 = eng.stats()
     assert st1["expert_misses"] >= 2
-    # the demand copies did not wait for the 8 speculative ones: most of them have not even been issued yet
-    assert st1["prefetch_issued"] <= 4, st1
+    # the demand copies did not wait for the 8 speculative ones: most of them have not even been issued yet (no
+    # speculative copy starts while a demand copy is on the link; this stats() call may start the next window)
+    assert st1["prefetch_issued"] <= st0["prefetch_issued"] + 2 and st1["prefetch_queued"] >= e - 5, st1
     assert_block_close(out, R.block_mixtral(x[None], gates[0], ws[0], top_k=k), torch.bfloat16, "demand-missed layer")
     eng.sync_copies()  # serves the rest of the queue
     st2 = eng.stats()
