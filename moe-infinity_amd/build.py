@@ -51,7 +51,12 @@ def build(force=False, verbose=False):
     stale = [s for s in SOURCES if force or _mtime(_obj(s)) < max(_mtime(os.path.join(CSRC, s)), hdr)]
 
     def compile_one(src):
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if src.endswith(".cpp"):
+            # host code only (HIP runtime API, no kernels): a plain C++ compile — hipcc would run the device pass over it too
+            cmd = [_hipcc(), "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-O2", "-std=c++17", "-fPIC",
+                   "-Wno-unused-value", "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        else:
+            cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True, cwd=CSRC)

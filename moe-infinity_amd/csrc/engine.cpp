@@ -195,6 +195,7 @@ struct moeinf_engine {
   PrefetchQueue pq;
   std::unique_ptr<PrioAioPool> aio;   // disk tier reader (created with the first expert registered from a store)
   std::deque<QueuedTask> disk_inflight;  // speculative tasks whose host blob is being read from disk (low priority)
+  std::vector<int> stale_disk;        // nodes whose speculative disk read outlived its task (stale layer): adopted when done
   int disk_window = 2;                // such reads in flight at most
   bool draining = false;              // moeinf_sync_copies: serve the queue even while demand copies are in flight
   std::deque<int> demand_inflight;    // node indices whose copy was issued on the demand lane and not yet observed complete
@@ -249,6 +250,7 @@ struct moeinf_engine {
           *d_ep_pair_pos = nullptr;
   int ep_cap_rows = 0;   // per-peer capacity of the last ep_pack (0: compact, variable-split exchange)
   int ep_alloc_cap = 0;  // what the EP workspace is sized for
+  int64_t ep_alloc_np = 0;  // ... and the max_tokens*K it was built for
 
   // stage-2 output override of the expert-parallel FFN: rows go straight to the reply buffer, in arrival order
   void* ovr_out = nullptr;
@@ -271,6 +273,13 @@ struct moeinf_engine {
 };
 
 static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }
+// a node's disk backing, reference-counted on the store so that it cannot be closed under a live engine
+static void set_node_store(Node& n, const OffloadStore* st) {
+  if (n.store == st) return;
+  if (n.store) n.store->users -= 1;
+  n.store = st;
+  if (st) st->users += 1;
+}
 static bool owns(const moeinf_engine* g, int expert) { return g->cfg.ep_size <= 1 || (expert % g->cfg.ep_size) == g->cfg.ep_rank; }
 
 // ---- host arena ----------------------------------------------------------------------------
@@ -282,6 +291,8 @@ static int arena_alloc(moeinf_engine* g, int64_t bytes, void** out) {
     // chunk = at least 64 experts' worth or 1 GiB, so pinning cost is amortised
     int64_t want = std::max<int64_t>(bytes, std::min<int64_t>(std::max<int64_t>(bytes * 64, 1ll << 30), 8ll << 30));
     want = align_up(want, bytes);  // whole blobs per chunk
+    // a capped arena never pins more than the cap: the chunk is clamped to the whole blobs that still fit under it
+    if (g->cfg.host_memory_bytes > 0) want = std::max<int64_t>(bytes, std::min<int64_t>(want, (g->cfg.host_memory_bytes - g->arena_total) / bytes * bytes));
     void* p = nullptr;
     hipError_t e = hipHostMalloc(&p, (size_t)want, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -356,6 +367,12 @@ static void free_token_workspace(moeinf_engine* g) {
                    (void**)&g->d_topk_w, (void**)&g->d_router_prob, (void**)&g->d_slot_token, (void**)&g->d_slot_pair, (void**)&g->d_chunk, &g->d_h, &g->d_y};
   for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
 }
+static void free_ep_workspace(moeinf_engine* g) {
+  void** bufs[] = {(void**)&g->d_ep_key, (void**)&g->d_ep_counts, (void**)&g->d_ep_offsets, (void**)&g->d_ep_active, (void**)&g->d_ep_nactive,
+                   (void**)&g->d_ep_pair_slot, (void**)&g->d_ep_slot_token, (void**)&g->d_ep_slot_pair, (void**)&g->d_ep_pair_pos};
+  for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+  g->ep_alloc_cap = 0; g->ep_cap_rows = 0; g->ep_alloc_np = 0;
+}
 static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
   const size_t T = (size_t)max_tokens, K = (size_t)g->K;
   const size_t rows = T * K + (g->has_shared ? T : 0);
@@ -373,7 +390,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
   hipSetDevice(g->cfg.device_id);
   hipDeviceSynchronize();
-  for (auto& n : g->nodes) { for (auto& h : n.disk_reqs) PrioAioPool::wait(h); n.disk_reqs.clear(); }  // reads into the arena
+  for (auto& n : g->nodes) { for (auto& h : n.disk_reqs) PrioAioPool::wait(h); n.disk_reqs.clear(); set_node_store(n, nullptr); }  // reads into the arena
   g->aio.reset();
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
@@ -404,6 +421,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   return MOEINF_OK;
 }
 
+static void prealloc_slots(moeinf_engine* g);
 extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   if (!out) return fail(MOEINF_ERR_INVALID, "out is NULL");
   *out = nullptr;
@@ -491,6 +509,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     for (int i = 0; i < kFenceRing; ++i) g->mirror_pool.push_back(g->mirror_slab + per * i);
   }
   TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
+  prealloc_slots(g);
+  if (g->slots.empty() && g->slab_exhausted) { fail(MOEINF_ERR_OOM, "no device memory for a single expert slot of %lld bytes", (long long)g->slot_bytes); return bail(MOEINF_ERR_OOM); }
   *out = g;
   return MOEINF_OK;
 #undef TRY
@@ -498,6 +518,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
 }
 
 static int retile_tensor(const moeinf_engine* g, const DevLayout& dl, int i, const void* staged, void* slot, hipStream_t cs);
+static int alloc_host_block(moeinf_engine* g, int idx, void** out);
+static int invalidate_resident(moeinf_engine* g, int idx);
 
 // ---- registration --------------------------------------------------------------------------
 extern "C" int moeinf_expert_layout(const moeinf_engine* g, int which, int64_t offsets[4], int64_t sizes[4], int32_t* n_tensors, int64_t* total_bytes) {
@@ -522,9 +544,26 @@ extern "C" int moeinf_register_expert(moeinf_engine* g, int layer, int expert, c
   if (!owns(g, expert)) return fail(MOEINF_ERR_INVALID, "expert %d is not owned by ep_rank %d of %d", expert, g->cfg.ep_rank, g->cfg.ep_size);
   if (blob && nbytes != g->lay.total) return fail(MOEINF_ERR_INVALID, "expert blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay.total);
   HIPCHK(hipSetDevice(g->cfg.device_id));
-  Node& n = g->nodes[node_index(g, layer, expert)];
-  if (!n.host) CHK(arena_alloc(g, g->lay.total, &n.host));
-  if (blob) memcpy(n.host, blob, (size_t)nbytes);
+  const int idx = node_index(g, layer, expert);
+  Node& n = g->nodes[idx];
+  if (n.host_pending) {  // a background disk read of the old payload is under way: let it finish into its block first
+    for (auto& h : n.disk_reqs) PrioAioPool::wait(h);
+    n.disk_reqs.clear();
+    for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end(); ++it)
+      if ((int)it->node == idx) { g->disk_inflight.erase(it); break; }
+    { auto sit = std::find(g->stale_disk.begin(), g->stale_disk.end(), idx); if (sit != g->stale_disk.end()) g->stale_disk.erase(sit); }
+    n.host = n.host_pending;
+    n.host_pending = nullptr;
+  }
+  if (!n.host) CHK(alloc_host_block(g, idx, &n.host));
+  // the caller's blob is now the authoritative host copy: the expert is no longer re-readable from (and must never be
+  // overwritten by) an offload directory it was registered from earlier
+  set_node_store(n, nullptr);
+  memset(n.store_ids, 0, sizeof n.store_ids);
+  if (blob) {
+    CHK(invalidate_resident(g, idx));
+    memcpy(n.host, blob, (size_t)nbytes);
+  }
   return MOEINF_OK;
 }
 
@@ -580,6 +619,27 @@ static void drop_ready_count(moeinf_engine* g, int idx) {
   if (n.slot >= 0 && n.ready_waited) g->resident_per_layer[idx % g->L] -= 1;
 }
 
+// Allocate the HBM slots up to the budget NOW (engine creation, budget growth) instead of on the first miss that needs
+// one: a hipMalloc of a 336 MiB slot costs milliseconds and would sit on the demand-miss path.  If physical memory runs
+// out before the budget does, the cache simply has fewer slots.  MOEINF_PREALLOC=0 restores first-touch allocation.
+static void prealloc_slots(moeinf_engine* g) {
+  static const bool on = getenv("MOEINF_PREALLOC") ? atoi(getenv("MOEINF_PREALLOC")) != 0 : true;
+  if (!on) return;
+  while ((int64_t)g->slots.size() < g->max_slots && !g->slab_exhausted) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)g->slot_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      g->slab_exhausted = true;
+      g->st.slots_total = (int64_t)g->slots.size();
+      break;
+    }
+    Slot s;
+    s.dev = p;
+    g->slots.push_back(s);
+    g->free_slots.push_back((int)g->slots.size() - 1);
+  }
+}
+
 // obtain a device slot for node `idx`; may evict.  Pinned entries (pol[].pinned) are never evicted.
 // *victim_out = node index of the evicted tenant (-1: the slot was free / fresh).
 static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_protected, int* victim_out) {
@@ -618,6 +678,23 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   queue_poke(g, (int)(v % g->L), (int)(v / g->L), 0);
   *slot_out = slot;
   *victim_out = (int)v;
+  return MOEINF_OK;
+}
+
+// the host copy of node idx is about to change: wait for a transfer that may still read it and give up the HBM slot, so
+// the next dispatch copies the new payload (the slot's reuse fences cover kernels that may still read the old one)
+static int invalidate_resident(moeinf_engine* g, int idx) {
+  Node& n = g->nodes[idx];
+  if (n.copy_inflight && n.ready) { HIPCHK(hipEventSynchronize(n.ready)); n.copy_inflight = false; }
+  if (n.slot < 0) return MOEINF_OK;
+  drop_ready_count(g, idx);
+  const int slot = n.slot;
+  n.slot = -1; n.prefetched = false; n.ready_waited = true; n.waited1 = true;
+  g->pol[idx].resident = false;
+  g->slots[slot].node = -1;
+  g->free_slots.push_back(slot);
+  g->st.slots_used -= 1;
+  queue_poke(g, idx % g->L, idx / g->L, 0);
   return MOEINF_OK;
 }
 
@@ -786,6 +863,24 @@ static int alloc_host_block(moeinf_engine* g, int idx, void** out) {
       g->nodes[busy].copy_inflight = false;
       victim = busy;
     }
+    if (victim < 0 && (!g->disk_inflight.empty() || !g->stale_disk.empty())) {
+      // every block is held by a speculative disk read that has not been adopted yet: the oldest one (stale ones
+      // first) is promoted, waited for and gives up its block (its task is dropped — the expert stays on disk)
+      int di;
+      if (!g->stale_disk.empty()) { di = g->stale_disk.front(); g->stale_disk.erase(g->stale_disk.begin()); }
+      else { di = (int)g->disk_inflight.front().node; g->disk_inflight.pop_front(); }
+      Node& dn = g->nodes[di];
+      if (di != idx && dn.host_pending) {
+        for (auto& h : dn.disk_reqs) g->aio->promote(h);
+        for (auto& h : dn.disk_reqs) PrioAioPool::wait(h);
+        dn.disk_reqs.clear();
+        blk = dn.host_pending;
+        dn.host_pending = nullptr;
+        g->st.prefetch_dropped += 1;
+        *out = blk;
+        return MOEINF_OK;
+      }
+    }
     if (victim < 0) return fail(MOEINF_ERR_OOM, "pinned host arena cap (%lld bytes) reached and no host blob can be dropped", (long long)g->cfg.host_memory_bytes);
     blk = g->nodes[victim].host;
     g->nodes[victim].host = nullptr;
@@ -848,6 +943,7 @@ static int ensure_host(moeinf_engine* g, int idx) {
     for (auto& h : n.disk_reqs) g->aio->promote(h);
     for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end(); ++it)
       if ((int)it->node == idx) { g->disk_inflight.erase(it); break; }
+    { auto sit = std::find(g->stale_disk.begin(), g->stale_disk.end(), idx); if (sit != g->stale_disk.end()) g->stale_disk.erase(sit); }
     return finish_host_read(g, idx);
   }
   void* blk = nullptr;
@@ -863,9 +959,15 @@ static int pump_prefetch(moeinf_engine* g);
 // (StartExec drops every queued task with a smaller layer id, task_scheduler.cpp:158-168)
 static inline void drop_stale_prefetches(moeinf_engine* g, int layer) {
   if (!g->pq.empty()) g->st.prefetch_cancelled += g->pq.on_demand(-1, layer);
+  // speculative disk reads for layers the pass has left: the read itself finishes (the blob is adopted into the host
+  // tier by the next demand for it), but its task leaves the pipeline so that no H2D copy is issued for a stale layer
+  for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end();) {
+    if (it->layer < layer) { g->stale_disk.push_back((int)it->node); it = g->disk_inflight.erase(it); g->st.prefetch_cancelled += 1; }
+    else ++it;
+  }
 }
 static inline int pump_if_pending(moeinf_engine* g) {
-  if (g->pq.empty() && g->prefetch_inflight.empty() && g->disk_inflight.empty()) return MOEINF_OK;
+  if (g->pq.empty() && g->prefetch_inflight.empty() && g->disk_inflight.empty() && g->stale_disk.empty()) return MOEINF_OK;
   return pump_prefetch(g);
 }
 static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
@@ -1430,6 +1532,13 @@ extern "C" int moeinf_get_logits(moeinf_engine* g, float* host_out, int64_t n_fl
 // lane (reference: one worker thread per GPU popping ArcherTaskPool's queue, task_scheduler.cpp:451-517).  Called
 // from every entry point that may have freed the lane or added work; never blocks.
 static int pump_prefetch(moeinf_engine* g) {
+  for (size_t i = 0; i < g->stale_disk.size();) {  // disk reads that outlived their task: adopt the blob once it has landed
+    const int di = g->stale_disk[i];
+    Node& dn = g->nodes[di];
+    if (dn.host_pending && !host_read_done(dn)) { ++i; continue; }
+    if (dn.host_pending) CHK(finish_host_read(g, di));
+    g->stale_disk.erase(g->stale_disk.begin() + (long)i);
+  }
   while (!g->prefetch_inflight.empty()) {  // retire finished copies, oldest first
     const int idx = g->prefetch_inflight.front();
     Node& n = g->nodes[idx];
@@ -1478,7 +1587,11 @@ static int pump_prefetch(moeinf_engine* g) {
       g->st.disk_reads_async += 1;
       continue;
     }
-    if (nd.host_pending) continue;  // already parked in disk_inflight by an earlier request
+    if (nd.host_pending) {  // its disk read is under way: parked in disk_inflight by an earlier request, or stale — then this request re-parks it
+      auto sit = std::find(g->stale_disk.begin(), g->stale_disk.end(), idx);
+      if (sit != g->stale_disk.end()) { g->stale_disk.erase(sit); g->disk_inflight.push_back(t); }
+      continue;
+    }
     // speculation governor: once enough speculative copies have finished and too few of them were ever dispatched,
     // stop issuing — all but one probe in `gov_probe_every`, so that a workload whose predictions become good again
     // is noticed
@@ -1563,6 +1676,7 @@ extern "C" int moeinf_sync_copies(moeinf_engine* g) {
     // speculative blobs still on their way from disk: wait for the oldest, the next pump issues its H2D copy
     if (!g->disk_inflight.empty()) { Node& dn = g->nodes[(int)g->disk_inflight.front().node]; for (auto& h : dn.disk_reqs) PrioAioPool::wait(h); }
   }
+  for (int di : g->stale_disk) { Node& dn = g->nodes[di]; for (auto& h : dn.disk_reqs) PrioAioPool::wait(h); }
   CHK(pump_prefetch(g));
   settle_copy_timers(g, true);
   return MOEINF_OK;
@@ -1668,6 +1782,7 @@ extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_b
   g->max_slots = new_max;
   g->slab_exhausted = false;
   g->st.slots_total = new_max;
+  prealloc_slots(g);  // a grown budget gets its slots here, not on the misses that will use them
   return MOEINF_OK;
 }
 
@@ -1690,6 +1805,9 @@ extern "C" int moeinf_reserve_tokens(moeinf_engine* g, int max_tokens) {
   }
   g->cfg.max_tokens = max_tokens;
   g->last_layer = -1;  // routing results of the previous forward lived in the old buffers
+  // the expert-parallel workspace (keys, pair positions, slot maps) is sized by max_tokens*K as well: drop it, the next
+  // ep_pack re-allocates it for the new size (ep_alloc)
+  free_ep_workspace(g);
   return MOEINF_OK;
 }
 
@@ -1710,6 +1828,7 @@ extern "C" int moeinf_store_open(const char* path, moeinf_store** out) {
 }
 extern "C" int moeinf_store_close(moeinf_store* st) {
   if (!st) return MOEINF_OK;
+  if (st->s.users > 0) return fail(MOEINF_ERR_STATE, "offload store is still backing %d experts of a live engine: destroy the engine first", st->s.users);
   int rc = MOEINF_OK;
   if (st->s.dirty()) { const std::string err = st->s.flush(); if (!err.empty()) rc = fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
   for (int i = 0; i < 2; ++i) { if (st->bounce[i]) hipHostFree(st->bounce[i]); if (st->bounce_ev[i]) hipEventDestroy(st->bounce_ev[i]); }
@@ -1800,12 +1919,23 @@ extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, in
   HIPCHK(hipSetDevice(g->cfg.device_id));
   const int idx = node_index(g, layer, expert);
   Node& nd = g->nodes[idx];
-  nd.store = &st->s;  // the store must stay open for as long as the engine may re-read this expert
+  set_node_store(nd, &st->s);  // counted: moeinf_store_close refuses while an engine may still re-read this expert
   for (int i = 0; i < n; ++i) nd.store_ids[i] = tensor_ids[i];
   // disk -> pinned host now while the arena has room; once the cap is reached the expert stays on disk and is read on
   // its first miss (the host tier then works as an LRU cache over the offload directory)
   const bool room = g->cfg.host_memory_bytes <= 0 || !g->host_free.empty() || g->arena_total + g->lay.total <= g->cfg.host_memory_bytes;
-  if (!nd.host && room) CHK(ensure_host(g, idx));
+  if (nd.host_pending) CHK(ensure_host(g, idx));  // a background read of the previous registration: finish it first
+  if (nd.host) {
+    // re-registration: the directory's payload replaces whatever the host blob held (and any resident copy of it)
+    CHK(invalidate_resident(g, idx));
+    void* blk = nd.host;
+    nd.host = nullptr;
+    const int rc = submit_host_read(g, idx, blk, /*high=*/true);
+    if (rc != MOEINF_OK) { g->host_free.push_back(blk); return rc; }
+    CHK(finish_host_read(g, idx));
+  } else if (room) {
+    CHK(ensure_host(g, idx));
+  }
   return MOEINF_OK;
 }
 
@@ -1998,10 +2128,10 @@ static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t 
   return MOEINF_OK;
 }
 static int ep_alloc(moeinf_engine* g, int cap_rows) {
-  if (g->d_ep_key && g->ep_alloc_cap >= cap_rows) { g->ep_cap_rows = cap_rows; return MOEINF_OK; }
-  void* olds[] = {g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active, g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
-  for (void* p : olds) if (p) hipFree(p);
   const size_t np = (size_t)g->cfg.max_tokens * g->K;
+  if (g->d_ep_key && g->ep_alloc_cap >= cap_rows && g->ep_alloc_np >= (int64_t)np) { g->ep_cap_rows = cap_rows; return MOEINF_OK; }
+  if (g->d_ep_key) HIPCHK(hipDeviceSynchronize());  // kernels of earlier layers may still use the old buffers
+  free_ep_workspace(g);
   const size_t nr = std::max<size_t>(np, (size_t)g->cfg.ep_size * cap_rows);
   const size_t nk = std::max<size_t>((size_t)g->cfg.ep_size, (size_t)g->E) + 2;
   CHK(dmalloc(&g->d_ep_key, nr)); CHK(dmalloc(&g->d_ep_counts, nk)); CHK(dmalloc(&g->d_ep_offsets, nk + 1)); CHK(dmalloc(&g->d_ep_active, nk));
@@ -2009,6 +2139,7 @@ static int ep_alloc(moeinf_engine* g, int cap_rows) {
   CHK(dmalloc(&g->d_ep_pair_pos, np));
   g->ep_cap_rows = cap_rows;
   g->ep_alloc_cap = cap_rows;
+  g->ep_alloc_np = (int64_t)np;
   return MOEINF_OK;
 }
 

@@ -239,6 +239,9 @@ class OffloadStore {
 
   const std::string& prefix() const { return prefix_; }
   bool dirty() const { return dirty_; }
+  // experts of live engines that may still re-read their blob from this directory (moeinf_register_expert_from_store):
+  // the store cannot be closed while the count is non-zero
+  mutable int users = 0;
 
  private:
   static int64_t align_up(int64_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }

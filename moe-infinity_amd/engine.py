@@ -57,12 +57,14 @@ class MoEEngine:
         self.gate_dtype = _TORCH_DTYPE[cfg.dtype if cfg.gate_dtype is None else cfg.gate_dtype]
         self.device = torch.device("cuda", cfg.device_id)
         self._last_T = 0
+        self._stores = set()  # OffloadStore objects experts were registered from (kept alive until close())
 
     # ---- lifecycle ---------------------------------------------------------------------------
     def close(self):
         if self._h:
             check(self.lib.moeinf_destroy(self._h))
             self._h = C.c_void_p()
+            self._stores.clear()
 
     def __del__(self):
         try:

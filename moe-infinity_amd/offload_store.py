@@ -86,3 +86,6 @@ class OffloadStore:
         """disk -> pinned host arena for one expert (tensor ids in the reference's blob order)."""
         a = (C.c_uint32 * len(tensor_ids))(*tensor_ids)
         check(self.lib.moeinf_register_expert_from_store(engine._h, layer, expert, self._h, a, len(tensor_ids)))
+        # the engine may re-read this expert from the directory for as long as it lives: it keeps the store alive (the
+        # C side refuses moeinf_store_close while experts of a live engine are backed by it)
+        engine._stores.add(self)
