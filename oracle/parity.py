@@ -66,7 +66,12 @@ def block_report(got: torch.Tensor, ref, dtype, golden: torch.Tensor = None, x: 
     denom = want.abs().mean().item() + 1e-30
     rel = err.mean().item() / denom
     worst = float(ratio.max()) if ratio.numel() else 0.0
+    # plain figures next to the bar: largest absolute error, and largest error relative to max(|want|, mean|want|)
+    # (elements on the NLLB passthrough discontinuity that legitimately took the other branch are excluded, as above)
+    floor = torch.maximum(want.abs(), want.abs().mean()) + 1e-30
     rep = {"worst": worst, "n_bad": int(bad.sum()), "n": int(bad.numel()), "mean_rel": rel,
+           "max_abs_err": float(err.max()) if err.numel() else 0.0,
+           "max_rel_err": float((err / floor).max()) if err.numel() else 0.0,
            "passthrough_ambiguous": ambiguous, "ok": (not bool(bad.any())) and rel <= 1e-3}
     if bad.any():
         i = int(ratio.reshape(-1).argmax())
