@@ -189,7 +189,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
 
     ep = None
     if use_ep:
-        ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev)
+        ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E)
 
         def layer_fwd(l, x):
             ep.forward(l, x, gates[l], out=out)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MOEINF_ABI_VERSION 3
+#define MOEINF_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -186,6 +186,21 @@ int moeinf_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tok
  * already resident when dispatched (wait_expert's 4th tuple field), 0 if fetched on demand, -1 if idle. */
 int moeinf_dispatch_mask(moeinf_engine* eng, int layer, const void* x_dev, int tokens, const void* router_mask_dev,
                          int mask_elem_bytes, void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream);
+
+/* The combine loop of the reference's blocks on its own (mixtral.py:96-101 `final_hidden_states[token_indices] +=
+ * output * routing_weights_mask[...]`, deepseek.py:123-131, switch_transformers.py:99-109 incl. the `router_probs *`
+ * scale and the passthrough of dropped tokens, nllb_moe.py:84-104 incl. `next_states[next_states == 0] = hidden`), for
+ * callers that keep the Python router and use moeinf_dispatch_mask for the experts.
+ *   y_dev         expert outputs as expert-sorted rows (what moeinf_dispatch_mask wrote / wait_expert()'s tensors
+ *                 concatenated in ascending expert order)
+ *   topk_idx_dev  [tokens, K] int32 expert of every (token, k) pair, -1 = pair not dispatched (capacity / zero weight)
+ *   topk_w_dev    [tokens, K] float combine weights (the values of routing_weights_mask at the chosen experts)
+ *   router_prob_dev [tokens] float, Switch only (router_probs); x_dev [tokens, H]: Switch/NLLB passthrough (else may be NULL)
+ * Summation order = ascending expert id (the order dispatch_local enqueues and wait_expert returns), rounding points
+ * of the block's dtype arithmetic as in moeinf_moe_forward.  DeepSeek's shared expert is NOT added (the reference adds it
+ * in Python after the loop, deepseek.py:133-136). */
+int moeinf_combine(moeinf_engine* eng, const void* x_dev, const void* y_dev, const int32_t* topk_idx_dev, const float* topk_w_dev,
+                   const float* router_prob_dev, int tokens, void* out_dev, void* stream);
 
 /* Device-side copies of the LAST forward's router results into caller tensors (async on `stream`;
  * any pointer may be NULL): logits [tokens,E] f32, topk_idx [tokens,K] i32, topk_w [tokens,K] f32.
@@ -381,9 +396,16 @@ int moeinf_aio_stats(const moeinf_aio* a, int64_t out[5]); /* blocks_high, block
 int moeinf_ep_row_elems(const moeinf_engine* eng, int32_t* elems);
 /* After a MOEINF_FWD_ROUTE_ONLY forward: write, for each destination rank r, the rows of x whose
  * expert lives on r ((e % ep_size) == r) into send_dev[r*cap_rows ...] ([ep_size*cap_rows, ep_row_elems],
- * cfg.dtype).  send_counts_dev[ep_size] (optional) receives the row counts. */
+ * cfg.dtype).  send_counts_dev[ep_size] (optional) receives the row counts.  cap_rows must be at least
+ * tokens * min(K, ceil(E / ep_size)): a token sends a rank at most one row per expert that rank owns. */
 int moeinf_ep_pack(moeinf_engine* eng, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows,
                    void* stream);
+/* Sender side in ONE call: router (gate -> top-k -> dispatch index; a decode-sized DeepSeek forward carries its shared
+ * expert's FFN inside these launches, i.e. under the exchange) + moeinf_ep_pack.  For decode-sized forwards the send rows
+ * are written by the router's own launch: two launches before the all-to-all.  cap_rows >= tokens * min(K, experts per
+ * rank).  Arguments as moeinf_moe_forward / moeinf_ep_pack. */
+int moeinf_ep_route_pack(moeinf_engine* eng, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                         void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream);
 /* Run the expert FFN on rows received from all ranks: recv_dev [ep_size*cap_rows, ep_row_elems];
  * writes y_dev [ep_size*cap_rows, H] in the same row order (padding rows are left untouched: nobody reads them). */
 int moeinf_ep_expert_ffn(moeinf_engine* eng, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream);

@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 3  # include/moeinf.h MOEINF_ABI_VERSION
+ABI_VERSION = 4  # include/moeinf.h MOEINF_ABI_VERSION
 
 
 class MoeInfError(RuntimeError):
@@ -140,6 +140,8 @@ PROTOTYPES = {
     "moeinf_ep_pack_compact": (C.c_int, [_P, _P, _P, _P, _P]),
     "moeinf_ep_expert_ffn_rows": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P]),
     "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    "moeinf_ep_route_pack": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "moeinf_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
 }
 
 

@@ -1273,6 +1273,38 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
   return MOEINF_OK;
 }
 
+static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st);
+static void make_route_args(const moeinf_engine* g, const void* x_dev, const void* gate_w_dev, int T, RouteArgs& ra) {
+  memset(&ra, 0, sizeof ra);
+  ra.x = x_dev; ra.gate_w = gate_w_dev; ra.logits = g->d_logits;
+  ra.T = T; ra.H = g->H; ra.E = g->E; ra.K = g->K;
+  ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
+  ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
+  ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
+  ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
+  ra.router_prob = g->d_router_prob;
+}
+static void make_index_args(const moeinf_engine* g, int T, int batch_rows, int32_t* mirror, IndexArgs& ia) {
+  memset(&ia, 0, sizeof ia);
+  ia.topk_idx = g->d_topk_idx; ia.pair_valid = g->d_pair_valid; ia.T = T; ia.K = g->K; ia.E = g->E;
+  ia.rows = batch_rows;
+  ia.capacity = g->cfg.router_kind == MOEINF_ROUTER_SWITCH ? g->cfg.expert_capacity : 0;
+  ia.shared = g->has_shared ? 1 : 0;
+  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
+  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mirror;
+}
+// decode-sized DeepSeek forwards: the shared expert (routing-independent, always resident) runs INSIDE the two router launches
+static bool can_hide_shared(const moeinf_engine* g, int T) {
+  static const bool hide_env = getenv("MOEINF_HIDE_SHARED") ? atoi(getenv("MOEINF_HIDE_SHARED")) != 0 : true;
+  return hide_env && g->has_shared && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * g->K <= 64 && g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
+}
+static void hidden_shared_stages(const moeinf_engine* g, int layer, const void* x_dev, FfnStage& sh1, FfnStage& sh2) {
+  fill_stage(g, layer, 1, sh1, 0);
+  sh1.in = x_dev; sh1.row_map = nullptr; sh1.out = g->d_h_sh; sh1.ld_out = g->Fs;
+  fill_stage(g, layer, 2, sh2, 0);
+  sh2.in = g->d_h_sh; sh2.ld_in = g->Fs; sh2.out = g->d_y_sh; sh2.out_map = nullptr;
+}
+
 extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                                   void* out_dev, void* stream, uint32_t flags) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
@@ -1289,14 +1321,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const int T = tokens, K = g->K, E = g->E;
 
   RouteArgs ra;
-  memset(&ra, 0, sizeof ra);
-  ra.x = x_dev; ra.gate_w = gate_w_dev; ra.logits = g->d_logits;
-  ra.T = T; ra.H = g->H; ra.E = E; ra.K = K;
-  ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
-  ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
-  ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
-  ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
-  ra.router_prob = g->d_router_prob;
+  make_route_args(g, x_dev, gate_w_dev, T, ra);
   moeinf_engine::ProfRec pr;
   const bool prof = g->profiling && !route_only;
   if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
@@ -1307,18 +1332,10 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   }
 
   IndexArgs ia;
-  memset(&ia, 0, sizeof ia);
-  ia.topk_idx = g->d_topk_idx; ia.pair_valid = g->d_pair_valid; ia.T = T; ia.K = K; ia.E = E;
-  ia.rows = batch_rows;
-  ia.capacity = g->cfg.router_kind == MOEINF_ROUTER_SWITCH ? g->cfg.expert_capacity : 0;
-  ia.shared = g->has_shared ? 1 : 0;
-  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
+  make_index_args(g, T, batch_rows, mp.target, ia);
   // decode-sized DeepSeek forwards: the shared expert (routing-independent, always resident) runs INSIDE the two router
   // launches instead of behind them
-  static const bool hide_env = getenv("MOEINF_HIDE_SHARED") ? atoi(getenv("MOEINF_HIDE_SHARED")) != 0 : true;
-  const bool hide_shared = hide_env && g->has_shared && !route_only && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * K <= 64 &&
-                           g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
+  const bool hide_shared = !route_only && can_hide_shared(g, T);
   g->last_hidden_shared = hide_shared;
   // batch-1 decode on the sync-free path (gated families, bf16): no top-k/index launch at all — FFN stage 1 routes for
   // itself from the gate logits (ffn1_selfroute_kernel) and one extra block of it writes the routing outputs
@@ -1330,10 +1347,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   g->last_selfroute = selfroute;
   FfnStage sh1, sh2;
   if (hide_shared) {
-    fill_stage(g, layer, 1, sh1);
-    sh1.in = x_dev; sh1.row_map = nullptr; sh1.out = g->d_h_sh; sh1.ld_out = g->Fs;
-    fill_stage(g, layer, 2, sh2);
-    sh2.in = g->d_h_sh; sh2.ld_in = g->Fs; sh2.out = g->d_y_sh; sh2.out_map = nullptr;
+    hidden_shared_stages(g, layer, x_dev, sh1, sh2);
     ia.shared = 0;  // the index lists routed experts only
   }
   if (selfroute) {
@@ -1424,6 +1438,39 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
   return pump_if_pending(g);
+}
+
+// Standalone combine for callers that keep the reference's PYTHON router: the weighted
+// scatter-add loop of the blocks (mixtral.py:96-101, deepseek.py:123-131, switch_transformers.py:99-109,
+// nllb_moe.py:84-104) over the expert outputs moeinf_dispatch_mask returned.
+extern "C" int moeinf_combine(moeinf_engine* g, const void* x_dev, const void* y_dev, const int32_t* topk_idx_dev, const float* topk_w_dev,
+                              const float* router_prob_dev, int tokens, void* out_dev, void* stream) {
+  if (!g || !y_dev || !topk_idx_dev || !topk_w_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
+  const int kind = g->cfg.router_kind;
+  if ((kind == MOEINF_ROUTER_SWITCH || kind == MOEINF_ROUTER_NLLB) && !x_dev) return fail(MOEINF_ERR_INVALID, "x_dev is needed for the Switch/NLLB passthrough rules");
+  if (kind == MOEINF_ROUTER_SWITCH && !router_prob_dev) return fail(MOEINF_ERR_INVALID, "router_prob_dev is needed for the Switch block");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  drain_mirrors(g, true);
+  const int T = tokens, K = g->K;
+  HIPCHK(launch_prep_pairs(topk_idx_dev, topk_w_dev, T, K, g->d_topk_idx, g->d_topk_w, g->d_pair_valid, g->d_pair_order, st));
+  // expert-sorted row of every pair = the row order moeinf_dispatch_mask / wait_expert() produce (expert ascending,
+  // tokens ascending inside an expert)
+  IndexArgs ia;
+  make_index_args(g, T, 1, nullptr, ia);
+  ia.capacity = 0;  // the caller's router already applied its capacity rule (dropped pairs arrive as -1)
+  ia.shared = 0;
+  CHK(launch_index_auto(g, ia, st));
+  CombineArgs ca;
+  memset(&ca, 0, sizeof ca);
+  ca.x = x_dev; ca.y = y_dev; ca.out = out_dev;
+  ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_pair_slot; ca.pair_order = g->d_pair_order;
+  ca.router_prob = router_prob_dev; ca.y_shared = nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
+  ca.T = T; ca.H = g->H; ca.K = K; ca.kind = kind; ca.dtype = g->dt;
+  HIPCHK(launch_combine(ca, st));
+  g->last_T = T; g->last_stream = st;
+  return MOEINF_OK;
 }
 
 extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int32_t* topk_idx_dev, float* topk_w_dev, void* stream) {
@@ -2144,6 +2191,12 @@ static int ep_alloc(moeinf_engine* g, int cap_rows) {
 }
 
 static int64_t ep_row_elems(const moeinf_engine* g) { return g->H + 16 / g->es; }
+// fewest row slots per peer that can never overflow: a token sends a rank at most one row per expert that rank owns
+static int ep_min_cap(const moeinf_engine* g, int T) {
+  const int per_rank = (g->E + g->cfg.ep_size - 1) / g->cfg.ep_size;
+  return T * std::min(g->K, per_rank);
+}
+static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st);
 
 extern "C" int moeinf_ep_row_elems(const moeinf_engine* g, int32_t* elems) {
   if (!g || !elems) return fail(MOEINF_ERR_INVALID, "NULL argument");
@@ -2154,10 +2207,13 @@ extern "C" int moeinf_ep_row_elems(const moeinf_engine* g, int32_t* elems) {
 extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
   if (!g || !x_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack needs a preceding ROUTE_ONLY forward");
-  if (cap_rows < g->last_T * g->K) return fail(MOEINF_ERR_INVALID, "cap_rows %d < tokens*K %d (worst case: every pair goes to one rank)", cap_rows, g->last_T * g->K);
+  if (cap_rows < ep_min_cap(g, g->last_T)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank) (worst case: every pair a rank can receive from these tokens)", cap_rows, ep_min_cap(g, g->last_T));
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
   CHK(ep_alloc(g, cap_rows));
+  return ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st);
+}
+static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st) {
   const int np = g->last_T * g->K, ep = g->cfg.ep_size;
   if (np <= 64) {  // decode: one launch
     EpPackArgs pa;
@@ -2181,6 +2237,57 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
   HIPCHK(launch_ep_pack(pa, st));
   if (send_counts_dev) HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
+  return MOEINF_OK;
+}
+
+// Sender side of the fixed-capacity exchange in ONE call: gate (+ stage 1 of a hidden DeepSeek shared expert) -> top-k +
+// dispatch index (+ its stage 2) -> send rows.  For decode-sized forwards the send rows are written by the
+// single-workgroup router launch itself (EpFuse): two launches per layer before the all-to-all.
+extern "C" int moeinf_ep_route_pack(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                                    void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
+  if (!g || !x_dev || !gate_w_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
+  if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
+  if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
+  if (cap_rows < ep_min_cap(g, tokens)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank)", cap_rows, ep_min_cap(g, tokens));
+  if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const int T = tokens, K = g->K, np = T * K;
+  CHK(ep_alloc(g, cap_rows));
+  RouteArgs ra;
+  make_route_args(g, x_dev, gate_w_dev, T, ra);
+  IndexArgs ia;
+  make_index_args(g, T, batch_rows, nullptr, ia);
+  ia.shared = 0;  // the owner-side index is built from the received rows; the shared expert never crosses the fabric
+  const bool hide_shared = can_hide_shared(g, T);
+  g->last_hidden_shared = hide_shared;
+  g->last_selfroute = false;
+  // the pack rides in the router's single-workgroup launch while the rows are few KB (one workgroup copies them)
+  static const int fuse_kb = getenv("MOEINF_EP_FUSE_PACK_KB") ? atoi(getenv("MOEINF_EP_FUSE_PACK_KB")) : 64;
+  const bool fuse = np <= 64 && T <= 64 && (int64_t)np * g->H * g->es <= (int64_t)fuse_kb * 1024;
+  EpFuse pk;
+  memset(&pk, 0, sizeof pk);
+  pk.a.x = x_dev; pk.a.send = send_dev; pk.a.ld_send = ep_row_elems(g); pk.a.pair_pos = g->d_ep_pair_pos; pk.a.topk_idx = g->d_topk_idx;
+  pk.a.K = K; pk.a.H = g->H; pk.a.ep_size = g->cfg.ep_size; pk.a.cap_rows = cap_rows; pk.a.dtype = g->dt;
+  pk.pair_valid = g->d_pair_valid; pk.send_counts = send_counts_dev; pk.on = 1;
+  if (hide_shared) {
+    FfnStage sh1, sh2;
+    hidden_shared_stages(g, layer, x_dev, sh1, sh2);
+    HIPCHK(launch_gate_shared1(ra, sh1, st));
+    HIPCHK(launch_route_shared2(ra, ia, sh2, st, fuse ? &pk : nullptr));
+  } else {
+    HIPCHK(launch_gate_logits(ra, st));
+    if (T <= 64) {
+      HIPCHK(launch_route_index(ra, ia, st, fuse ? &pk : nullptr));
+    } else {
+      HIPCHK(launch_route_topk(ra, st));
+      CHK(launch_index_auto(g, ia, st));
+    }
+  }
+  g->last_T = T; g->last_layer = layer; g->last_stream = st;
+  g->st.forwards += 1;
+  if (!fuse) CHK(ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st));
   return MOEINF_OK;
 }
 
@@ -2238,9 +2345,47 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
   MirrorPlan mp;
   drop_stale_prefetches(g, layer);
   CHK(plan_mirror(g, layer, mp));
+  const int owned = std::max(1, g->owned_experts);
+  // Decode-sized exchange on the sync-free path: both FFN stages index for themselves from the row tails
+  // (launch_ffn_ep_stage) — no dispatch-index launch between the all-to-all and the weight stream.
+  static const bool selfindex_env = getenv("MOEINF_EP_SELFINDEX") ? atoi(getenv("MOEINF_EP_SELFINDEX")) != 0 : true;
+  if (selfindex_env && mp.fast && nrows <= 64 && (E - 1) / g->cfg.ep_size < 64) {
+    moeinf_engine::PendingMirror pm;
+    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = nrows; pm.prof = g->profiling; pm.local = false;
+    g->pend.push_back(pm);
+    for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
+      const Node& n = g->nodes[node_index(g, layer, e)];
+      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
+    }
+    CHK(flush_pokes(g, st));
+    FfnStage s1, s2;
+    fill_stage(g, layer, 1, s1, ld);
+    s1.in = recv_dev; s1.row_map = nullptr;
+    fill_stage(g, layer, 2, s2);
+    s2.out = y_dev; s2.out_map = nullptr;
+    EpOwnArgs o;
+    memset(&o, 0, sizeof o);
+    o.recv = recv_dev; o.ld_recv = ld; o.H = g->H; o.nrows = nrows; o.ep_size = g->cfg.ep_size; o.ep_rank = g->cfg.ep_rank;
+    o.max_active = std::min(owned, nrows);
+    moeinf_engine::ProfRec pr;
+    const bool prof = g->profiling;
+    if (prof) {
+      for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
+      hipEventRecord(pr.ev[0], st); hipEventRecord(pr.ev[1], st); hipEventRecord(pr.ev[2], st);
+    }
+    o.stage = 1; o.mirror = mp.target;
+    HIPCHK(launch_ffn_ep_stage(s1, o, st));
+    if (prof) hipEventRecord(pr.ev[3], st);
+    o.stage = 2; o.mirror = nullptr;
+    HIPCHK(launch_ffn_ep_stage(s2, o, st));
+    if (prof) { hipEventRecord(pr.ev[4], st); hipEventRecord(pr.ev[5], st); g->prof_pending.push_back(pr); }
+    g->st.forwards += 1;
+    g->seq += 1;
+    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+    return pump_if_pending(g);
+  }
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
   CHK(launch_index_auto(g, ia, st));
-  const int owned = std::max(1, g->owned_experts);
   // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
   // row), so the reply needs no un-sort pass
   g->ovr_out = y_dev; g->ovr_map = g->d_slot_pair;
@@ -2267,8 +2412,9 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
   if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows (0 after ep_pack_compact)");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   hipStream_t st = (hipStream_t)stream;
-  if (g->has_shared) {
-    // the shared expert (always resident, replicated on every rank) runs on this rank's own tokens
+  if (g->has_shared && !g->last_hidden_shared) {
+    // the shared expert (always resident, replicated on every rank) runs on this rank's own tokens; for decode-sized
+    // forwards it already ran inside the router launches of moeinf_ep_route_pack, i.e. UNDER the exchange
     const int T = g->last_T;
     if (!g->shared_dev[g->last_layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", g->last_layer);
     IndexArgs ia;
@@ -2289,7 +2435,7 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
   memset(&ca, 0, sizeof ca);
   ca.x = x_dev; ca.y = ret_dev; ca.out = out_dev;
   ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
-  ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? g->d_y : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
+  ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? (g->last_hidden_shared ? g->d_y_sh : g->d_y) : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
   ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
   HIPCHK(launch_combine(ca, st));
   return MOEINF_OK;

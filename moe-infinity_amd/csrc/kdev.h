@@ -151,14 +151,13 @@ __device__ __forceinline__ void combine_meta(const CombineArgs& a, const int t, 
   // by the caller) so the rounds stay branch-free
   const int K = a.K;
   const size_t p0 = (size_t)t * K;
-  int ko[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) ko[kk] = a.pair_order[p0 + min(kk, K - 1)];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    m.slot[kk] = a.pair_slot[p0 + ko[kk]];
-    m.w[kk] = a.topk_w[p0 + ko[kk]];
-  }
+  const int32_t* po = a.pair_order + p0;
+  // scalars, not an array: an int ko[8] indexed inside the second loop ended up in scratch (24 B per thread)
+  const int k0 = po[0], k1 = po[min(1, K - 1)], k2 = po[min(2, K - 1)], k3 = po[min(3, K - 1)];
+  const int k4 = po[min(4, K - 1)], k5 = po[min(5, K - 1)], k6 = po[min(6, K - 1)], k7 = po[min(7, K - 1)];
+#define MOEINF_CM(kk, ko) m.slot[kk] = a.pair_slot[p0 + ko]; m.w[kk] = a.topk_w[p0 + ko];
+  MOEINF_CM(0, k0) MOEINF_CM(1, k1) MOEINF_CM(2, k2) MOEINF_CM(3, k3) MOEINF_CM(4, k4) MOEINF_CM(5, k5) MOEINF_CM(6, k6) MOEINF_CM(7, k7)
+#undef MOEINF_CM
 }
 template <typename T, bool COH = false>  // COH: y / y_shared were written by other workgroups of THIS launch
 __device__ __forceinline__ void combine_apply(const CombineArgs& a, const int t, const int h0, const CombineMeta& m) {
@@ -228,7 +227,8 @@ __device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, 
 // shared expert's FFN along (gate_shared1_kernel / route_shared2_kernel).
 template <typename T, int NMAT, int NW, int U, int NT>
 __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, const char* W, const bool sh, const int cnt, const int off,
-                                              float (*red)[NMAT][256], const int xrow_fixed = -1) {
+                                              float (*red)[NMAT][256], const int xrow_fixed = -1,
+                                              const int* in_rows = nullptr, const int* out_rows = nullptr) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
   const int K = sh ? s.K_sh : s.K;
@@ -255,7 +255,11 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
       const int srow = off + min((tile0 + tt) * 16 + n, cnt - 1);
       // xrow_fixed >= 0: every row of this item is token xrow_fixed (the self-routing decode kernel: the row map is
       // being written by another block of the same launch)
-      const int64_t xrow = xrow_fixed >= 0 ? (int64_t)xrow_fixed : (s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow);
+      // in_rows / out_rows (workgroup-local arrays, indexed by the row's position INSIDE this item): the expert-parallel
+      // owner-side kernel derives an expert's rows itself and keeps their ids in LDS
+      const int64_t xrow = xrow_fixed >= 0 ? (int64_t)xrow_fixed
+                           : in_rows     ? (int64_t)in_rows[min((tile0 + tt) * 16 + n, cnt - 1)]
+                                         : (s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow);
       xr[tt] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + kq;
       acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -336,7 +340,7 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
             if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
           }
           const int srow = off + tile * 16 + tn;
-          T* op = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[srow] : srow) * s.ld_out + orow;
+          T* op = reinterpret_cast<T*>(s.out) + (size_t)(out_rows ? out_rows[tile * 16 + tn] : (s.out_map ? s.out_map[srow] : srow)) * s.ld_out + orow;
           if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v); else DT<T>::store(op, v);
         }
       }
@@ -902,5 +906,52 @@ __device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ log
   return chosen;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Expert-parallel exchange, sender side, decode-sized forwards (<= 64 (token,k) pairs): the send rows of the
+// all-to-all written by the SAME workgroup that just routed and indexed the tokens (no pack launch).  Row (d, pos) of
+// `send` = the pos-th pair (stable, pair order) whose expert lives on rank d = e % ep_size; its 16-byte tail carries the
+// expert id, tails of unused rows are -1.  Call with every thread of the workgroup after a __syncthreads() that made
+// topk_idx / pair_valid visible.  Same layout, bit for bit, as ep_pack_small_kernel (ep_kernels.hip).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void ep_pack_block(const EpPackArgs& a, const int32_t* pair_valid, const int n_pairs, int32_t* send_counts,
+                                              int* s_row /*LDS [64]*/) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nrows = a.ep_size * a.cap_rows;
+  T* send = reinterpret_cast<T*>(a.send);
+  for (int r = tid; r < nrows; r += nthr) reinterpret_cast<int32_t*>(send + (size_t)r * a.ld_send + a.H)[0] = -1;
+  if (tid < 64) {
+    const int lane = tid;
+    int key = -1;
+    if (lane < n_pairs) {
+      const int e = a.topk_idx[lane];
+      if (e >= 0 && (!pair_valid || pair_valid[lane])) key = e % a.ep_size;
+    }
+    int row = -1;
+    for (int d = 0; d < a.ep_size; ++d) {
+      const uint64_t mine = __ballot(key == d);
+      if (key == d) row = d * a.cap_rows + __popcll(mine & lanes_below(lane));  // < cap_rows: the host checks cap_rows >= tokens * min(K, experts per rank)
+      if (send_counts && lane == 0) send_counts[d] = __popcll(mine);
+    }
+    if (lane < n_pairs) a.pair_pos[lane] = row;
+    s_row[lane] = row;
+  }
+  __syncthreads();  // (also orders the -1 tails above before the occupied rows' tails below)
+  constexpr int EPV = DT<T>::EPV;
+  const int cpr = a.H / EPV;  // 16-byte chunks per row
+  for (int i = tid; i < n_pairs * cpr; i += nthr) {
+    const int p = i / cpr, c = i - p * cpr;
+    const int row = s_row[p];
+    if (row < 0) continue;
+    T* dst = send + (size_t)row * a.ld_send;
+    *reinterpret_cast<u32x4*>(dst + c * EPV) = ld16(reinterpret_cast<const T*>(a.x) + (size_t)(p / a.K) * a.H + c * EPV);
+    if (c == 0) reinterpret_cast<int32_t*>(dst + a.H)[0] = a.topk_idx[p];
+  }
+}
+__device__ __forceinline__ void ep_pack_block_dt(const EpFuse& f, const int n_pairs, int* s_row) {
+  if (f.a.dtype == DT_BF16) ep_pack_block<uint16_t>(f.a, f.pair_valid, n_pairs, f.send_counts, s_row);
+  else ep_pack_block<float>(f.a, f.pair_valid, n_pairs, f.send_counts, s_row);
+}
 
 }  // namespace moeinf

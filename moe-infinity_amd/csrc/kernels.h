@@ -7,6 +7,7 @@
 namespace moeinf {
 
 enum { DT_BF16 = 0, DT_F32 = 1 };
+struct EpFuse;
 
 // epilogues of the row-dot (weight-streaming) FFN kernel
 enum {
@@ -118,14 +119,14 @@ hipError_t launch_dispatch_index_wide(const IndexArgs& a, int32_t* chunk_scratch
 // dispatch index from a dense router_mask[T,E] (element size 1, 4 or 8 bytes, non-zero = routed)
 hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st);
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
-hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st);
+hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st, const EpFuse* pack = nullptr);
 // Decode-sized DeepSeek forwards (bf16, T*K <= 64): the shared expert's FFN rides along with the router.
 //   gate_shared1: gate logits + stage 1 of the shared expert (s = its stage-1 descriptor: in = x, row_map = nullptr,
 //                 out = h_shared [T, R_sh]);
 //   route_shared2: top-k + dispatch index (a.shared must be 0) + stage 2 of the shared expert (s: in = h_shared,
 //                 out = y_shared [T, R_sh == H]).
 hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_t st);
-hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st);
+hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st, const EpFuse* pack = nullptr);
 
 // Batch-1 decode of the gated families (bf16, T == 1, K <= 8, T*K <= 64, every owned expert resident): FFN stage 1 that
 // routes for itself from the gate logits (no top-k/index launch).  r/a as for launch_route_index (a.shared must be 0),
@@ -168,10 +169,38 @@ struct EpPackArgs {
   int K, H, ep_size, cap_rows, dtype;
 };
 hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
+// the pack riding in the single-workgroup router launch of a decode-sized forward (launch_route_index /
+// launch_route_shared2): on != 0 makes the workgroup that routed and indexed the tokens write the send rows as well
+struct EpFuse {
+  EpPackArgs a;
+  const int32_t* pair_valid;
+  int32_t* send_counts;  // optional [ep_size]
+  int on;
+};
 // compact, destination-sorted send rows (variable-split exchange): row r = r-th pair in destination order
 hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st);
 // n_pairs <= 64: dest keys + stable ranks + row copy in one launch (counts/offsets/slot_pair of `a` unused);
 // send_counts (optional, [ep_size]) receives the rows per destination
 hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st);
+
+// Expert-parallel exchange, owner side, decode-sized (<= 64 received row slots, every owned expert resident): one FFN
+// stage that INDEXES FOR ITSELF — every workgroup reads the expert ids in the received rows' tails, derives "its"
+// expert (the blockIdx.y-th smallest id present) and that expert's rows, and streams the weights once over them: no
+// dispatch-index launch between the all-to-all and the FFN.  stage 1: in = recv rows, out = h (expert-sorted rows);
+// stage 2: in = h, out = the reply buffer, every row at its ARRIVAL position (no un-sort pass).
+struct EpOwnArgs {
+  const void* recv;     // [nrows, ld_recv]: H activations + 16-byte tail (first int32 = expert id, -1 = padding)
+  int64_t ld_recv;      // elements
+  int H;                // activation elements per received row
+  int nrows;            // <= 64
+  int ep_size, ep_rank;
+  int stage;            // 1 or 2
+  int max_active;       // grid.y
+  int32_t* mirror;      // stage 1 only (optional): pinned routing mirror {n_active, counts[E+1], active[E+1]}
+};
+hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st);
+// [T,K] routing of a caller that kept its own router -> the engine's pair arrays (moeinf_combine): idx < 0 = dropped pair
+hipError_t launch_prep_pairs(const int32_t* idx_in, const float* w_in, int T, int K, int32_t* topk_idx, float* topk_w,
+                             int32_t* pair_valid, int32_t* pair_order, hipStream_t st);
 
 }  // namespace moeinf

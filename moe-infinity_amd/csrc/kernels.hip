@@ -14,6 +14,8 @@
 // are reproduced (Tr() below) so results match its CPU path to accumulation-order noise.
 #include "kdev.h"
 
+#include <string.h>
+
 namespace moeinf {
 
 // ------------------------------------------------------------------------------------------------
@@ -308,7 +310,8 @@ hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st) {
 
 // decode-sized batches: softmax/top-k of every token (one wave each) and the dispatch index in ONE
 // launch of one workgroup — saves a kernel boundary per layer where launches dominate the layer time
-__global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, IndexArgs a) {
+// pk.on: the expert-parallel send rows are written by this workgroup too (T*K <= 64; ep_pack_block, kdev.h)
+__global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, IndexArgs a, EpFuse pk) {
   __shared__ int wave_cnt[IDX_WAVES * IDX_MAXE];
   __shared__ int running[IDX_MAXE];
   __shared__ int offs[IDX_MAXE + 1];
@@ -321,12 +324,17 @@ __global__ __launch_bounds__(IDX_THREADS) void route_index_kernel(RouteArgs r, I
   } else {
     index_body(a, wave_cnt, running, offs, scan_tmp);
   }
+  if (pk.on) {  // block-uniform
+    __threadfence_block();
+    __syncthreads();  // pair_valid may have been edited by the index (Switch capacity)
+    ep_pack_block_dt(pk, a.T * a.K, scan_tmp);
+  }
 }
 
 // block 0: softmax/top-k of every token (4 waves) + the one-wave dispatch index (T*K <= 64); blocks 1..: 16 rows each of
 // the shared expert's down projection over h_shared (written by gate_shared1_kernel)
 template <typename T, int NW, int U>
-__global__ __launch_bounds__(NW * 64) void route_shared2_kernel(RouteArgs r, IndexArgs a, FfnStage s) {
+__global__ __launch_bounds__(NW * 64) void route_shared2_kernel(RouteArgs r, IndexArgs a, FfnStage s, EpFuse pk) {
   __shared__ int running[IDX_MAXE];
   __shared__ int offs[IDX_MAXE + 1];
   __shared__ float red[NW][1][256];
@@ -335,15 +343,25 @@ __global__ __launch_bounds__(NW * 64) void route_shared2_kernel(RouteArgs r, Ind
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x < 64) index_small(a, running, offs);
+    if (pk.on) {  // expert-parallel: this workgroup writes the send rows as well (ep_pack_block, kdev.h)
+      __syncthreads();
+      ep_pack_block_dt(pk, a.T * a.K, reinterpret_cast<int*>(&red[0][0][0]));
+    }
   } else {
     const char* W = reinterpret_cast<const char*>(s.wptr[s.E]);
     ffn_rows_item<T, 1, NW, U, 1>(s, (int)blockIdx.x - 1, W, true, r.T, 0, red);
   }
 }
-hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st) {
+static EpFuse no_pack() {
+  EpFuse f;
+  memset(&f, 0, sizeof f);
+  return f;
+}
+hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const FfnStage& s, hipStream_t st, const EpFuse* pack) {
   static const int nw = env_int("MOEINF_SH2_NW", 8), u = env_int("MOEINF_SH2_U", 4);
   const dim3 grid(1 + (s.R_sh + 15) / 16);
-#define RS2(NWV, UU) hipLaunchKernelGGL((route_shared2_kernel<uint16_t, NWV, UU>), grid, dim3(NWV * 64), 0, st, r, a, s)
+  const EpFuse pk = pack ? *pack : no_pack();
+#define RS2(NWV, UU) hipLaunchKernelGGL((route_shared2_kernel<uint16_t, NWV, UU>), grid, dim3(NWV * 64), 0, st, r, a, s, pk)
   if (nw == 16) { if (u == 8) RS2(16, 8); else RS2(16, 4); }
   else if (nw == 4) { if (u == 8) RS2(4, 8); else RS2(4, 4); }
   else { if (u == 8) RS2(8, 8); else RS2(8, 4); }
@@ -559,8 +577,8 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(route_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, r, a);
+hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st, const EpFuse* pack) {
+  hipLaunchKernelGGL(route_index_kernel, dim3(1), dim3(IDX_THREADS), 0, st, r, a, pack ? *pack : no_pack());
   return hipGetLastError();
 }
 
@@ -679,117 +697,32 @@ hipError_t launch_poke(const PokeArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// expert-parallel helpers
-// ------------------------------------------------------------------------------------------------
-__global__ void ep_dest_key_kernel(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int32_t* pair_pos, int n, int ep) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int e = topk_idx[p];
-  key[p] = (e >= 0 && (!pair_valid || pair_valid[p])) ? (e % ep) : -1;
-  if (pair_pos) pair_pos[p] = -1;  // ep_pack fills the dispatched ones
-}
-hipError_t launch_ep_dest_key(const int32_t* topk_idx, const int32_t* pair_valid, int32_t* key, int32_t* pair_pos,
-                              int n_pairs, int ep_size, hipStream_t st) {
-  hipLaunchKernelGGL(ep_dest_key_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, topk_idx, pair_valid, key,
-                     pair_pos, n_pairs, ep_size);
-  return hipGetLastError();
-}
-
-// grid = (ep_size*cap_rows), block = 256: one send row per block
-template <typename T>
-__global__ __launch_bounds__(256) void ep_pack_kernel(EpPackArgs a) {
-  const int row = blockIdx.x;
-  const int d = row / a.cap_rows, pos = row % a.cap_rows;
-  const int cnt = a.counts[d];
-  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
-  int32_t* tail = reinterpret_cast<int32_t*>(dst + a.H);
-  if (pos >= cnt) {
-    if (threadIdx.x == 0) tail[0] = -1;
-    return;
-  }
-  const int pair = a.slot_pair[a.offsets[d] + pos];
-  const int t = pair / a.K;
-  if (threadIdx.x == 0) {
-    tail[0] = a.topk_idx[pair];
-    a.pair_pos[pair] = row;
-  }
-  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)t * a.H;
-  constexpr int EPV = DT<T>::EPV;
-  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
-}
-// <= 64 (token,k) pairs (decode): destination keys, stable ranks and the row copy in ONE launch.  Every block
-// (= one send row (d, pos)) re-derives "which pair is the pos-th one bound for rank d" with two ballots over the
-// pairs — the same stable order the dest-key + dispatch_index + pack sequence produces.
-template <typename T>
-__global__ __launch_bounds__(256) void ep_pack_small_kernel(EpPackArgs a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts) {
-  __shared__ int s_pair, s_cnt;
-  const int row = blockIdx.x;
-  const int d = row / a.cap_rows, pos = row % a.cap_rows;
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    int key = -1;
-    if (lane < n_pairs) {
-      const int e = a.topk_idx[lane];
-      if (e >= 0 && (!pair_valid || pair_valid[lane])) key = e % a.ep_size;
+// [T,K] routing of a caller that kept its own router (moeinf_combine) -> the engine's pair arrays: idx < 0 marks a
+// dropped pair; pair_order = the token's k-indices by ascending expert id (stable), as route_store writes it
+__global__ void prep_pairs_kernel(const int32_t* __restrict__ idx_in, const float* __restrict__ w_in, int T, int K, int32_t* __restrict__ topk_idx,
+                                  float* __restrict__ topk_w, int32_t* __restrict__ pair_valid, int32_t* __restrict__ pair_order) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int sel[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sel[k] = k < K ? idx_in[(size_t)t * K + k] : 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < K) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < K) rank += (sel[j] < sel[k] || (sel[j] == sel[k] && j < k)) ? 1 : 0;
+      topk_idx[(size_t)t * K + k] = sel[k];
+      topk_w[(size_t)t * K + k] = w_in[(size_t)t * K + k];
+      pair_valid[(size_t)t * K + k] = sel[k] >= 0 ? 1 : 0;
+      pair_order[(size_t)t * K + rank] = k;
     }
-    const uint64_t mine = __ballot(key == d);
-    const int rank = __popcll(mine & lanes_below(lane));
-    const uint64_t hit = __ballot(key == d && rank == pos);
-    if (lane == 0) { s_pair = hit ? (__ffsll((unsigned long long)hit) - 1) : -1; s_cnt = __popcll(mine); }
-    if (row == 0 && lane < n_pairs && key < 0) a.pair_pos[lane] = -1;  // never dispatched
   }
-  __syncthreads();
-  const int pair = s_pair;
-  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
-  int32_t* tail = reinterpret_cast<int32_t*>(dst + a.H);
-  if (threadIdx.x == 0 && pos == 0 && send_counts) send_counts[d] = s_cnt;
-  if (pair < 0) {
-    if (threadIdx.x == 0) tail[0] = -1;
-    return;
-  }
-  if (threadIdx.x == 0) {
-    tail[0] = a.topk_idx[pair];
-    a.pair_pos[pair] = row;
-  }
-  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)(pair / a.K) * a.H;
-  constexpr int EPV = DT<T>::EPV;
-  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
 }
-// Variable-split exchange (prefill-sized batches): send rows are COMPACT and sorted by destination rank — row r of
-// `send` is the r-th pair in destination order (slot_pair from dispatch_index over the destination keys), so the
-// all-to-all moves exactly the routed rows (split sizes = counts per destination) instead of a fixed capacity per
-// peer.  grid = n_pairs blocks; blocks past the number of dispatched pairs exit.
-template <typename T>
-__global__ __launch_bounds__(256) void ep_pack_compact_kernel(EpPackArgs a, int n_pairs) {
-  const int row = blockIdx.x;
-  const int total = a.offsets[a.ep_size];
-  if (row >= total) return;
-  const int pair = a.slot_pair[row];
-  T* dst = reinterpret_cast<T*>(a.send) + (size_t)row * a.ld_send;
-  if (threadIdx.x == 0) {
-    reinterpret_cast<int32_t*>(dst + a.H)[0] = a.topk_idx[pair];
-    a.pair_pos[pair] = row;
-  }
-  const T* src = reinterpret_cast<const T*>(a.x) + (size_t)(pair / a.K) * a.H;
-  constexpr int EPV = DT<T>::EPV;
-  for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
-}
-hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st) {
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_compact_kernel<uint16_t>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
-  else hipLaunchKernelGGL(ep_pack_compact_kernel<float>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
-  return hipGetLastError();
-}
-
-hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st) {
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_small_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);
-  else hipLaunchKernelGGL(ep_pack_small_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts);
-  return hipGetLastError();
-}
-
-hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st) {
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(ep_pack_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a);
+hipError_t launch_prep_pairs(const int32_t* idx_in, const float* w_in, int T, int K, int32_t* topk_idx, float* topk_w,
+                             int32_t* pair_valid, int32_t* pair_order, hipStream_t st) {
+  hipLaunchKernelGGL(prep_pairs_kernel, dim3((T + 127) / 128), dim3(128), 0, st, idx_in, w_in, T, K, topk_idx, topk_w, pair_valid, pair_order);
   return hipGetLastError();
 }
 

@@ -167,6 +167,21 @@ class MoEEngine:
         self._last_T = T
         return y[: int(counts.sum())], counts, hit
 
+    def combine(self, y: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor, x2: Optional[torch.Tensor] = None,
+                router_prob: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The block's combine loop on its own (moeinf_combine): y = expert-sorted expert outputs (dispatch_mask's), topk_idx
+        [T,K] int32 (-1 = dropped pair), topk_w [T,K] float32, both on the device."""
+        T = topk_idx.shape[0]
+        self._check_dev(y, self.dtype, "y")
+        self._check_dev(topk_idx, torch.int32, "topk_idx")
+        self._check_dev(topk_w, torch.float32, "topk_w")
+        if out is None:
+            out = torch.empty((T, self.cfg.hidden), dtype=self.dtype, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_combine(self._h, _ptr(x2) if x2 is not None else None, _ptr(y), _ptr(topk_idx), _ptr(topk_w),
+                                      _ptr(router_prob) if router_prob is not None else None, T, _ptr(out), stream))
+        return out
+
     def routing_tensors(self, logits: bool = True, topk: bool = False):
         """Device copies of the last forward's router results (logits f32 [T,E], topk_idx i32, topk_w f32)."""
         T, K, E = self._last_T, self.cfg.top_k, self.cfg.num_experts
@@ -279,6 +294,14 @@ class MoEEngine:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(self.lib.moeinf_ep_pack(self._h, _ptr(x2), _ptr(send), _ptr(send_counts) if send_counts is not None else None,
                                       cap_rows, stream))
+
+    def ep_route_pack(self, layer: int, x2: torch.Tensor, gate_w: torch.Tensor, send: torch.Tensor,
+                      send_counts: Optional[torch.Tensor], cap_rows: int, batch_rows: int = 1):
+        """router + pack of the fixed-capacity exchange in one call (moeinf_ep_route_pack)"""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_route_pack(self._h, layer, _ptr(x2), x2.shape[0], batch_rows, _ptr(gate_w), _ptr(send),
+                                            _ptr(send_counts) if send_counts is not None else None, cap_rows, stream))
+        self._last_T = x2.shape[0]
 
     def ep_expert_ffn(self, layer: int, recv: torch.Tensor, y: torch.Tensor, cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

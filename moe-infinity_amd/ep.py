@@ -37,6 +37,9 @@ class HipEpOps:
 
         self.engine.forward(layer, x2, gate_w, flags=FWD_ROUTE_ONLY)
 
+    def route_pack(self, layer, x2, gate_w, send, counts, cap_rows):
+        self.engine.ep_route_pack(layer, x2, gate_w, send, counts, cap_rows)
+
     def row_elems(self):
         return self.engine.ep_row_elems()
 
@@ -69,13 +72,19 @@ class ExpertParallelMoE:
     PHASES = ("route_pack", "a2a_dispatch", "owner_ffn", "a2a_combine", "combine")
 
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
-                 group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64):
+                 group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None):
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.hidden, self.top_k = hidden, top_k
-        self.cap_rows = max_tokens * top_k
+        # row slots per peer of the fixed form: a token sends a rank at most one row per expert that rank owns, so
+        # tokens * min(K, ceil(E / world)) can never overflow (Mixtral on 8 ranks: 1 slot per token, not K) — and needs
+        # no agreement between ranks, unlike any capacity that CAN overflow (switching to the variable form would have to
+        # be decided collectively: one more host-synchronised collective per layer)
+        per_rank = top_k if num_experts is None else min(top_k, -(-num_experts // self.world))
+        self.cap_rows = max_tokens * per_rank
+        self.max_tokens = max_tokens
         self.var_threshold = var_threshold
         n = self.world * self.cap_rows
         mk = lambda *s, dt=dtype: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
@@ -133,7 +142,7 @@ class ExpertParallelMoE:
     def forward(self, layer: int, x: torch.Tensor, gate_w: torch.Tensor, out: Optional[torch.Tensor] = None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        if x2.shape[0] * self.top_k > self.cap_rows:
+        if x2.shape[0] > self.max_tokens:
             raise ValueError("more tokens than the exchange buffers were sized for")
         if out is None:
             out = torch.empty_like(x2)
@@ -146,8 +155,11 @@ class ExpertParallelMoE:
     def _forward_fixed(self, layer, x2, gate_w, out):
         self.last_form = "fixed"
         self._mark()
-        self.ops.route(layer, x2, gate_w)
-        self.ops.pack(x2, self.send, None, self.cap_rows)
+        if hasattr(self.ops, "route_pack"):  # one host call; decode-sized: the router's own launch writes the send rows
+            self.ops.route_pack(layer, x2, gate_w, self.send, None, self.cap_rows)
+        else:
+            self.ops.route(layer, x2, gate_w)
+            self.ops.pack(x2, self.send, None, self.cap_rows)
         self._mark()
         # dispatch all-to-all: rows with their expert ids in the tail, equal splits of cap_rows per peer
         self._a2a(self.recv, self.send)

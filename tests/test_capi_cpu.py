@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(PROTOTYPES), declared ^ set(PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), f"libmoeinf_hip.so does not export {name}"
-    assert lib.moeinf_abi_version() == 3
+    assert lib.moeinf_abi_version() == 4
 
 
 def test_struct_sizes_match_header():
