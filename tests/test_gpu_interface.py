@@ -249,3 +249,64 @@ def test_expert_parallel_module_through_rccl_world_size_1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family", ["mixtral", "deepseek", "switch", "nllb"])
+def test_standalone_combine_export_matches_the_fused_forward(family):
+    """moeinf_combine (the decomposed `combine(...)` for callers that keep the Python router):
+    expert outputs from moeinf_dispatch_mask + the router's top-k (ids, weights) -> the block output, bit-identical to
+    what moeinf_moe_forward produces for the same tokens (same summation order, same rounding points)."""
+    h, f, e, t = 256, 512, 8, 23
+    k = {"mixtral": 2, "deepseek": 3, "switch": 1, "nllb": 2}[family]
+    dtype = torch.float32 if family == "switch" else torch.bfloat16
+    gate, experts, _ = make_weights(family, h, f, e, 880, dtype, gate_std=0.5 if family in ("switch", "nllb") else 0.02)
+    kw = dict(expert_capacity=4) if family == "switch" else {}
+    eng = engine_for(family, h, f, e, k, dtype, max_tokens=t, **kw)
+    register_all(eng, experts)
+    x = acts(t, h, dtype, 881).to(DEV)
+    g = gate.to(DEV)
+    batch_rows = 1
+    full = eng.forward(0, x, g, batch_rows=batch_rows).clone()
+    r = eng.routing()
+    idx = torch.from_numpy(r["topk_idx"]).to(torch.int32)          # -1 = dropped pair (Switch capacity, NLLB zero weight)
+    w = torch.from_numpy(r["topk_w"]).to(torch.float32)
+    mask = torch.zeros(t, e, dtype=torch.bool)
+    for ti in range(t):
+        for j in idx[ti]:
+            if j >= 0:
+                mask[ti, int(j)] = True
+    y, counts, _ = eng.dispatch_mask(0, x, mask.to(DEV))
+    assert int(counts.sum()) == int((idx >= 0).sum())
+    prob = w[:, 0].contiguous().to(DEV) if family == "switch" else None
+    out = eng.combine(y.contiguous(), idx.to(DEV), w.to(DEV), x2=x, router_prob=prob)
+    assert torch.equal(out.cpu(), full.cpu()), f"{family}: standalone combine differs from the fused forward"
+    eng.close()
+
+
+def test_skewed_routing_on_the_sync_free_path():
+    """Every token routed to the same two experts (200 rows each) while the sync-free path sizes its launch from the
+    ESTIMATE min(T, 1.5*T*K/E + 1) = 76 rows: the first forward takes the decision path (exact counts), the second
+    and third the sync-free path — all three must match the oracle."""
+    h, f, e, k, t = 256, 512, 8, 2, 200
+    gate, experts, _ = make_weights("mixtral", h, f, e, 910, torch.bfloat16)
+    gate = gate.clone()
+    gate[:, 0] = 0
+    gate[0, 0], gate[1, 0] = 1.0, 0.9          # feature 0 decides: experts 0 and 1 win for every token
+    x = acts(t, h, torch.bfloat16, 911).clone()
+    x[:, 0] = 4.0
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts)
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    assert set(ref.topk_idx.reshape(-1).tolist()) == {0, 1}
+    for i in range(3):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        if i == 0:
+            eng.sync_copies()  # every expert resident and landed: the next forwards are sync-free
+            for ee in range(e):
+                if not eng.is_resident(0, ee):
+                    eng.prefetch(0, [ee])
+            eng.sync_copies()
+        r = eng.routing()
+        assert list(r["counts"]) == [t, t, 0, 0, 0, 0, 0, 0]
+        assert_block_close(out, ref, torch.bfloat16, f"skewed routing, forward {i}")
+    eng.close()
