@@ -189,7 +189,8 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
 
     ep = None
     if use_ep:
-        ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E)
+        ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, native=None if args.ep_transport == "auto" else False)
+        log(f"expert-parallel transport: {'native, ' if ep.native else 'torch.distributed; native: '}{ep.native_note}")
 
         def layer_fwd(l, x):
             ep.forward(l, x, gates[l], out=out)
@@ -492,7 +493,9 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
     res = {"label": label, "family": family, "cfg": cfg, "L": L, "E": E, "K": K, "H": H, "B": B, "dt": dt,
            "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
            "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
-           "warm": warm, "st": st, "ep_phases": ep_phases}
+           "warm": warm, "st": st, "ep_phases": ep_phases,
+           "ep_transport": None if ep is None else ("RCCL called from inside the engine, one host call per layer (moeinf_ep_moe_forward)" if ep.native
+                                                    else f"torch.distributed all_to_all_single, five host calls per layer (native: {ep.native_note})")}
     eng.close()
     return res
 
@@ -517,6 +520,8 @@ def main():
     ap.add_argument("--prompt", type=int, default=512, help="prefill length run once before decoding (examples/interface_example.py protocol); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the cpu_baseline AND parity legs")
     ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
+    ap.add_argument("--ep-transport", default="auto", choices=["auto", "torch"],
+                    help="auto: RCCL called from inside the engine (one host call per layer) if its self-test passes on every rank, else torch.distributed; torch: always torch.distributed")
     ap.add_argument("--cpu-sample-layers", type=int, default=4)
     ap.add_argument("--cpu-sample-steps", type=int, default=3)
     ap.add_argument("--miss-heavy-frac", type=float, default=0.5, help="miss_heavy leg: cache budget as a fraction of the expert bytes (0 = skip)")
@@ -612,6 +617,7 @@ def main():
             "parity": r["parity"],
             "miss_heavy": r["miss"],
             "ep_phases_us_per_layer": r["ep_phases"],
+            "ep_transport": r["ep_transport"],
             "other_configs": others or None,
         }
         for pr in [r["parity"]] + [o.get("parity") for o in others]:

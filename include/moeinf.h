@@ -252,8 +252,9 @@ int moeinf_set_prefetch_governor(moeinf_engine* eng, float min_useful_fraction, 
  * call and has no such limit; expert_dispatcher.set_inputs grows it on demand).  Only grows; synchronises the device. */
 int moeinf_reserve_tokens(moeinf_engine* eng, int max_tokens);
 
-/* prefetch_handle.get_hit_rate() (archer_prefetch_handle.cpp:281-297): per-expert counters,
- * out[L*E][6] = {visit_cnt, hit_cnt, miss_cnt, prefetch_cnt, incache_visit_count, resident} */
+/* prefetch_handle.get_hit_rate() (archer_prefetch_handle.cpp:281-297; columns model_topology.cpp:253-263): per-expert
+ * counters, out[L*E][7] = {visit_cnt, hit_cnt, miss_cnt, prefetch_cnt, incache_visit_count, resident, unused_count}
+ * (unused_count: times the expert was evicted after a speculative copy no dispatch ever used, task_scheduler.cpp:304) */
 int moeinf_get_expert_counters(moeinf_engine* eng, int64_t* out, int64_t n_int64);
 int moeinf_get_stats(moeinf_engine* eng, moeinf_stats* out);
 int moeinf_reset_stats(moeinf_engine* eng);
@@ -272,7 +273,7 @@ typedef struct moeinf_profile {
   double route_ms, ffn1_ms, ffn2_ms, combine_ms;
   double host_wait_ms; /* wall-clock time the host spent blocked on the routing D2H */
 } moeinf_profile;
-int moeinf_set_profiling(moeinf_engine* eng, int enabled);
+int moeinf_set_profiling(moeinf_engine* eng, int enabled); /* bit 0: per-kernel events; bit 1: per-phase events of moeinf_ep_moe_forward */
 /* synchronises the last stream, returns the accumulated numbers and resets them */
 int moeinf_get_profile(moeinf_engine* eng, moeinf_profile* out);
 
@@ -421,6 +422,29 @@ int moeinf_ep_expert_ffn_rows(moeinf_engine* eng, int layer, const void* recv_de
  * (DeepSeek) registered, its FFN over x_dev runs here, on the token's home rank, and is added last. */
 int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows,
                       void* stream);
+
+/* ---- native transport of the exchange: a whole expert-parallel layer in ONE call ----------------------------------
+ * RCCL (ncclSend/ncclRecv in one group = an all-to-all over xGMI) is called from inside the engine; the library is
+ * bound at run time (the copy PyTorch-ROCm already loaded, else ROCm's).  Bootstrap like any NCCL program: rank 0 gets
+ * a 128-byte unique id and hands it to the other ranks over whatever channel the host has (torch.distributed
+ * broadcast, a file, MPI); every rank then calls moeinf_ep_comm_init (collective; rank/size = cfg.ep_rank/ep_size).
+ * cap_tokens = the largest token count per forward through this path, THE SAME ON EVERY RANK (it sizes the per-peer row
+ * slots of the fixed-capacity exchange: cap_tokens * min(K, ceil(E/ep_size))).  The reference has no collective here:
+ * it copies rows between GPUs from one process (core/parallel/expert_dispatcher.cpp:284,405). */
+int moeinf_ep_comm_unique_id(void* id_out, int nbytes /* 128 */);
+int moeinf_ep_comm_init(moeinf_engine* eng, const void* unique_id, int nbytes, int cap_tokens);
+/* equal-split all-to-all of device buffers on `stream`: segment p (bytes_per_peer bytes) of send_dev goes to rank p */
+int moeinf_ep_all_to_all(moeinf_engine* eng, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
+/* moeinf_moe_forward for an expert-parallel engine: moeinf_ep_route_pack -> all-to-all -> moeinf_ep_expert_ffn ->
+ * all-to-all -> moeinf_ep_combine, all enqueued on `stream` from this one call (tokens <= cap_tokens). */
+int moeinf_ep_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                          void* out_dev, void* stream);
+/* per-phase HIP-event times of moeinf_ep_moe_forward calls made while moeinf_set_profiling was on (synchronises, resets) */
+typedef struct moeinf_ep_profile {
+  int64_t calls;
+  double route_pack_ms, a2a_dispatch_ms, owner_ffn_ms, a2a_combine_ms, combine_ms;
+} moeinf_ep_profile;
+int moeinf_ep_get_profile(moeinf_engine* eng, moeinf_ep_profile* out);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,14 @@ class Profile(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class EpProfile(C.Structure):
+    _fields_ = [("calls", C.c_int64), ("route_pack_ms", C.c_double), ("a2a_dispatch_ms", C.c_double), ("owner_ffn_ms", C.c_double),
+                ("a2a_combine_ms", C.c_double), ("combine_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _P = C.c_void_p
 _I32P = C.POINTER(C.c_int32)
 _I64P = C.POINTER(C.c_int64)
@@ -142,6 +150,11 @@ PROTOTYPES = {
     "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "moeinf_ep_route_pack": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "moeinf_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "moeinf_ep_comm_unique_id": (C.c_int, [_P, C.c_int]),
+    "moeinf_ep_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "moeinf_ep_all_to_all": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "moeinf_ep_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "moeinf_ep_get_profile": (C.c_int, [_P, C.POINTER(EpProfile)]),
 }
 
 

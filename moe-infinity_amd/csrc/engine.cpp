@@ -25,6 +25,7 @@
 #include <map>
 #include <mutex>
 #include "aio_pool.h"
+#include "ep_comm.h"
 #include "offload_store.h"
 #include "prefetch_queue.h"
 #include "tracer.h"
@@ -131,6 +132,7 @@ struct Node {
   bool copy_inflight = false;  // an H2D transfer out of `host` was issued and has not been OBSERVED complete yet
   bool prefetched = false;     // resident because of a prefetch, not yet dispatched
   int64_t visit = 0, hit = 0, miss = 0, prefetch_cnt = 0;
+  int64_t unused = 0;          // evicted after a speculative copy that no dispatch ever used (Node::unused_count, task_scheduler.cpp:304)
   // disk tier (register_expert_from_store): where the host blob can be re-read from when the arena evicted it
   const OffloadStore* store = nullptr;
   uint32_t store_ids[4] = {0, 0, 0, 0};
@@ -252,6 +254,14 @@ struct moeinf_engine {
   int ep_alloc_cap = 0;  // what the EP workspace is sized for
   int64_t ep_alloc_np = 0;  // ... and the max_tokens*K it was built for
 
+  // native transport of the exchange (moeinf_ep_comm_init): RCCL communicator + engine-owned exchange buffers
+  RcclComm ep_comm = nullptr;
+  int ep_cap_tokens = 0, ep_x_cap_rows = 0;
+  void *ep_x_send = nullptr, *ep_x_recv = nullptr, *ep_x_y = nullptr, *ep_x_ret = nullptr;
+  struct EpProfRec { hipEvent_t ev[6]; };
+  std::vector<EpProfRec> ep_prof_pending;
+  moeinf_ep_profile ep_prof;
+
   // stage-2 output override of the expert-parallel FFN: rows go straight to the reply buffer, in arrival order
   void* ovr_out = nullptr;
   const int32_t* ovr_map = nullptr;
@@ -266,7 +276,7 @@ struct moeinf_engine {
   moeinf_stats st;
 
   // profiling
-  bool profiling = false;
+  bool profiling = false, ep_profiling = false;
   struct ProfRec { hipEvent_t ev[6]; };
   std::vector<ProfRec> prof_pending;
   moeinf_profile prof;
@@ -392,6 +402,8 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   hipDeviceSynchronize();
   for (auto& n : g->nodes) { for (auto& h : n.disk_reqs) PrioAioPool::wait(h); n.disk_reqs.clear(); set_node_store(n, nullptr); }  // reads into the arena
   g->aio.reset();
+  if (g->ep_comm) { std::string e; if (const RcclApi* api = RcclApi::get(&e)) api->CommDestroy(g->ep_comm); g->ep_comm = nullptr; }
+  for (void* b : {g->ep_x_send, g->ep_x_recv, g->ep_x_y, g->ep_x_ret}) if (b) hipFree(b);
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
   for (auto p : g->arena_chunks) hipHostFree(p);
@@ -434,6 +446,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   g->cfg = *cfg;
   memset(&g->st, 0, sizeof g->st);
   memset(&g->prof, 0, sizeof g->prof);
+  memset(&g->ep_prof, 0, sizeof g->ep_prof);
   for (int i = 0; i < kFenceRing; ++i) g->fence_ev[i] = nullptr;
   g->L = cfg->num_layers; g->E = cfg->num_experts; g->K = cfg->top_k; g->H = cfg->hidden; g->F = cfg->inter; g->Fs = cfg->shared_inter;
   g->has_shared = cfg->shared_inter > 0;
@@ -669,7 +682,7 @@ static int acquire_slot(moeinf_engine* g, int idx, int* slot_out, bool allow_pro
   drop_ready_count(g, (int)v);
   const int slot = vn.slot;
   vn.slot = -1;
-  if (vn.prefetched) { g->st.prefetch_wasted += 1; g->gov_score += (0.f - g->gov_score) * 0.125f; g->gov_outcomes += 1; }  // brought in speculatively, evicted before any dispatch used it
+  if (vn.prefetched) { g->st.prefetch_wasted += 1; vn.unused += 1; g->gov_score += (0.f - g->gov_score) * 0.125f; g->gov_outcomes += 1; }  // brought in speculatively, evicted before any dispatch used it
   vn.prefetched = false;
   g->pol[v].resident = false;
   g->slots[slot].node = -1;
@@ -1488,7 +1501,8 @@ extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int3
 
 extern "C" int moeinf_set_profiling(moeinf_engine* g, int enabled) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  g->profiling = enabled != 0;
+  g->profiling = (enabled & 1) != 0;     // per-kernel events of the forwards
+  g->ep_profiling = (enabled & 2) != 0;  // per-phase events of moeinf_ep_moe_forward
   return MOEINF_OK;
 }
 
@@ -1732,13 +1746,13 @@ extern "C" int moeinf_sync_copies(moeinf_engine* g) {
 extern "C" int moeinf_get_expert_counters(moeinf_engine* g, int64_t* out, int64_t n_int64) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
   drain_mirrors(g, true);
-  if (n_int64 != (int64_t)g->L * g->E * 6) return fail(MOEINF_ERR_INVALID, "n_int64 must be L*E*6");
+  if (n_int64 != (int64_t)g->L * g->E * 7) return fail(MOEINF_ERR_INVALID, "n_int64 must be L*E*7");
   for (int l = 0; l < g->L; ++l)
     for (int e = 0; e < g->E; ++e) {
       const int idx = node_index(g, l, e);
-      int64_t* o = out + ((int64_t)l * g->E + e) * 6;
+      int64_t* o = out + ((int64_t)l * g->E + e) * 7;
       o[0] = g->nodes[idx].visit; o[1] = g->nodes[idx].hit; o[2] = g->nodes[idx].miss; o[3] = g->nodes[idx].prefetch_cnt;
-      o[4] = g->pol[idx].incache; o[5] = g->nodes[idx].slot >= 0 ? 1 : 0;
+      o[4] = g->pol[idx].incache; o[5] = g->nodes[idx].slot >= 0 ? 1 : 0; o[6] = g->nodes[idx].unused;
     }
   return MOEINF_OK;
 }
@@ -2438,5 +2452,101 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
   ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? (g->last_hidden_shared ? g->d_y_sh : g->d_y) : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
   ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
   HIPCHK(launch_combine(ca, st));
+  return MOEINF_OK;
+}
+
+// ---- native transport of the exchange (ep_comm.h) ---------------------------------------------------------------
+extern "C" int moeinf_ep_comm_unique_id(void* id_out, int nbytes) {
+  if (!id_out || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "id_out must hold %d bytes", (int)sizeof(RcclUniqueId));
+  std::string err;
+  const RcclApi* api = RcclApi::get(&err);
+  if (!api) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
+  RcclUniqueId id;
+  const int rc = api->GetUniqueId(&id);
+  if (rc) return fail(MOEINF_ERR_HIP, "ncclGetUniqueId: %s", api->GetErrorString(rc));
+  memcpy(id_out, &id, sizeof id);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_comm_init(moeinf_engine* g, const void* unique_id, int nbytes, int cap_tokens) {
+  if (!g || !unique_id || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "unique_id must be %d bytes", (int)sizeof(RcclUniqueId));
+  if (cap_tokens <= 0 || cap_tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "cap_tokens %d not in 1..max_tokens(%d)", cap_tokens, g->cfg.max_tokens);
+  if (g->ep_comm) return fail(MOEINF_ERR_STATE, "the engine already has a communicator");
+  std::string err;
+  const RcclApi* api = RcclApi::get(&err);
+  if (!api) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  // exchange buffers: cap_rows row slots per peer, both directions (send/recv rows carry the 16-byte id tail)
+  const int cap_rows = ep_min_cap(g, cap_tokens);
+  const size_t n = (size_t)g->cfg.ep_size * cap_rows;
+  if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
+  HIPCHK(hipMalloc(&g->ep_x_send, n * ep_row_elems(g) * g->es));
+  HIPCHK(hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es));
+  HIPCHK(hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es));
+  HIPCHK(hipMalloc(&g->ep_x_ret, n * (size_t)g->H * g->es));
+  HIPCHK(hipMemset(g->ep_x_y, 0, n * (size_t)g->H * g->es));  // padding rows travel as they are: keep them defined
+  RcclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  const int rc = api->CommInitRank(&g->ep_comm, g->cfg.ep_size, id, g->cfg.ep_rank);
+  if (rc) { g->ep_comm = nullptr; return fail(MOEINF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", g->cfg.ep_rank, g->cfg.ep_size, api->GetErrorString(rc)); }
+  g->ep_cap_tokens = cap_tokens;
+  g->ep_x_cap_rows = cap_rows;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_all_to_all(moeinf_engine* g, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream) {
+  if (!g || !send_dev || !recv_dev || bytes_per_peer <= 0) return fail(MOEINF_ERR_INVALID, "bad all_to_all arguments");
+  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no communicator: call moeinf_ep_comm_init first");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  const std::string err = rccl_all_to_all(RcclApi::get(nullptr), g->ep_comm, g->cfg.ep_size, send_dev, recv_dev, (size_t)bytes_per_peer, (hipStream_t)stream);
+  if (!err.empty()) return fail(MOEINF_ERR_HIP, "%s", err.c_str());
+  return MOEINF_OK;
+}
+
+// One expert-parallel MoE layer in ONE host call (fixed-capacity form): router + send rows -> all-to-all -> owner FFN ->
+// all-to-all -> combine, every launch and both collectives enqueued on `stream` from here.
+extern "C" int moeinf_ep_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                                     void* out_dev, void* stream) {
+  if (!g || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no communicator: call moeinf_ep_comm_init first");
+  if (tokens > g->ep_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the communicator's exchange buffers", tokens, g->ep_cap_tokens);
+  hipStream_t st = (hipStream_t)stream;
+  const RcclApi* api = RcclApi::get(nullptr);
+  const int cap = g->ep_x_cap_rows, G = g->cfg.ep_size;
+  moeinf_engine::EpProfRec pr;
+  const bool prof = g->ep_profiling;
+  auto mark = [&](int i) { if (prof) hipEventRecord(pr.ev[i], st); };
+  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
+  mark(0);
+  CHK(moeinf_ep_route_pack(g, layer, x_dev, tokens, batch_rows, gate_w_dev, g->ep_x_send, nullptr, cap, stream));
+  mark(1);
+  std::string err = rccl_all_to_all(api, g->ep_comm, G, g->ep_x_send, g->ep_x_recv, (size_t)cap * ep_row_elems(g) * g->es, st);
+  if (!err.empty()) return fail(MOEINF_ERR_HIP, "dispatch all-to-all: %s", err.c_str());
+  mark(2);
+  CHK(moeinf_ep_expert_ffn(g, layer, g->ep_x_recv, g->ep_x_y, cap, stream));
+  mark(3);
+  err = rccl_all_to_all(api, g->ep_comm, G, g->ep_x_y, g->ep_x_ret, (size_t)cap * g->H * g->es, st);
+  if (!err.empty()) return fail(MOEINF_ERR_HIP, "combine all-to-all: %s", err.c_str());
+  mark(4);
+  CHK(moeinf_ep_combine(g, x_dev, g->ep_x_ret, out_dev, cap, stream));
+  mark(5);
+  if (prof) g->ep_prof_pending.push_back(pr);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_get_profile(moeinf_engine* g, moeinf_ep_profile* out) {
+  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  if (g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
+  for (auto& r : g->ep_prof_pending) {
+    float ms = 0.f;
+    double* dst[5] = {&g->ep_prof.route_pack_ms, &g->ep_prof.a2a_dispatch_ms, &g->ep_prof.owner_ffn_ms, &g->ep_prof.a2a_combine_ms, &g->ep_prof.combine_ms};
+    for (int i = 0; i < 5; ++i) if (hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]) == hipSuccess) *dst[i] += ms;
+    for (int i = 0; i < 6; ++i) g->event_pool.push_back(r.ev[i]);
+    g->ep_prof.calls += 1;
+  }
+  g->ep_prof_pending.clear();
+  *out = g->ep_prof;
+  memset(&g->ep_prof, 0, sizeof g->ep_prof);
   return MOEINF_OK;
 }

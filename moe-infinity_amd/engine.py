@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Config, MoeInfError, Profile, Stats, check, load_library
+from ._lib import Config, EpProfile, MoeInfError, Profile, Stats, check, load_library
 from .config import DTYPE_BF16, DTYPE_F32, EngineConfig
 
 FWD_DEFAULT, FWD_ROUTE_ONLY, FWD_NO_COMBINE = 0, 1, 2
@@ -262,8 +262,8 @@ class MoEEngine:
         check(self.lib.moeinf_set_prefetch_governor(self._h, float(min_useful_fraction), int(probe_every)))
 
     def expert_counters(self) -> np.ndarray:
-        """[L, E, 6] = visit, hit, miss, prefetch, incache_visit_count, resident (get_hit_rate analogue)."""
-        a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 6), np.int64)
+        """[L, E, 7] = visit, hit, miss, prefetch, incache_visit_count, resident, unused_count (get_hit_rate analogue)."""
+        a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 7), np.int64)
         check(self.lib.moeinf_get_expert_counters(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
         return a
 
@@ -275,8 +275,9 @@ class MoEEngine:
     def reset_stats(self):
         check(self.lib.moeinf_reset_stats(self._h))
 
-    def set_profiling(self, on: bool):
-        check(self.lib.moeinf_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, on):
+        """True / 1: per-kernel events; 2: per-phase events of ep_moe_forward; 3: both"""
+        check(self.lib.moeinf_set_profiling(self._h, int(on)))
 
     def profile(self) -> dict:
         """Accumulated per-kernel event timings + algorithmic bytes since the last call (resets)."""
@@ -318,6 +319,36 @@ class MoEEngine:
     def ep_combine(self, x2: torch.Tensor, ret: torch.Tensor, out: torch.Tensor, cap_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(self.lib.moeinf_ep_combine(self._h, _ptr(x2), _ptr(ret), _ptr(out), cap_rows, stream))
+
+
+    # ---- native transport (RCCL called from inside the engine) ---------------------------------
+    def ep_comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(self.lib.moeinf_ep_comm_unique_id(buf, 128))
+        return bytes(buf)
+
+    def ep_comm_init(self, unique_id: bytes, cap_tokens: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(self.lib.moeinf_ep_comm_init(self._h, buf, 128, int(cap_tokens)))
+
+    def ep_all_to_all(self, send: torch.Tensor, recv: torch.Tensor):
+        """equal-split all-to-all of two device tensors of the same size (segment p goes to rank p)"""
+        nbytes = send.numel() * send.element_size()
+        if nbytes != recv.numel() * recv.element_size() or nbytes % self.cfg.ep_size:
+            raise ValueError("send/recv must have the same size, divisible by ep_size")
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_all_to_all(self._h, _ptr(send), _ptr(recv), nbytes // self.cfg.ep_size, stream))
+
+    def ep_moe_forward(self, layer: int, x2: torch.Tensor, gate_w: torch.Tensor, out: torch.Tensor, batch_rows: int = 1):
+        """one expert-parallel MoE layer in one host call (moeinf_ep_moe_forward)"""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_moe_forward(self._h, layer, _ptr(x2), x2.shape[0], batch_rows, _ptr(gate_w), _ptr(out), stream))
+        self._last_T = x2.shape[0]
+
+    def ep_profile(self) -> dict:
+        p = EpProfile()
+        check(self.lib.moeinf_ep_get_profile(self._h, C.byref(p)))
+        return p.as_dict()
 
 
 class CacheSim:

@@ -72,7 +72,8 @@ class ExpertParallelMoE:
     PHASES = ("route_pack", "a2a_dispatch", "owner_ffn", "a2a_combine", "combine")
 
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
-                 group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None):
+                 group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None,
+                 native: Optional[bool] = False):
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
@@ -94,9 +95,80 @@ class ExpertParallelMoE:
         self.send_counts, self.recv_counts = mk(self.world, dt=torch.int32), mk(self.world, dt=torch.int32)
         self.device = torch.device(device)
         # per-phase timers (bench.py --gpus N): events on the current stream around the five phases of a layer
-        self.profile = False
+        self._profile = False
         self._marks = []
         self.last_form = None
+        # native transport: RCCL called from inside the engine, a whole layer = ONE host call (moeinf_ep_moe_forward)
+        self.native = False
+        self.native_note = "not requested"
+        if native is not False:
+            self.native = self._try_native(max_tokens)
+
+    @property
+    def profile(self):
+        return self._profile
+
+    @profile.setter
+    def profile(self, on):
+        self._profile = bool(on)
+        if self.native:
+            self.ops.engine.set_profiling(2 if on else 0)
+
+    # -- native transport -----------------------------------------------------------------------
+    def _agree(self, ok: bool) -> bool:
+        """True only if EVERY rank says ok (a path that some ranks take and others do not would dead-lock)"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
+    def _try_native(self, cap_tokens: int) -> bool:
+        """Bootstrap the engine's own RCCL communicator through the existing process group, then PROVE it: a tagged
+        all-to-all must deliver the expected rows on every rank.  Any failure, on any rank, leaves every rank on the
+        torch.distributed transport (the decision is collective)."""
+        eng = getattr(self.ops, "engine", None)
+        if eng is None or self.device.type != "cuda" or not hasattr(eng, "ep_comm_init"):
+            self.native_note = "ops are not the HIP engine"
+            return False
+        if dist.get_backend(self.group) != "nccl":
+            self.native_note = "process group is not RCCL (several ranks may share one GPU)"
+            return False
+        uid = None
+        try:
+            uid = eng.ep_comm_unique_id()  # every rank: proves librccl can be bound here
+        except Exception as ex:  # noqa: BLE001
+            self.native_note = f"librccl not usable: {ex}"
+        if not self._agree(uid is not None):
+            return False
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        ok = True
+        try:
+            eng.ep_comm_init(bytes(t.cpu().tolist()), cap_tokens)
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"ncclCommInitRank failed: {ex}"
+        if not self._agree(ok):
+            return False
+        # self-test: segment p of rank r carries the value 16*r + p; after the exchange segment p must hold 16*p + r
+        seg = 1024
+        send = torch.empty(self.world * seg, dtype=torch.int32, device=self.device)
+        for p in range(self.world):
+            send[p * seg:(p + 1) * seg] = 16 * self.rank + p
+        recv = torch.full_like(send, -1)
+        try:
+            eng.ep_all_to_all(send, recv)
+            torch.cuda.synchronize(self.device)
+            want = torch.cat([torch.full((seg,), 16 * p + self.rank, dtype=torch.int32) for p in range(self.world)])
+            ok = bool(torch.equal(recv.cpu(), want))
+            if not ok:
+                self.native_note = "native all-to-all self-test delivered wrong rows"
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"native all-to-all failed: {ex}"
+        if not self._agree(ok):
+            return False
+        self.native_note = "RCCL inside the engine (self-test passed on every rank)"
+        return True
 
     # -- timers ---------------------------------------------------------------------------------
     def _mark(self):
@@ -113,6 +185,11 @@ class ExpertParallelMoE:
 
     def phase_times_us(self):
         """Mean microseconds per layer call of each phase since profiling was switched on."""
+        if self.native:
+            p = self.ops.engine.ep_profile()
+            c = max(1, p["calls"])
+            return {"calls": p["calls"], **{ph: round(p[ph + "_ms"] * 1e3 / c, 2) for ph in self.PHASES},
+                    "timed_by": "HIP events inside moeinf_ep_moe_forward"}
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         n = len(self.PHASES) + 1
@@ -148,6 +225,9 @@ class ExpertParallelMoE:
             out = torch.empty_like(x2)
         if x2.shape[0] * self.top_k > self.var_threshold and self.world > 1:
             self._forward_variable(layer, x2, gate_w, out)
+        elif self.native:
+            self.last_form = "fixed"
+            self.ops.engine.ep_moe_forward(layer, x2, gate_w, out)
         else:
             self._forward_fixed(layer, x2, gate_w, out)
         return out.reshape(shape)

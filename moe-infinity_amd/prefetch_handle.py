@@ -81,7 +81,7 @@ class PrefetchHandle:
         cpu_visit, hit, gpu_hit, cpu_hit, #tensor ids, prefetch, unused_count, io_state, is_sparse.  One row per
         expert in (layer, expert) order (the reference also lists the dense nodes, which this engine does not
         manage).  There is no CPU execution here, so the cpu_* columns are 0."""
-        c = self.engine.expert_counters()  # [L, E, 6] = visit, hit, miss, prefetch, incache, resident
+        c = self.engine.expert_counters()  # [L, E, 7] = visit, hit, miss, prefetch, incache, resident, unused
         L, E, _ = c.shape
         out = np.zeros((L * E, 11), np.int64)
         v, h, _m, p = (c[..., i].reshape(-1) for i in range(4))

@@ -281,13 +281,20 @@ class prefetch_handle:
     def get_hit_rate(self) -> torch.Tensor:
         """GetHitRate (archer_prefetch_handle.cpp:281-297; columns: model_topology.cpp:253-263), one row per node in
         topology order.  Experts take their counters from the engine."""
+        # columns (model_topology.cpp:253-263): visit_cnt, gpu_visit_cnt, cpu_visit_cnt, hit_cnt, gpu_hit_cnt, cpu_hit_cnt,
+        # len(tensor_ids), prefetch_cnt, unused_count, io_state, is_sparse.  What the reference's code can actually put
+        # there: every execution targets the GPU, so gpu_visit_cnt == visit_cnt (task_scheduler.cpp:140,154-156) and
+        # cpu_visit_cnt stays 0 (its only increment is commented out, :147-151); cpu_hit_cnt needs a CPU destination
+        # (:179-181: never requested); io_state is reset to NODE_STATE_NONE by the getter itself (:250).  unused_count is
+        # real: evictions of a speculatively fetched node nobody visited (:304) — an engine counter for experts.
         rows = np.zeros((len(self._nodes), 11), np.int64)
         c = self.engine.expert_counters() if self.engine is not None else None
         for i, n in enumerate(self._nodes):
-            v, h, p = n.visit, n.hit, n.prefetch
+            v, h, p, unused = n.visit, n.hit, n.prefetch, 0
             if n.sparse and n.expert and c is not None:
                 v, h, _m, p = (int(x) for x in c[n.expert[0], n.expert[1], :4])
-            rows[i] = [v, v, 0, h, h, 0, len(n.ids), p, 0, 0, int(n.sparse)]
+                unused = int(c[n.expert[0], n.expert[1], 6])
+            rows[i] = [v, v, 0, h, h, 0, len(n.ids), p, unused, 0, int(n.sparse)]
         return torch.from_numpy(rows)
 
     def set_trace(self, trace: torch.Tensor):
@@ -379,6 +386,10 @@ class expert_dispatcher:
                 raise RuntimeError(f"tensor {tensor_ids[0]} is not a [F, H] matrix in the offload index")
             f, hid = int(m["shape"][0]), int(m["shape"][1])
             rk = _ROUTER_OF.get(self.expert_type, Cf.ROUTER_MIXTRAL)
+            # The dispatcher's constructor carries no top-k (py_archer_prefetch.cpp:84-85) and this path never runs the
+            # engine's router (the caller's Python router hands over a dense mask), so K only SIZES the workspace
+            # (max_tokens * K rows).  Without configure(top_k=...) the engine's own limit min(8, E) is used: an upper
+            # bound for every supported model (K <= 8), i.e. more workspace, never too little.
             k = {Cf.ROUTER_SWITCH: 1, Cf.ROUTER_NLLB: 2}.get(rk, _OPTIONS["top_k"] or min(8, self.num_experts))
             cfg = Cf.EngineConfig(num_layers=self.num_layers, num_experts=self.num_experts, expert_type=self.expert_type,
                                   hidden=hid, inter=f, top_k=k, router_kind=rk, dtype=self.dtype, device_id=h.device_id,

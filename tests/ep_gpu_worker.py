@@ -35,7 +35,7 @@ def main():
                     eng.register_expert(l, i, ex)
             if ws[l][2]:
                 eng.register_shared(l, ws[l][2])
-        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64)
+        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64, num_experts=e)
         for t in (1, 3 + rank, tmax - 3 * rank):  # batch 1, ragged small batches (fixed form), prefill-sized (variable split)
             for l in range(L):
                 x = acts(t, h, torch.bfloat16, 3200 + 7 * t + l + 1000 * rank)

@@ -234,17 +234,28 @@ def test_expert_parallel_module_through_rccl_world_size_1():
             tmax = 40
             eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=tmax)
             register_all(eng, experts, shared)
-            ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, DEV)
-            g = gate.to(DEV)
-            for t in (3, 40):
-                x = acts(t, h, torch.bfloat16, 541 + t)
-                for _ in range(2):
-                    out = ep.forward(0, x.to(DEV), g)
-                if family == "mixtral":
-                    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
-                else:
-                    ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
-                assert_block_close(out, ref, torch.bfloat16, f"EP module, {family}, {t} tokens")
+            # torch.distributed transport (five host calls per layer), then the engine's own RCCL communicator (one host call
+            # per layer: moeinf_ep_moe_forward) — bootstrapped through the process group and self-tested before use
+            for native in (False, None):
+                ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, DEV, num_experts=e, native=native)
+                if native is None:
+                    assert ep.native, f"native transport not available: {ep.native_note}"
+                g = gate.to(DEV)
+                for t in (1, 3, 40):
+                    x = acts(t, h, torch.bfloat16, 541 + t)
+                    for _ in range(3):  # the first forward takes the decision path, the others the sync-free (self-indexing) one
+                        out = ep.forward(0, x.to(DEV), g)
+                    if family == "mixtral":
+                        ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+                    else:
+                        ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+                    assert_block_close(out, ref, torch.bfloat16, f"EP module, {family}, {t} tokens, native={ep.native}")
+                if ep.native:
+                    ep.profile = True
+                    ep.forward(0, x.to(DEV), g)
+                    ph = ep.phase_times_us()
+                    assert ph["calls"] == 1 and all(ph[p] > 0 for p in ep.PHASES), ph
+                    ep.profile = False
             eng.close()
     finally:
         if created:
