@@ -150,3 +150,163 @@ def test_dense_nodes_over_the_cache_limit_are_dropped_and_refetched(tmp_path):
     finally:
         handle.clean_up_resources()
         P.configure(dense_cache_fraction=0.7, device_memory_bytes=0)
+
+
+# ---- (f)-2 with the reference's OWN caller ---------------------------------------------------------------------------
+# tests/golden/offload_engine_trace.json is the sequence of boundary calls that the REFERENCE'S code made — OffloadEngine.
+# _offload_state_dict / setup_archer_hooks (get_topology, gen_args_hook, register_expert) / the begin-end module hooks,
+# SyncMixtralSparseMoeBlock.forward and DistributedExpertExecutor.dispatch_local, executed from /root/reference by
+# oracle/gen_offload_trace.py against a recording stand-in of the pybind module (tests/test_ref_offload_trace_cpu.py keeps
+# the file in step with the reference).  /root/reference cannot travel to the GPU box, so here the REAL prefetch_op is
+# driven through a logging proxy: the set-up phase replays the recorded calls literally, the forward follows the toy
+# model, and the proxy's log must equal the reference's sequence call for call — then the logits must match too.
+class _Log:
+    def __init__(self, obj, log, pid):
+        self._o, self._log, self._pid = obj, log, pid
+
+    def __getattr__(self, name):
+        fn = getattr(self._o, name)
+
+        def call(*a):
+            r = fn(*a)
+            if name in ("begin", "end"):
+                self._log.append([name, int(a[0]), self._pid[id(a[1])]])
+            elif name == "offload":
+                self._log.append([name, int(a[1]), list(a[0].shape), str(a[0].dtype)])
+            elif name == "register":
+                self._log.append([name, int(a[1])])
+            elif name == "set_topology":
+                self._log.append([name, len(a[0])])
+            elif name in ("get_node_default_device",):
+                self._log.append([name, [int(t) for t in a[0]]])
+            elif name == "fetch_tensors":
+                self._log.append([name, int(a[0]), [int(t) for t in a[1]]])
+            elif name == "register_expert":
+                self._log.append([name, int(a[0]), int(a[1]), [int(t) for t in a[2]]])
+            elif name == "set_inputs":
+                self._log.append([name, list(a[0].shape), list(a[1].shape), [int(v) for v in a[1].reshape(-1, a[1].shape[-1]).sum(0)]])
+            elif name == "set_expected_queue":
+                self._log.append([name, int(a[0])])
+            elif name == "enqueue_expert":
+                self._log.append([name, int(a[0]), int(a[1]), int(a[2]), bool(a[3])])
+            elif name == "wait_expert":
+                self._log.append([name, len(r)])
+            return r
+
+        return call
+
+
+def test_prefetch_op_under_the_reference_offload_engines_own_call_sequence(tmp_path):
+    import json
+    import os
+
+    from moe_infinity_amd import prefetch_op as P
+    from moe_infinity_amd.expert_executor import DistributedExpertExecutor
+    from oracle.gen_offload_trace import build_model, toy_input
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "offload_engine_trace.json")))
+    sh = gold["shapes"]
+    L, E, K = sh["L"], sh["E"], sh["K"]
+    nid = gold["name_id_map"]
+
+    class _Expert(torch.nn.Module):  # the HF 4.37 Mixtral expert MLP: only its parameter names/shapes matter here
+        def __init__(self, cfg):
+            super().__init__()
+            self.w1 = torch.nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+            self.w2 = torch.nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+            self.w3 = torch.nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+
+    class _Block(torch.nn.Module):  # parameter layout of SyncMixtralSparseMoeBlock (mixtral.py:22-34); forward is driven below
+        def __init__(self, cfg):
+            super().__init__()
+            self.gate = torch.nn.Linear(cfg.hidden_size, cfg.num_local_experts, bias=False)
+            self.experts = torch.nn.ModuleList([_Expert(cfg) for _ in range(cfg.num_local_experts)])
+
+    model = build_model(_Block)  # same seed, same construction order -> the weights the reference run offloaded
+    state = {nid[n]: t.detach().clone() for n, t in model.state_dict().items()}
+    assert sorted(state) == list(range(len(nid)))
+    params = {}
+    for n, p in model.named_parameters():
+        p.data = torch.zeros(1, dtype=p.dtype)  # apply_to_model_decorator (model_offload.py:183-193)
+        params[nid[n]] = p
+    pid = {id(p): t for t, p in params.items()}
+
+    P.configure(dense_cache_fraction=0.7, device_memory_bytes=0, max_tokens=8, top_k=K)
+    log = []
+    handle = _Log(P.prefetch_handle(str(tmp_path), 0.5), log, pid)
+    disp = _Log(P.expert_dispatcher(E, L, 0, 4, 8), log, pid)
+    try:
+        calls = gold["calls"]
+        first_fwd = next(i for i, c in enumerate(calls) if c[0] == "forward")
+        for c in calls[:first_fwd]:  # set-up phase: the reference's calls, literally
+            if c[0] == "offload":
+                assert not handle._o.is_tensor_offloaded(c[1])
+                handle.offload(state[c[1]], c[1])
+            elif c[0] == "register":
+                handle.register(params[c[1]].data, c[1])
+            elif c[0] == "set_topology":
+                handle.set_topology([(name, groups) for name, groups in gold["topology"]])
+            elif c[0] == "get_node_default_device":
+                assert handle.get_node_default_device(c[1]) == 0
+            elif c[0] == "register_expert":
+                disp.register_expert(c[1], c[2], c[3])
+            else:
+                raise AssertionError(f"unexpected set-up call {c}")
+        ex = DistributedExpertExecutor(None)  # our mirror of dispatch_local, shown call-identical to the reference's in test_dropin_cpu.py
+        ex.set_expert_dispatcher(disp)
+        topo = dict((name, groups) for name, groups in gold["topology"])
+
+        def forward(x):
+            h = x.to(DEV)
+            for l in range(L):
+                handle.fetch_tensors(0, topo[f"layers.{l}"][0])                    # gen_args_hook's pre-forward hook (:775-783)
+                w, b = params[nid[f"layers.{l}.attn.weight"]], params[nid[f"layers.{l}.attn.bias"]]
+                handle.begin(0, w); handle.begin(0, b)                             # _pre_forward_module_hook (:925-947)
+                assert w.is_cuda and torch.equal(w.data.cpu(), state[nid[f"layers.{l}.attn.weight"]])
+                a = F.linear(h, w, b)
+                handle.end(0, w); handle.end(0, b)                                 # _post_forward_module_hook (:949-979)
+                assert w.numel() == 1
+                h = h + a
+                gw = params[nid[f"layers.{l}.block_sparse_moe.gate.weight"]]
+                handle.begin(0, gw)
+                hs = h.view(-1, h.shape[-1])
+                logits = F.linear(hs, gw)                                           # mixtral.py:46-65
+                handle.end(0, gw)
+                rw = torch.softmax(logits, dim=1, dtype=torch.float)
+                rw, sel = torch.topk(rw, K, dim=-1)
+                rw = (rw / rw.sum(-1, keepdim=True)).to(hs.dtype)
+                one = torch.nn.functional.one_hot(sel, num_classes=E)
+                wmask = (rw[:, :, None] * one).permute(0, 2, 1).sum(-1)
+                rmask = one.permute(0, 2, 1).sum(-1) > 0
+                res = ex.dispatch_local(hs, rmask, l)                               # mixtral.py:92-94
+                fin = torch.zeros_like(hs)
+                for out, _, idx, _ in res:                                          # mixtral.py:95-100
+                    tok = rmask[:, idx].bool()
+                    fin[tok, :] += out.to(wmask.device) * wmask[tok, idx][:, None]
+                h = h + fin.reshape(h.shape)
+            handle.fetch_tensors(0, topo["lm_head"][0])
+            lm = params[nid["lm_head.weight"]]
+            handle.begin(0, lm)
+            y = F.linear(h, lm)
+            handle.end(0, lm)
+            return y
+
+        x = toy_input()
+        log.append(["forward", 0])
+        y = forward(x)
+        log.append(["forward", 1])
+        y2 = forward(x)
+        assert torch.equal(y, y2)
+        # 1. the call sequence is the reference's, call for call (ids, shapes, per-expert token counts, queue lengths)
+        assert len(log) == len(calls), (len(log), len(calls))
+        for i, (got, want) in enumerate(zip(log, calls)):
+            assert got == want, f"boundary call {i}: ours {got}, the reference's {want}"
+        # 2. and the logits match what the reference's code computed on the CPU
+        want = torch.tensor(gold["output"]).reshape(gold["out_shape"])
+        rel = (y.float().cpu() - want).abs().mean().item() / want.abs().mean().item()
+        assert rel <= 1e-2, f"logits differ from the reference run: mean relative {rel:.3e}"
+        hr = handle._o.get_hit_rate()
+        assert tuple(hr.shape) == (len(gold["topology"]) - L + L * E, 11)
+    finally:
+        handle._o.clean_up_resources()
+        P.configure(dense_cache_fraction=0.7, device_memory_bytes=0, max_tokens=256, top_k=0)
