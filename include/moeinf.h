@@ -300,6 +300,15 @@ int moeinf_tracer_predict(moeinf_tracer* tr, int64_t seq_id, int layer, const in
 int moeinf_tracer_prefetch_order(const moeinf_tracer* tr, int layer, const float* matrix, int32_t* layers_out,
                                  int32_t* experts_out, float* scores_out, int32_t* n_out);
 int moeinf_tracer_get_eam(moeinf_tracer* tr, int64_t seq_id, double* eam_out);
+/* Activation-aware speculation INSIDE the engine.  With a tracer attached, every forward feeds the running sequence's EAM
+ * from the routing mirror its index kernel wrote (ExpertTracer.update_entry) and — on forwards that take the decision
+ * path, where the host holds the layer's routing anyway — runs ExpertPredictor.predict + ExpertPrefetcher.prefetch_experts
+ * for the next `lookahead_layers` layers: experts whose predicted share of their layer's activations is >= min_share,
+ * best first, at most max_experts per layer call, go into the pending-transfer queue (moeinf_prefetch semantics).  No
+ * device synchronisation and no host code between "layer l routed" and "layer l+k requested" (the reference does this in
+ * Python with a D2H read per layer, expert_tracer.py:94-125, and requests EVERY predicted expert).  tr == NULL or
+ * seq_id < 0 detaches.  The tracer must outlive the attachment. */
+int moeinf_set_predictor(moeinf_engine* eng, moeinf_tracer* tr, int64_t seq_id, int lookahead_layers, float min_share, int max_experts);
 
 /* ---- disk tier: the reference's offload directory (host only) ----------------
  * Reads and writes `<offload_path>/archer_index` + `archer_param_<n>` in the reference's own format

@@ -254,6 +254,15 @@ struct moeinf_engine {
   int ep_alloc_cap = 0;  // what the EP workspace is sized for
   int64_t ep_alloc_np = 0;  // ... and the max_tokens*K it was built for
 
+  // activation-aware speculation inside the engine (moeinf_set_predictor): the attached tracer is fed from the routing
+  // mirrors the index kernels write — no read-back, no Python between "layer l routed" and "layer l+k experts requested"
+  Tracer* pred_tracer = nullptr;
+  int64_t pred_seq = -1;
+  int pred_lookahead = 0, pred_max = 0;
+  float pred_min_share = 0.f;
+  std::vector<float> pred_matrix;
+  int64_t pred_calls = 0, pred_enqueued = 0;
+
   // native transport of the exchange (moeinf_ep_comm_init): RCCL communicator + engine-owned exchange buffers
   RcclComm ep_comm = nullptr;
   int ep_cap_tokens = 0, ep_x_cap_rows = 0;
@@ -1041,6 +1050,52 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
 }
 
+// ExpertPredictor.predict + ExpertPrefetcher.prefetch_experts (moe_infinity/memory/expert_predictor.py:17-35,
+// expert_prefetcher.py:42-59) for the attached sequence, from a routing mirror {n_active, counts[E+1], active[E+1]}:
+// update the sequence's EAM with this layer's experts, find the nearest historical EAM, and (prefetch) request the
+// experts it predicts for the next `pred_lookahead` layers — only those whose predicted share of their layer's
+// activations is >= pred_min_share, best first, at most pred_max per call, never a resident one.  The reference
+// requests EVERY predicted expert of every later layer; on a 56 GB/s link that is 5x slower than fetching on demand
+// (DESIGN.md section 7.3), hence the threshold and the bounded look-ahead.
+static int predictor_observe(moeinf_engine* g, int layer, const int32_t* mirror, bool prefetch) {
+  Tracer* tr = g->pred_tracer;
+  if (!tr || !tr->has(g->pred_seq)) return MOEINF_OK;
+  const int E = g->E, E1 = E + 1, L = g->L;
+  std::vector<int32_t> ex;
+  for (int i = 0; i < mirror[0]; ++i) {
+    const int e = mirror[1 + E1 + i];
+    if (e < 0 || e >= E) continue;
+    for (int c = 0; c < std::max(1, (int)mirror[1 + e]); ++c) ex.push_back(e);  // one entry per routed (token, k) pair, as expert_index lists them
+  }
+  g->pred_matrix.resize((size_t)L * E);
+  tr->predict(g->pred_seq, layer, ex.data(), (int)ex.size(), g->pred_matrix.data());
+  g->pred_calls += 1;
+  if (!prefetch || g->pred_lookahead <= 0) return MOEINF_OK;
+  struct Cand { float score; int layer, expert; };
+  std::vector<Cand> cand;
+  for (int l2 = layer + 1; l2 < L && l2 <= layer + g->pred_lookahead; ++l2) {
+    const float* row = &g->pred_matrix[(size_t)l2 * E];
+    double sum = 0;
+    for (int e = 0; e < E; ++e) sum += row[e];
+    if (!(sum > 0)) continue;
+    for (int e = 0; e < E; ++e) {
+      if (!owns(g, e) || row[e] / sum < g->pred_min_share) continue;
+      const Node& nd = g->nodes[node_index(g, l2, e)];
+      if (nd.slot >= 0 || (!nd.host && !nd.store)) continue;  // resident / in flight / never registered
+      cand.push_back({row[e], l2, e});
+    }
+  }
+  std::stable_sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.score > b.score; });
+  if ((int)cand.size() > g->pred_max) cand.resize((size_t)std::max(0, g->pred_max));
+  const float top = cand.empty() ? 1.f : std::max(cand[0].score, 1e-30f);
+  for (const Cand& c : cand) {
+    const float sc = c.score / top;
+    g->st.prefetch_cancelled += g->pq.enqueue(node_index(g, c.layer, c.expert), c.layer, priority_from_score(&sc, 0));
+    g->pred_enqueued += 1;
+  }
+  return MOEINF_OK;
+}
+
 // apply the routing mirrors of finished sync-free forwards to counters / stats (all were hits).
 // Entries beyond `max_pending` are waited for (oldest first), the rest are taken only if already complete.
 static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
@@ -1070,6 +1125,7 @@ static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
       g->pol[idx].last_access = ++g->clock;
     }
     if (pm.prof) account_profile(g, pm.buf, pm.T, pm.local);
+    if (g->pred_tracer && pm.local) predictor_observe(g, pm.layer, pm.buf, /*prefetch=*/false);  // resident layer: trace only
     g->mirror_pool.push_back(pm.buf);
     g->pend.pop_front();
   }
@@ -1281,6 +1337,9 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
       if (e < E && !owns(g, e)) return fail(MOEINF_ERR_STATE, "rank %d was handed rows for expert %d it does not own", g->cfg.ep_rank, e);
     }
     if (prof) account_profile(g, g->h_mirror, T, !g->ovr_out);
+    // the host holds this layer's routing right now: predict and request the next layers' experts BEFORE serving this
+    // layer's misses, so the speculative queue is ordered and the copies start as soon as the link is free
+    if (g->pred_tracer && !g->ovr_out) CHK(predictor_observe(g, layer, g->h_mirror, /*prefetch=*/true));
     CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused));
   }
   return MOEINF_OK;
@@ -2179,6 +2238,17 @@ extern "C" int moeinf_tracer_prefetch_order(const moeinf_tracer* t, int layer, c
 extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* eam_out) {
   if (!t || !t->t->has(seq_id) || !eam_out) return fail(MOEINF_ERR_INVALID, "bad tracer_get_eam arguments");
   t->t->get_eam(seq_id, eam_out);
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_set_predictor(moeinf_engine* g, moeinf_tracer* tr, int64_t seq_id, int lookahead_layers, float min_share, int max_experts) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  drain_mirrors(g, true);  // mirrors of earlier forwards belong to the previous sequence
+  if (!tr || seq_id < 0) { g->pred_tracer = nullptr; g->pred_seq = -1; return MOEINF_OK; }
+  if (tr->t->layers() != g->L || tr->t->experts() != g->E) return fail(MOEINF_ERR_INVALID, "tracer is [%d,%d], engine is [%d,%d]", tr->t->layers(), tr->t->experts(), g->L, g->E);
+  if (!tr->t->has(seq_id)) return fail(MOEINF_ERR_INVALID, "unknown seq_id");
+  if (lookahead_layers < 0 || max_experts < 0 || !(min_share >= 0.f && min_share <= 1.f)) return fail(MOEINF_ERR_INVALID, "bad predictor options");
+  g->pred_tracer = tr->t; g->pred_seq = seq_id; g->pred_lookahead = lookahead_layers; g->pred_min_share = min_share; g->pred_max = max_experts;
   return MOEINF_OK;
 }
 

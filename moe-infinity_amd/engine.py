@@ -261,6 +261,14 @@ class MoEEngine:
         dispatched (one probe in ``probe_every`` keeps watching); 0 switches the governor off."""
         check(self.lib.moeinf_set_prefetch_governor(self._h, float(min_useful_fraction), int(probe_every)))
 
+    def set_predictor(self, tracer: Optional["ExpertTracerNative"], seq_id: int = -1, lookahead_layers: int = 2,
+                      min_share: float = 0.15, max_experts: int = 16):
+        """attach (or with tracer=None detach) the native tracer: the engine itself predicts and requests the next layers'
+        experts from the routing it already holds (moeinf_set_predictor)"""
+        self._predictor = tracer  # keep it alive while attached
+        check(self.lib.moeinf_set_predictor(self._h, tracer._h if tracer is not None else None, int(seq_id), int(lookahead_layers),
+                                            float(min_share), int(max_experts)))
+
     def expert_counters(self) -> np.ndarray:
         """[L, E, 7] = visit, hit, miss, prefetch, incache_visit_count, resident, unused_count (get_hit_rate analogue)."""
         a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 7), np.int64)

@@ -321,3 +321,45 @@ def test_skewed_routing_on_the_sync_free_path():
         assert list(r["counts"]) == [t, t, 0, 0, 0, 0, 0, 0]
         assert_block_close(out, ref, torch.bfloat16, f"skewed routing, forward {i}")
     eng.close()
+
+
+def test_engine_side_predictor_requests_the_next_layers_experts_without_host_code():
+    """moeinf_set_predictor: the native tracer attached to the engine is fed from the routing mirrors and, on forwards
+    that take the decision path, requests the predicted experts of the next layers itself (no eng.routing(), no Python
+    predictor between the layers).  With a history that matches the sequence the copies arrive as hits; the EAM the
+    engine accumulated equals the routing that actually happened; numerics are unchanged."""
+    from moe_infinity_amd.engine import ExpertTracerNative
+
+    h, f, e, k, L, t = 256, 512, 8, 2, 4, 1
+    ws = [make_weights("mixtral", h, f, e, 650 + l, torch.bfloat16) for l in range(L)]
+    slot = 3 * f * h * 2
+    eng = engine_for("mixtral", h, f, e, k, torch.bfloat16, max_tokens=t, num_layers=L, device_memory_bytes=12 * slot)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    steps = 6
+    xs = [[acts(t, h, torch.bfloat16, 7300 + 10 * s + l) for l in range(L)] for s in range(steps)]
+    eam = np.zeros((1, L, e), np.float32)
+    for s in range(steps):
+        for l in range(L):
+            sel, _, _ = R.route_mixtral(xs[s][l], ws[l][0], k)
+            for i in sel.reshape(-1).tolist():
+                eam[0, l, i] += 1
+    tr = ExpertTracerNative(L, e, 4)
+    tr.load_trace(np.repeat(eam, 4, axis=0))
+    seq = tr.create_entry()
+    eng.set_predictor(tr, seq, lookahead_layers=2, min_share=0.1, max_experts=8)
+    gates = [w[0].to(DEV) for w in ws]
+    for s in range(steps):
+        for l in range(L):
+            out = eng.forward(l, xs[s][l].to(DEV), gates[l])
+            ref = R.block_mixtral(xs[s][l][None], ws[l][0], ws[l][1], top_k=k)
+            assert_block_close(out, ref, torch.bfloat16, f"step {s} layer {l}")
+    st = eng.stats()
+    assert st["prefetch_issued"] > 0 and st["prefetch_useful"] > 0, st
+    assert st["expert_hits"] + st["expert_misses"] == steps * L * k
+    torch.cuda.synchronize()
+    eng.stats()  # drains the pending mirrors into the tracer
+    assert np.array_equal(tr.get_eam(seq), eam[0].astype(np.float64)), "the engine-fed EAM is the routing that happened"
+    eng.set_predictor(None)
+    tr.finish_entry(seq)
+    eng.close()

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--types", type=int, default=4)
     ap.add_argument("--seqs", type=int, default=8)
     ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--policies", default="", help="comma-separated subset of the policies")
     args = ap.parse_args()
 
     from moe_infinity_amd import MoEEngine
@@ -66,7 +67,11 @@ def main():
     one = (time.perf_counter() - t0) / 50 * 1e6
     reps = max(1, int(round(args.attn_us / one)))
 
-    for policy_name in ("lfu", "lru", "lfu+prefetch_all", "lfu+prefetch", "lfu+prefetch+governor"):
+    policies = ("lfu", "lru", "lfu+prefetch_all", "lfu+prefetch", "lfu+prefetch+governor",
+                "lfu+engine_predictor_la1", "lfu+engine_predictor_la2+governor", "lfu+engine_predictor_la8+governor")
+    if args.policies:
+        policies = tuple(args.policies.split(","))
+    for policy_name in policies:
         cfg = getattr(Cf, args.workload)(device_memory_ratio=0.5, max_tokens=1,
                                          policy=Cf.POLICY_LRU if policy_name == "lru" else Cf.POLICY_LFU_INCACHE)
         cfg.num_layers = L
@@ -106,7 +111,9 @@ def main():
 
         tracer = ExpertTracer(max(args.hist_seqs, 4), L, E)
         use_pf = "prefetch" in policy_name
-        if use_pf:
+        engine_pred = "engine_predictor" in policy_name  # the tracer attached to the engine: no read-back, no Python per layer
+        lookahead = int(policy_name.split("_la")[1].split("+")[0]) if engine_pred else 0
+        if use_pf or engine_pred:
             # history: EAMs of earlier sequences drawn from the same routing distribution (routing only, no FFN)
             hist = np.zeros((args.hist_seqs, L, E), np.float32)
             for s in range(args.hist_seqs):
@@ -116,6 +123,12 @@ def main():
                         for i in eng.routing()["topk_idx"].reshape(-1):
                             hist[s, l, i] += 1
             tracer.load_trace(hist)
+        native = None
+        if engine_pred:
+            from moe_infinity_amd.engine import ExpertTracerNative
+
+            native = ExpertTracerNative(L, E, max(args.hist_seqs, 4))
+            native.load_trace(hist)
         pred = ExpertPredictor(L, E)
         pred.add_tracer(tracer)
         pf = ExpertPrefetcher(L, E, tracer)
@@ -126,6 +139,17 @@ def main():
         naive = policy_name.endswith("_all")
 
         def run_sequence(sid, steps, prefetch):
+            if engine_pred and prefetch:
+                nseq = native.create_entry()
+                eng.set_predictor(native, nseq, lookahead_layers=lookahead, min_share=args.min_share, max_experts=args.max_prefetch)
+                for step in range(steps):
+                    for l in range(L):
+                        for _ in range(reps):
+                            a @ b  # attention stand-in on the compute stream
+                        eng.forward(l, x_of(sid, step, l), gates[l], out=out)
+                eng.set_predictor(None)
+                native.finish_entry(nseq)
+                return
             seq = tracer.create_entry()
             for step in range(steps):
                 for l in range(L):
@@ -149,7 +173,7 @@ def main():
         t0 = time.perf_counter()
         for sid in range(args.seqs):
             eng.clear_expert_cache_counts()  # prefill->decode boundary of every sequence (interface_example.py:39)
-            run_sequence(sid, args.seq_len, use_pf)
+            run_sequence(sid, args.seq_len, use_pf or engine_pred)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         eng.sync_copies()
