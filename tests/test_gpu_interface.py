@@ -337,7 +337,9 @@ def test_engine_side_predictor_requests_the_next_layers_experts_without_host_cod
     for l in range(L):
         register_all(eng, ws[l][1], layer=l)
     steps = 6
-    xs = [[acts(t, h, torch.bfloat16, 7300 + 10 * s + l) for l in range(L)] for s in range(steps)]
+    # the same token every step: the routing repeats, so the history below predicts it exactly (and with 12 slots for 32
+    # experts no layer is ever fully resident: every forward takes the decision path, where the predictor runs)
+    xs = [[acts(t, h, torch.bfloat16, 7300 + l) for l in range(L)] for s in range(steps)]
     eam = np.zeros((1, L, e), np.float32)
     for s in range(steps):
         for l in range(L):
