@@ -716,6 +716,10 @@ template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
   static const int use_gemm = env_int("MOEINF_FFN_GEMM", 2);
   static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
+  // more than 256 rows per expert (long prefills): the 256 x 256 / 32x32x16-MFMA kernel (ffn_gemm_big.hip)
+  static const int big_env = env_int("MOEINF_GEMM_BIG", 1);
+  static const int big_rows = env_int("MOEINF_GEMM_BIG_ROWS", 256);
+  if (use_gemm == 2 && big_env && sizeof(T) == 2 && max_rows > big_rows && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return true;
   const int ept = sizeof(T) == 2 ? 32 : 16;
   const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
   // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to

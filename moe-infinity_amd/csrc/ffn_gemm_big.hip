@@ -1,0 +1,217 @@
+// ffn_gemm_big.hip — grouped expert GEMM for the COMPUTE-bound regime (more than 128 rows per expert: long prefills).
+//
+// What limits ffn_gemm_lds / ffn_gemm_ring there (0.63-0.76 PFLOP/s per layer at 4096 tokens, 23-31 % MFMA-busy by PMC):
+// 256 tokens against 64-128 weight rows per block and the 16x16x32 MFMA — every B fragment read from LDS feeds two
+// MFMAs, a barrier every 32 MFMAs per wave.  Here
+//   * block tile 256 x 256: 256 weight rows (gated stage: 128 rows of BOTH matrices, so SiLU*mul stays in registers;
+//     plain stage: 256 rows) x 256 tokens, BK = 64 per stage, 8 waves as 2 (rows) x 4 (tokens);
+//   * v_mfma_f32_32x32x16_bf16: a wave owns 128 weight rows x 64 tokens = 8 accumulator tiles of 32x32 (128 VGPRs);
+//     per 16-deep k-step 4 A + 2 B fragment reads feed 8 MFMAs of 32 cycles each — a third of the LDS bytes per flop of
+//     the 16x16x32 kernels, 32 MFMAs (1024 matrix-pipe cycles) per wave between barriers;
+//   * both operands through LDS by the asynchronous global->LDS DMA, two 64-KiB stages: the DMA of stage s+1 is
+//     issued right after the barrier that opens stage s and has a whole stage of MFMAs (~1 us) to land;
+//   * weight tiles are already MFMA fragments in HBM (the tiled slot layout): a 32-row A fragment is two vertically
+//     adjacent 1-KiB tiles, read from the DMA image at tile[(row>>4)] + ((q*16 + (row&15)) * 16) — 256 contiguous bytes
+//     per 16 lanes, conflict-free for ds_read_b128;
+//   * activations in full 128-byte lines (8 token rows x 128 B per DMA), XOR-swizzled on the SOURCE side with
+//     f(piece, row) = (row>>1 & 3) | (piece & 1) << 2 so that the 32-token fragments of the 32x32 MFMA read
+//     conflict-free (the (chunk ^ row) swizzle of the 16-token kernels is 2-way conflicting for 32 tokens);
+//   * grid = (row blocks, active experts, token passes): an expert's 256-token passes run as separate workgroups
+//     (a 1024-row expert re-reads its weights from L2/MALL, not from HBM), so short matrices still fill the chip.
+// Replaces the reference's per-expert torch::matmul triple (core/parallel/expert_module.cpp:171-175) for prefill-sized
+// batches.  bf16 only; K % 64 == 0.
+#include "kdev.h"
+
+#include <type_traits>
+
+namespace moeinf {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NMAT>
+__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s) {
+  typedef uint16_t T;
+  constexpr int EPT = 32, EPV = 8;
+  constexpr int RGB = 16 / NMAT;   // row groups (16 rows) of EACH matrix per block
+  constexpr int RT = 4 / NMAT;     // 32-row tiles of each matrix per wave
+  constexpr int KK = 2;            // k-tiles (32 k) per stage
+  constexpr int A_TILES = KK * NMAT * RGB;  // 32
+  constexpr int B_PIECES = 32;              // 256 tokens in pieces of 8 rows x 128 B
+  constexpr int STAGE = (A_TILES + B_PIECES) * 1024;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];  // the ONLY __shared__ object (a second one de-pipelines the DMA)
+
+  const int u = blockIdx.y;
+  if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
+  const int e = s.active[u];
+  const bool sh = (e == s.E);
+  const int K = sh ? s.K_sh : s.K;
+  const int R = sh ? s.R_sh : s.R;
+  const int nrg_total = (R + 15) / 16;
+  const int rg0 = blockIdx.x * RGB;
+  if (rg0 >= nrg_total) return;
+  const int cnt = s.counts[e];
+  const int off = s.offsets[e];
+  const char* W = reinterpret_cast<const char*>(s.wptr[e]);
+  if (W == nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int KB = K / EPT;  // K % 64 == 0 (checked by the launcher)
+  const int KS = KB / KK;
+  const size_t rg_stride = (size_t)KB * 1024;
+  const char* wbase[NMAT];
+  wbase[0] = W + (sh ? s.off_a_sh : s.off_a);
+  if (NMAT == 2) wbase[NMAT - 1] = W + (sh ? s.off_b_sh : s.off_b);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // this wave's DMA work per stage: A tiles t = wave + 8i, B pieces pc = wave + 8i (i < 4)
+  const char* asrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = wave + 8 * i;
+    const int rg_l = t % RGB, m = (t / RGB) % NMAT, kk = t / (RGB * NMAT);
+    asrc[i] = wbase[m] + (size_t)min(rg0 + rg_l, nrg_total - 1) * rg_stride + (size_t)kk * 1024 + lane * 16;  // + ks * KK * 1024 per stage
+  }
+  // fragment read offsets inside a stage (bytes)
+  const int row32 = lane & 31, kg = lane >> 5;
+  const int wrg0 = wm * (RGB / 2);
+  int a_off[NMAT][RT];  // + (kk * NMAT * RGB) * 1024 + (ks2 * 2 * 16) * 16 per k16 step
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      a_off[m][rt] = (m * RGB + wrg0 + rt * 2 + (row32 >> 4)) * 1024 + (kg * 16 + (row32 & 15)) * 16;
+  int b_off[2], b_f[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int p_local = wn * 8 + tt * 4 + (row32 >> 3), r8 = row32 & 7;
+    b_off[tt] = (A_TILES + p_local) * 1024 + r8 * 128;
+    b_f[tt] = ((r8 >> 1) & 3) | ((p_local & 1) << 2);
+  }
+
+  for (int tile0 = blockIdx.z * 16; tile0 * 16 < cnt; tile0 += gridDim.z * 16) {
+    // activation rows this wave DMA-loads: 8-row pieces pc = wave + 8i, source chunk swizzled
+    const T* xrp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = wave + 8 * i, r8 = lane >> 3;
+      const int trow = tile0 * 16 + pc * 8 + r8;
+      const int srow = off + min(trow, cnt - 1);
+      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+      const int f = ((r8 >> 1) & 3) | ((pc & 1) << 2);
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (((lane & 7) ^ f) * EPV);
+    }
+    f32x16 acc[NMAT][RT][2];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][rt][tt][i] = 0.f;
+
+    auto issue = [&](int ks, int buf) {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (size_t)ks * KK * 1024), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + (A_TILES + wave + 8 * i) * 1024), 16, 0, 0);
+    };
+
+    issue(0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
+      __syncthreads();                                   // ... everybody's has, and stage ks-1 is fully consumed
+      if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);
+      const char* base = smem + (ks & 1) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // four 16-deep k-steps per stage: k-tile kk = j >> 1, half ks2 = j & 1
+        const int kk = j >> 1, ks2 = j & 1;
+        u32x4 af[NMAT][RT], bf[2];
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            af[m][rt] = *reinterpret_cast<const u32x4*>(base + a_off[m][rt] + kk * NMAT * RGB * 1024 + ks2 * 512);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) bf[tt] = *reinterpret_cast<const u32x4*>(base + b_off[tt] + (((j * 2 + kg) ^ b_f[tt]) << 4));
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m][rt]), __builtin_bit_cast(bf16x8, bf[tt]),
+                                                                       acc[m][rt][tt], 0, 0, 0);
+      }
+    }
+    // epilogue from the accumulators: lane holds, for token (lane & 31), rows 8*(i>>2) + 4*kg + (i&3) of each 32-row tile —
+    // four consecutive rows per group of four registers = one 8-byte store
+    auto epilogue_tile = [&](auto rtc) {  // rt as a compile-time constant: the accumulator arrays must never be indexed dynamically
+      constexpr int rt = decltype(rtc)::value;
+      const int rgt = rg0 + wrg0 + rt * 2;  // first row group of this 32-row tile
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int tok = tile0 * 16 + wn * 64 + tt * 32 + row32;
+        if (tok < cnt && rgt < nrg_total) {
+          const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
+          T* orow_p = reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int orow0 = rgt * 16 + 8 * g4 + 4 * kg;
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int orow = orow0 + jj;
+              float a0 = DT<T>::round(acc[0][rt][tt][g4 * 4 + jj]);
+              if (s.epi == EPI_GATED_SILU) {
+                const float bb = DT<T>::round(acc[NMAT - 1][rt][tt][g4 * 4 + jj]);
+                const float sl = DT<T>::round(a0 / (1.0f + expf(-a0)));
+                a0 = DT<T>::round(sl * bb);
+              } else {
+                if ((s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU) && orow < R)
+                  a0 = DT<T>::round(a0 + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
+                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) a0 = fmaxf(a0, 0.f);
+              }
+              v[jj] = a0;
+            }
+            if (orow0 + 3 < R) {
+              DT<T>::store4(orow_p + orow0, v);
+            } else {
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+                if (orow0 + jj < R) DT<T>::store(orow_p + orow0 + jj, v[jj]);
+            }
+          }
+        }
+      }
+    };
+    epilogue_tile(std::integral_constant<int, 0>{});
+    epilogue_tile(std::integral_constant<int, 1>{});
+    if constexpr (RT == 4) {
+      epilogue_tile(std::integral_constant<int, 2>{});
+      epilogue_tile(std::integral_constant<int, 3>{});
+    }
+    __syncthreads();  // the next pass re-uses buffer 0
+  }
+}
+
+// max_rows: (an estimate of) the rows of the busiest expert; the kernel's pass loop covers more
+bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st) {
+  if (s.dtype != DT_BF16 || (s.K % 64) != 0 || (s.K_sh % 64) != 0) return false;
+  const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
+  const int passes = max_rows <= 256 ? 1 : (max_rows + 255) / 256;
+  const dim3 g((rmax + 255 / nmat) / (256 / nmat), grid.y, passes > 8 ? 8 : passes);
+  if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2>), g, dim3(512), 0, st, s);
+  else hipLaunchKernelGGL((ffn_gemm_big_kernel<1>), g, dim3(512), 0, st, s);
+  return true;
+}
+
+}  // namespace moeinf

@@ -11,6 +11,9 @@
 
 namespace moeinf {
 
+// ffn_gemm_big.hip: the compute-bound grouped GEMM (false: shape not supported, the caller picks another kernel)
+bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st);
+
 // tuning knobs are read once per process from the environment (sweeps only)
 static inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);

@@ -169,7 +169,7 @@ hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_
   dim3 grid(n_gate + (s.R_sh + 15) / 16);
   const int rb = gate_rounds_bf16(a);
   // bf16 model (DeepSeek): activations bf16, gate bf16 or fp32
-  static const int u8 = env_int("MOEINF_SH1_U", 4) == 8;
+  static const int u8 = env_int("MOEINF_SH1_U", 8) == 8;  // 8 tiles per wave and matrix per batch: 1.035 -> 1.007 ms/token (DeepSeek-V2-Lite)
 #define GS1(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU>), grid, dim3(256), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
   if (a.gate_dtype == DT_BF16) { if (u8) GS1(uint16_t, 8); else GS1(uint16_t, 4); }
   else { if (u8) GS1(float, 8); else GS1(float, 4); }
@@ -462,7 +462,10 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
   // staggered finishes.  Small grids (DeepSeek: 657 workgroups, all resident anyway) are left alone.
   static const int lds_env = env_int("MOEINF_SR_LDS_KB", -1);
   const size_t dyn = (size_t)(lds_env >= 0 ? lds_env : (grid.x > 4 * 256 ? 30 : 0)) * 1024;
-  static const int sr_u = env_int("MOEINF_SR_U", 4);  // tiles per wave and matrix fetched per batch
+  // tiles per wave and matrix fetched per batch: 8 for grids that are resident all at once (DeepSeek-V2-Lite: 657
+  // workgroups, 1.035 -> 1.009 ms/token), 4 for multi-round grids (Mixtral: 1793 workgroups at four per CU)
+  static const int sr_u_env = env_int("MOEINF_SR_U", 0);
+  const int sr_u = sr_u_env ? sr_u_env : (grid.x > 4 * 256 ? 4 : 8);
   if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
   else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
   return hipGetLastError();
@@ -653,13 +656,16 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
     return hipGetLastError();
   }
   // K = 3..8: eight columns per workgroup, every expert and the combine inside it (MOEINF_DEC1_HALF=0: arrival-counter form)
-  static const int half_env = env_int("MOEINF_DEC1_HALF", 1);
+  // Measured (profiles/r03_deepseek_decode_variants.txt): 1.035 ms/token vs 1.037 for the arrival-counter form — the tail it
+  // removes is paid back by the half-tile loads (32 active lanes, 128-byte segments per instruction): opt-in only.
+  static const int half_env = env_int("MOEINF_DEC1_HALF", 0);
   // y_shared of a hidden shared expert is written by the previous launch (stage 1 carries its stage 2); a NON-hidden one
   // (shared_offsets set: its rows are produced by THIS stage) cannot be combined inside the workgroup
   if (half_env && s2.comb.K >= 3 && s2.comb.K <= 8 && (s2.K % 32) == 0 && s2.comb.kind <= 1 && !s2.comb.shared_offsets) {
     const dim3 g2(2 * ((s2.R + 15) / 16));
     static const int hu = env_int("MOEINF_DEC1_HALF_U", 8);
 #define HALF(KX, NWE) do { if (hu == 4) hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 4>), g2, dim3(KX * NWE * 64), 0, st, s2); \
+                           else if (hu == 12) hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 12>), g2, dim3(KX * NWE * 64), 0, st, s2); \
                            else hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 8>), g2, dim3(KX * NWE * 64), 0, st, s2); } while (0)
     switch (s2.comb.K) {
       case 3: HALF(3, 4); break;
@@ -674,7 +680,10 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
   const size_t kbytes = (size_t)s2.K * 2;
+  static const int du = env_int("MOEINF_DEC1_U", 4);  // k-tiles per wave fetched per batch (short reductions)
   if (kbytes >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);
+  else if (du == 8) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 8>), grid, dim3(256), 0, st, s2);
+  else if (du == 12) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 12>), grid, dim3(256), 0, st, s2);
   else hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, s2);
   return hipGetLastError();
 }

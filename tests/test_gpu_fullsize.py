@@ -45,7 +45,7 @@ def _check_index(eng, ref):
     return r
 
 
-@pytest.mark.parametrize("t", [1, 512], ids=["decode_b1", "prefill_t512"])
+@pytest.mark.parametrize("t", [1, 512, 2048], ids=["decode_b1", "prefill_t512", "prefill_t2048_compute_bound_gemm"])
 def test_mixtral_8x7b_layer(t):
     eng, cfg = _engine("mixtral_8x7b", t)
     experts, _ = fill_layer_on_gpu(eng, "mixtral", 0, 1234)
@@ -62,7 +62,7 @@ def test_mixtral_8x7b_layer(t):
     eng.close()
 
 
-@pytest.mark.parametrize("t", [1, 512], ids=["decode_b1", "prefill_t512"])
+@pytest.mark.parametrize("t", [1, 512, 4096], ids=["decode_b1", "prefill_t512", "prefill_t4096_compute_bound_gemm"])
 def test_deepseek_v2_lite_layer(t):
     eng, cfg = _engine("deepseek_v2_lite", t)
     experts, shared = fill_layer_on_gpu(eng, "deepseek", 0, 2234)

@@ -691,3 +691,32 @@ def test_batch1_selfrouting_ties_lowest_index(family, e, k):
         hits += int(2 in set(int(v) for v in ref.topk_idx[0]))
     assert hits > 0, "the tied group never reached the top-k: the test exercises nothing"
     eng.close()
+
+
+@pytest.mark.parametrize("family,t,h,f,e,k,n_shared", [
+    ("mixtral", 1400, 256, 384, 4, 2, 0),     # 700 rows per expert: 3 token passes, F = 3 row blocks of 128
+    ("deepseek", 2000, 256, 192, 8, 3, 2),    # routed 750 rows; shared expert 2000 rows x F_shared 384 (its own K and R)
+    ("nllb", 900, 256, 320, 4, 2, 0),         # plain stages with bias: 320 = 256 + 64 rows (partly filled row block), H = 256
+    ("mixtral", 300, 128, 128, 1, 1, 0),      # a single expert with 300 rows: 2 passes, the second mostly empty
+], ids=["mixtral_700_rows", "deepseek_750_rows_shared", "nllb_bias_partial_row_block", "one_expert_300_rows"])
+def test_compute_bound_grouped_gemm_256x256_tiles(family, t, h, f, e, k, n_shared):
+    """More than 256 rows per expert: ffn_gemm_big (256 x 256 block tile, 32x32x16 MFMA, both operands through LDS).
+    Per-expert rows within 1 ulp (2 for the bias epilogues) and the block inside the bar, on the decision path (exact
+    counts) and on the sync-free path (launch sized from the estimate)."""
+    gate, experts, shared = make_weights(family, h, f, e, 2600, torch.bfloat16, n_shared=n_shared, gate_std=0.5 if family == "nllb" else 0.02)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=t)
+    register_all(eng, experts, shared)
+    x = acts(t, h, torch.bfloat16, 2601)
+    if family == "mixtral":
+        ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    elif family == "deepseek":
+        ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+    else:
+        ref = R.block_nllb(x[None], gate, experts)
+    assert max(int(v.shape[0]) for v in ref.expert_out.values()) > 256
+    for i in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        rows = oracle_expert_rows(ref, e)
+        assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, f"expert rows, forward {i}", ulps=2.0 if family == "nllb" else 1.0)
+        assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block, forward {i}")
+    eng.close()
