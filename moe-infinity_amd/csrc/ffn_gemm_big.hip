@@ -16,8 +16,9 @@
 //   * activations in full 128-byte lines (8 token rows x 128 B per DMA), XOR-swizzled on the SOURCE side with
 //     f(piece, row) = (row>>1 & 3) | (piece & 1) << 2 so that the 32-token fragments of the 32x32 MFMA read
 //     conflict-free (the (chunk ^ row) swizzle of the 16-token kernels is 2-way conflicting for 32 tokens);
-//   * grid = (row blocks, active experts, token passes): an expert's 256-token passes run as separate workgroups
-//     (a 1024-row expert re-reads its weights from L2/MALL, not from HBM), so short matrices still fill the chip.
+//   * an expert's 256-token passes run as separate workgroups, placed on ONE XCD and dispatched together (1-D grid,
+//     id -> (slab, pass) below): the weight slab comes from HBM once, the other passes read it from that XCD's L2; short
+//     matrices still fill the chip.
 // Replaces the reference's per-expert torch::matmul triple (core/parallel/expert_module.cpp:171-175) for prefill-sized
 // batches.  bf16 only; K % 64 == 0.
 #include "kdev.h"
@@ -29,7 +30,7 @@ namespace moeinf {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int NMAT>
-__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s) {
+__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map) {
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
   constexpr int RGB = 16 / NMAT;   // row groups (16 rows) of EACH matrix per block
@@ -40,20 +41,32 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s) {
   constexpr int STAGE = (A_TILES + B_PIECES) * 1024;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];  // the ONLY __shared__ object (a second one de-pipelines the DMA)
 
-  const int u = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule; a wrong guess costs speed, never
+  // correctness).  The nz token passes of ONE weight slab (row block bx of expert slot u) get ids 8 apart — the same XCD,
+  // dispatched together — so the slab streams from HBM once and the other passes hit it in that XCD's L2:
+  //   id = ((g / 8) * nz + pass) * 8 + g % 8,   g = u * nx + bx
+  int pass0, g;
+  if (xcd_map) {
+    const int xcd = blockIdx.x & 7, tq = blockIdx.x >> 3;
+    pass0 = tq % nz; g = (tq / nz) * 8 + xcd;
+  } else {  // MOEINF_GEMM_BIG_XCD=0 (A/B): passes adjacent in id, i.e. spread over the XCDs
+    pass0 = blockIdx.x % nz; g = blockIdx.x / nz;
+  }
+  if (g >= nx * ny) return;
+  const int u = g / nx, bx = g - u * nx;
   if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
   const int e = s.active[u];
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
   const int nrg_total = (R + 15) / 16;
-  const int rg0 = blockIdx.x * RGB;
+  const int rg0 = bx * RGB;
   if (rg0 >= nrg_total) return;
   const int cnt = s.counts[e];
   const int off = s.offsets[e];
   const char* W = reinterpret_cast<const char*>(s.wptr[e]);
   if (W == nullptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) atomicExch(s.miss_flag, 1);
+    if (threadIdx.x == 0 && bx == 0 && pass0 == 0) atomicExch(s.miss_flag, 1);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s) {
     b_f[tt] = ((r8 >> 1) & 3) | ((p_local & 1) << 2);
   }
 
-  for (int tile0 = blockIdx.z * 16; tile0 * 16 < cnt; tile0 += gridDim.z * 16) {
+  for (int tile0 = pass0 * 16; tile0 * 16 < cnt; tile0 += nz * 16) {
     // activation rows this wave DMA-loads: 8-row pieces pc = wave + 8i, source chunk swizzled
     const T* xrp[4];
 #pragma unroll
@@ -208,9 +221,11 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   if (s.dtype != DT_BF16 || (s.K % 64) != 0 || (s.K_sh % 64) != 0) return false;
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   const int passes = max_rows <= 256 ? 1 : (max_rows + 255) / 256;
-  const dim3 g((rmax + 255 / nmat) / (256 / nmat), grid.y, passes > 8 ? 8 : passes);
-  if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2>), g, dim3(512), 0, st, s);
-  else hipLaunchKernelGGL((ffn_gemm_big_kernel<1>), g, dim3(512), 0, st, s);
+  const int nx = (rmax + 255 / nmat) / (256 / nmat), ny = (int)grid.y, nz = passes > 8 ? 8 : passes;
+  const dim3 g((unsigned)(((nx * ny + 7) / 8) * nz * 8));
+  static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
+  if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+  else hipLaunchKernelGGL((ffn_gemm_big_kernel<1>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
   return true;
 }
 

@@ -75,7 +75,9 @@ def test_deepseek_v2_lite_layer(t):
     r = _check_index(eng, ref)
     assert np.array_equal(_mask_from_idx(r["topk_idx"], cfg.num_experts), ref.router_mask.numpy()), "routing sets must be bit-exact"
     rows = oracle_expert_rows(ref, cfg.num_experts)
-    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+    # the gated epilogue has three rounding points, Tr(Tr(silu(Tr(a))) * Tr(b)): a last-bit flip of a (fp32 summation order)
+    # can carry through the other two — at 50 M elements (4096 tokens) a handful reach 1.3 ulp; 1 ulp holds up to 512 tokens
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs", ulps=1.0 if t <= 512 else 1.5)
     assert_block_close(out, ref, torch.bfloat16, f"DeepSeek-V2-Lite layer, {t} tokens")
     eng.close()
 
