@@ -29,7 +29,12 @@ namespace moeinf {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int NMAT>
+// RING3: the weight image gets a THREE-deep LDS ring (3 x 32 KiB) and is fetched two stages ahead, the activation image
+// keeps two buffers (2 x 32 KiB) one stage ahead — 160 KiB, all of a CU's LDS; counted s_waitcnt vmcnt(4) + raw
+// s_barrier, so the four weight DMAs of stage s+1 stay in flight across the barrier that opens stage s (weights come
+// from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
+// into slots that are already consumed, so the count never varies.
+template <int NMAT, bool RING3>
 __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map) {
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
@@ -38,8 +43,10 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
   constexpr int KK = 2;            // k-tiles (32 k) per stage
   constexpr int A_TILES = KK * NMAT * RGB;  // 32
   constexpr int B_PIECES = 32;              // 256 tokens in pieces of 8 rows x 128 B
-  constexpr int STAGE = (A_TILES + B_PIECES) * 1024;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];  // the ONLY __shared__ object (a second one de-pipelines the DMA)
+  constexpr int ABYTES = A_TILES * 1024, BBYTES = B_PIECES * 1024;  // 32 KiB each per stage
+  constexpr int NA = RING3 ? 3 : 2;
+  constexpr int BOFF = NA * ABYTES;  // the activation buffers start behind the weight ring
+  __shared__ __attribute__((aligned(16))) char smem[NA * ABYTES + 2 * BBYTES];  // the ONLY __shared__ object (a second one de-pipelines the DMA)
 
   // 1-D grid, XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule; a wrong guess costs speed, never
   // correctness).  The nz token passes of ONE weight slab (row block bx of expert slot u) get ids 8 apart — the same XCD,
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int p_local = wn * 8 + tt * 4 + (row32 >> 3), r8 = row32 & 7;
-    b_off[tt] = (A_TILES + p_local) * 1024 + r8 * 128;
+    b_off[tt] = p_local * 1024 + r8 * 128;
     b_f[tt] = ((r8 >> 1) & 3) | ((p_local & 1) << 2);
   }
 
@@ -128,43 +135,70 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][rt][tt][i] = 0.f;
 
-    auto issue = [&](int ks, int buf) {
-      char* base = smem + buf * STAGE;
+    auto issue_a = [&](int ks, int slot) {
+      char* base = smem + slot * ABYTES;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (size_t)ks * KK * 1024), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int ks, int slot) {
+      char* base = smem + BOFF + slot * BBYTES;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + (A_TILES + wave + 8 * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
     };
 
-    issue(0, 0);
+    if constexpr (RING3) {
+      issue_a(0, 0); issue_b(0, 0); issue_a(min(1, KS - 1), 1);
+    } else {
+      issue_a(0, 0); issue_b(0, 0);
+    }
     for (int ks = 0; ks < KS; ++ks) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
-      __syncthreads();                                   // ... everybody's has, and stage ks-1 is fully consumed
-      if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);
-      const char* base = smem + (ks & 1) * STAGE;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // four 16-deep k-steps per stage: k-tile kk = j >> 1, half ks2 = j & 1
+      const char *abase, *bbase;
+      if constexpr (RING3) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest four DMAs (the weights of stage ks+1) have landed
+        __builtin_amdgcn_s_barrier();                      // ... everybody's have, and stage ks-1 is fully consumed
+        issue_b(min(ks + 1, KS - 1), (ks + 1) & 1);
+        issue_a(min(ks + 2, KS - 1), (ks + 2) % 3);
+        abase = smem + (ks % 3) * ABYTES;
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
+        __syncthreads();                                   // ... everybody's has, and stage ks-1 is fully consumed
+        if (ks + 1 < KS) { issue_a(ks + 1, (ks + 1) & 1); issue_b(ks + 1, (ks + 1) & 1); }
+        abase = smem + (ks & 1) * ABYTES;
+      }
+      bbase = smem + BOFF + (ks & 1) * BBYTES;
+      // four 16-deep k-steps per stage (k-tile kk = j >> 1, half ks2 = j & 1).  The fragments of step j+1 are read into
+      // a second register set BEFORE the eight MFMAs of step j issue (the compiler left to itself reads each pair of
+      // fragments just in time behind an lgkmcnt(0): every MFMA pair then waits out an LDS round trip)
+      u32x4 af[2][NMAT][RT], bf[2][2];
+      auto read_frags = [&](int j, u32x4 (&fa)[NMAT][RT], u32x4 (&fb)[2]) {
         const int kk = j >> 1, ks2 = j & 1;
-        u32x4 af[NMAT][RT], bf[2];
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            af[m][rt] = *reinterpret_cast<const u32x4*>(base + a_off[m][rt] + kk * NMAT * RGB * 1024 + ks2 * 512);
+            fa[m][rt] = *reinterpret_cast<const u32x4*>(abase + a_off[m][rt] + kk * NMAT * RGB * 1024 + ks2 * 512);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) bf[tt] = *reinterpret_cast<const u32x4*>(base + b_off[tt] + (((j * 2 + kg) ^ b_f[tt]) << 4));
+        for (int tt = 0; tt < 2; ++tt) fb[tt] = *reinterpret_cast<const u32x4*>(bbase + b_off[tt] + (((j * 2 + kg) ^ b_f[tt]) << 4));
+      };
+      read_frags(0, af[0], bf[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j + 1 < 4) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the MFMAs below
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
-              acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m][rt]), __builtin_bit_cast(bf16x8, bf[tt]),
+              acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
                                                                        acc[m][rt][tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (RING3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail issues
     // epilogue from the accumulators: lane holds, for token (lane & 31), rows 8*(i>>2) + 4*kg + (i&3) of each 32-row tile —
     // four consecutive rows per group of four registers = one 8-byte store
     auto epilogue_tile = [&](auto rtc) {  // rt as a compile-time constant: the accumulator arrays must never be indexed dynamically
@@ -224,8 +258,14 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   const int nx = (rmax + 255 / nmat) / (256 / nmat), ny = (int)grid.y, nz = passes > 8 ? 8 : passes;
   const dim3 g((unsigned)(((nx * ny + 7) / 8) * nz * 8));
   static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
-  if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
-  else hipLaunchKernelGGL((ffn_gemm_big_kernel<1>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+  static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
+  if (ring3) {
+    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+    else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+  } else {
+    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, false>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+    else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, false>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+  }
   return true;
 }
 
