@@ -716,10 +716,19 @@ template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
   static const int use_gemm = env_int("MOEINF_FFN_GEMM", 2);
   static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
-  // more than 256 rows per expert (long prefills): the 256 x 256 / 32x32x16-MFMA kernel (ffn_gemm_big.hip)
+  // long prefills: the 256 x 256 / 32x32x16-MFMA kernel (ffn_gemm_big.hip).  Measured (profiles/r03_ffn_sweep_prefill_big_*.txt):
+  // it beats ffn_gemm_lds from 257 rows per expert on (Mixtral down projection at 2048 tokens 846 -> 730 us, DeepSeek-V2-Lite
+  // at 4096 tokens 2.54 -> 1.96 ms per layer), but the register-ring kernel (gated stage, K >= 4096) only above ~1000 rows
+  // (Mixtral gate/up at 2048 tokens: ring 1292 us vs 1602; at 4096 tokens 2485 vs 2190)
   static const int big_env = env_int("MOEINF_GEMM_BIG", 1);
   static const int big_rows = env_int("MOEINF_GEMM_BIG_ROWS", 256);
-  if (use_gemm == 2 && big_env && sizeof(T) == 2 && max_rows > big_rows && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return true;
+  static const int big_rows_ring = env_int("MOEINF_GEMM_BIG_ROWS_RING", 1024);
+  bool ring_stage = false;
+  if constexpr (sizeof(T) == 2 && NMAT == 2) {
+    static const int ring_min_k0 = env_int("MOEINF_RING_MIN_K", 4096);
+    ring_stage = env_int("MOEINF_GEMM_RING", 1) && (s.K % 64) == 0 && s.K >= ring_min_k0 && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring_min_k0));
+  }
+  if (use_gemm == 2 && big_env && sizeof(T) == 2 && max_rows > (ring_stage ? big_rows_ring : big_rows) && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return true;
   const int ept = sizeof(T) == 2 ? 32 : 16;
   const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
   // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
