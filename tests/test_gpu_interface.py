@@ -354,6 +354,10 @@ def test_engine_side_predictor_requests_the_next_layers_experts_without_host_cod
     for s in range(steps):
         for l in range(L):
             out = eng.forward(l, xs[s][l].to(DEV), gates[l])
+            # a speculative copy is never started while an on-demand copy is on the link: let this layer's demand copies
+            # land and pump the queue (any API call does), so that the test does not depend on how long the host dawdles
+            torch.cuda.synchronize()
+            eng.stats()
             ref = R.block_mixtral(xs[s][l][None], ws[l][0], ws[l][1], top_k=k)
             assert_block_close(out, ref, torch.bfloat16, f"step {s} layer {l}")
     st = eng.stats()
