@@ -992,6 +992,13 @@ static inline int pump_if_pending(moeinf_engine* g) {
   if (g->pq.empty() && g->prefetch_inflight.empty() && g->disk_inflight.empty() && g->stale_disk.empty()) return MOEINF_OK;
   return pump_prefetch(g);
 }
+// FfnStage::fuse_combine: 1 = the hand-off rows leave as sixteen 2-byte write-through stores; 2 (MOEINF_WIDE_OUT=1) = gathered
+// through LDS into 16-byte ones — measured SLOWER (DeepSeek-V2-Lite 1.031/1.038 vs 1.022/1.031 ms/token, stage 2 +0.6 us: the
+// extra LDS round trip and barrier cost more than the fabric writes they save), so off by default
+static int fuse_mode() {
+  static const int m = (getenv("MOEINF_WIDE_OUT") && atoi(getenv("MOEINF_WIDE_OUT")) != 0) ? 2 : 1;
+  return m;
+}
 static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
   const DevLayout& b = g->dlay;
   const DevLayout& bs = g->dlay_sh;
@@ -1268,7 +1275,7 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     s1.active = g->d_active + a; s2.active = g->d_active + a;
     s1.n_active_host = b - a; s2.n_active_host = b - a;
     if (fuse && a == 0 && b == na && na > 0) {  // one chunk: the last column-tile block of stage 2 combines
-      s2.fuse_combine = 1; s2.tile_done = g->d_arrive; s2.comb = *fuse;
+      s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse;
       if (fused) *fused = true;
     }
     int max_rows = 0;
@@ -1318,7 +1325,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     fill_stage(g, layer, 1, s1, ld_x);
     s1.in = x_in;
     fill_stage(g, layer, 2, s2);
-    if (fuse) { s2.fuse_combine = 1; s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
+    if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
     if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));

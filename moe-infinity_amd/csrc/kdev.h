@@ -44,6 +44,13 @@ __device__ __forceinline__ V ld_coherent(const V* p) { return __hip_atomic_load(
 template <typename V>
 __device__ __forceinline__ void st_coherent(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_stores_acked() { __builtin_amdgcn_s_waitcnt(0); }
+// 16-byte write-through (sc1) store: a relaxed agent-scope __hip_atomic_store lowers to an sc1 store only up to 8 bytes, and
+// narrow sc1 stores are one fabric write each (a 2-byte one costs ~12x a 16-byte one per byte, MI355X_MICROARCH.md).  hipcc does
+// not count an asm store: the caller drains it with wait_stores_acked() (the s_nop keeps the data registers alive until read).
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+__device__ __forceinline__ void st16_coherent(void* p, u32x4_ v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 
 template <typename T>
 struct DT;
@@ -246,6 +253,8 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
   const char* a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)bx * KB * 1024 + lane * 16;
   const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)bx * KB * 1024 + lane * 16 : nullptr;
   const int kq = q * EPV;  // this lane's k offset inside a tile
+  // fused-combine hand-off rows as 16-byte stores: needs all 16 rows of the group inside the matrix and no in/out row lists
+  const bool wide_out = NMAT == 1 && NT == 1 && s.fuse_combine == 2 && r0 + 16 <= R && !out_rows;  // fuse_combine 1: narrow stores (A/B)
 
   // NT token tiles (16 tokens each) share one pass over the weights: experts with many tokens
   // (prefill, big batches) re-stream their weights every 16*NT tokens instead of every 16
@@ -344,7 +353,46 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
           }
           const int srow = off + tile * 16 + tn;
           T* op = reinterpret_cast<T*>(s.out) + (size_t)(out_rows ? out_rows[tile * 16 + tn] : (s.out_map ? s.out_map[srow] : srow)) * s.ld_out + orow;
-          if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v); else DT<T>::store(op, v);
+          if (NMAT == 1 && NT == 1 && s.fuse_combine) {
+            if (wide_out) red[0][0][i] = v; else DT<T>::store_coherent(op, v);  // wide: gathered below into 16-byte stores
+          } else {
+            DT<T>::store(op, v);
+          }
+        }
+      }
+      if constexpr (NMAT == 1 && NT == 1) {
+        if (wide_out) {
+          // the hand-off rows of the fused combine leave as 16-byte write-through stores: thread t gathers the 16 output rows
+          // of token t (sixteen 2-byte sc1 stores were sixteen fabric writes)
+          __syncthreads();
+          const int tn = tid;
+          if (tn < 16 && tile * 16 + tn < cnt) {
+            float v16[16];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v16[qq * 4 + j] = red[0][0][(qq * 16 + tn) * 4 + j];
+            const int srow = off + tile * 16 + tn;
+            T* op = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[srow] : srow) * s.ld_out + r0;
+            if constexpr (sizeof(T) == 2) {
+              u32x4 w0, w1;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                w0[j] = (uint32_t)f2bf(v16[2 * j]) | ((uint32_t)f2bf(v16[2 * j + 1]) << 16);
+                w1[j] = (uint32_t)f2bf(v16[8 + 2 * j]) | ((uint32_t)f2bf(v16[8 + 2 * j + 1]) << 16);
+              }
+              st16_coherent(op, w0);
+              st16_coherent(op + 8, w1);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                u32x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(v16[c * 4 + j]);
+                st16_coherent(op + c * 4, w);
+              }
+            }
+          }
         }
       }
       __syncthreads();
