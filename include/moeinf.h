@@ -440,6 +440,7 @@ int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev
  * cap_tokens = the largest token count per forward through this path, THE SAME ON EVERY RANK (it sizes the per-peer row
  * slots of the fixed-capacity exchange: cap_tokens * min(K, ceil(E/ep_size))).  The reference has no collective here:
  * it copies rows between GPUs from one process (core/parallel/expert_dispatcher.cpp:284,405). */
+int moeinf_ep_comm_available(int32_t* available); /* 1 if librccl could be bound in this process (no communicator is made) */
 int moeinf_ep_comm_unique_id(void* id_out, int nbytes /* 128 */);
 int moeinf_ep_comm_init(moeinf_engine* eng, const void* unique_id, int nbytes, int cap_tokens);
 /* equal-split all-to-all of device buffers on `stream`: segment p (bytes_per_peer bytes) of send_dev goes to rank p */

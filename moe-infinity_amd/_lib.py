@@ -151,6 +151,7 @@ PROTOTYPES = {
     "moeinf_ep_combine": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "moeinf_ep_route_pack": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "moeinf_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "moeinf_ep_comm_available": (C.c_int, [_I32P]),
     "moeinf_ep_comm_unique_id": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "moeinf_ep_all_to_all": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

@@ -2533,6 +2533,14 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
 }
 
 // ---- native transport of the exchange (ep_comm.h) ---------------------------------------------------------------
+extern "C" int moeinf_ep_comm_available(int32_t* available) {
+  if (!available) return fail(MOEINF_ERR_INVALID, "available is NULL");
+  std::string err;
+  *available = RcclApi::get(&err) ? 1 : 0;
+  if (!*available) g_err = err;
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_ep_comm_unique_id(void* id_out, int nbytes) {
   if (!id_out || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "id_out must hold %d bytes", (int)sizeof(RcclUniqueId));
   std::string err;

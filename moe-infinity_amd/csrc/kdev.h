@@ -161,13 +161,14 @@ __device__ __forceinline__ void combine_meta(const CombineArgs& a, const int t, 
   // by the caller) so the rounds stay branch-free
   const int K = a.K;
   const size_t p0 = (size_t)t * K;
-  const int32_t* po = a.pair_order + p0;
-  // scalars, not an array: an int ko[8] indexed inside the second loop ended up in scratch (24 B per thread)
-  const int k0 = po[0], k1 = po[min(1, K - 1)], k2 = po[min(2, K - 1)], k3 = po[min(3, K - 1)];
-  const int k4 = po[min(4, K - 1)], k5 = po[min(5, K - 1)], k6 = po[min(6, K - 1)], k7 = po[min(7, K - 1)];
-#define MOEINF_CM(kk, ko) m.slot[kk] = a.pair_slot[p0 + ko]; m.w[kk] = a.topk_w[p0 + ko];
-  MOEINF_CM(0, k0) MOEINF_CM(1, k1) MOEINF_CM(2, k2) MOEINF_CM(3, k3) MOEINF_CM(4, k4) MOEINF_CM(5, k5) MOEINF_CM(6, k6) MOEINF_CM(7, k7)
-#undef MOEINF_CM
+  int ko[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ko[kk] = a.pair_order[p0 + min(kk, K - 1)];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    m.slot[kk] = a.pair_slot[p0 + ko[kk]];
+    m.w[kk] = a.topk_w[p0 + ko[kk]];
+  }
 }
 template <typename T, bool COH = false>  // COH: y / y_shared were written by other workgroups of THIS launch
 __device__ __forceinline__ void combine_apply(const CombineArgs& a, const int t, const int h0, const CombineMeta& m) {
@@ -177,9 +178,11 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, const int t,
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const bool has_sh = (a.kind == 1 && a.y_shared);
   const int row0 = (has_sh && a.shared_offsets) ? a.shared_offsets[a.shared_E] : 0;
-  typename DT<T>::Raw4 rsh, ry[8];
+  typename DT<T>::Raw4 rsh = {}, ry[8];
+  // (a `has_sh ? a.y_shared : a.y` pointer select here was compiled into a two-entry pointer table in SCRATCH, 24 bytes per
+  // thread; a wave-uniform branch around the one load costs nothing)
+  if (has_sh) rsh = DT<T>::template fetch4<COH>(reinterpret_cast<const T*>(a.y_shared) + (size_t)(row0 + t) * a.H + h0);
   // absent slots fetch row 0 (ignored below) so the round stays branch-free
-  rsh = DT<T>::template fetch4<COH>(reinterpret_cast<const T*>(has_sh ? a.y_shared : a.y) + (size_t)(row0 + (has_sh ? t : 0)) * a.H + h0);
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) ry[kk] = DT<T>::template fetch4<COH>(y + (size_t)max(m.slot[kk], 0) * a.H + h0);
   float sh[4] = {0.f, 0.f, 0.f, 0.f};

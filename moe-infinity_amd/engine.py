@@ -330,6 +330,11 @@ class MoEEngine:
 
 
     # ---- native transport (RCCL called from inside the engine) ---------------------------------
+    def ep_comm_available(self) -> bool:
+        ok = C.c_int32()
+        check(self.lib.moeinf_ep_comm_available(C.byref(ok)))
+        return bool(ok.value)
+
     def ep_comm_unique_id(self) -> bytes:
         buf = (C.c_uint8 * 128)()
         check(self.lib.moeinf_ep_comm_unique_id(buf, 128))

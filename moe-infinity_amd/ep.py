@@ -132,12 +132,17 @@ class ExpertParallelMoE:
         if dist.get_backend(self.group) != "nccl":
             self.native_note = "process group is not RCCL (several ranks may share one GPU)"
             return False
-        uid = None
+        uid, ok = bytes(128), False
         try:
-            uid = eng.ep_comm_unique_id()  # every rank: proves librccl can be bound here
+            ok = eng.ep_comm_available()       # every rank: librccl can be bound here
+            if ok and self.rank == 0:
+                uid = eng.ep_comm_unique_id()  # rank 0 only: the id carries its bootstrap address
         except Exception as ex:  # noqa: BLE001
+            ok = False
             self.native_note = f"librccl not usable: {ex}"
-        if not self._agree(uid is not None):
+        if not self._agree(ok):
+            if ok:
+                self.native_note = "librccl not usable on another rank"
             return False
         t = torch.tensor(list(uid), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)

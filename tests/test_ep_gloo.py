@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, var_threshold=64):
+def _worker(rank, world, port, q, var_threshold=64, tight_capacity=False, t=6):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -32,10 +32,12 @@ def _worker(rank, world, port, q, var_threshold=64):
         from oracle import moe_ref as R
         from oracle.synth import acts, make_weights
 
-        h, f, e, k, t, L = 128, 256, 8, 2, 6, 2
+        h, f, e, k, L = 128, 256, 8, 2, 2
         ws = [make_weights("mixtral", h, f, e, 50 + l, torch.bfloat16) for l in range(L)]
         ops = OracleEpOps([w[1] for w in ws], rank, world, k, e, h)
-        ep = ExpertParallelMoE(ops, h, k, t, torch.bfloat16, "cpu", var_threshold=var_threshold)
+        # tight_capacity: tokens * min(K, ceil(E / world)) row slots per peer (world 8 with E = 8: ONE slot per token)
+        ep = ExpertParallelMoE(ops, h, k, t, torch.bfloat16, "cpu", var_threshold=var_threshold, num_experts=e if tight_capacity else None)
+        assert ep.cap_rows == (t * min(k, -(-e // world)) if tight_capacity else t * k)
         ep.profile = True
         worst = 0.0
         for step in range(3):
@@ -84,3 +86,21 @@ def test_ep_gloo_variable_split_exchange(world):
         assert p.exitcode == 0
     for rank, worst in res:
         assert worst == 0.0, f"rank {rank}: variable-split EP result differs from the oracle block by {worst}"
+
+
+def test_ep_gloo_capacity_of_one_slot_per_token_with_one_expert_per_rank():
+    """world size 8 with 8 experts: every rank owns ONE expert, so a token can send a rank at most one row — the fixed
+    form carries tokens x 1 slots per peer (not tokens x K) and can never overflow."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 64, True, 12)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in res:
+        assert worst == 0.0, f"rank {rank}: EP result differs from the oracle block by {worst}"
