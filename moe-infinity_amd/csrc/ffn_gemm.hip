@@ -558,16 +558,31 @@ __device__ __forceinline__ void ring_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d
   // the counted wait carries the stage's registers as in/out operands: no MFMA that reads them can be scheduled above it
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void ring_wait8(u32x4 (&w)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : "n"(N) : "memory");
+}
 
-template <int NTB, int D>
-__global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
+// KT = k-tiles (32 k each) per stage: 2 (a stage = 4 one-KiB weight tiles per wave) or 4 (8 tiles: twice the weight
+// bytes in flight per wave — the 512-token Mixtral prefill is bound by exactly that: 64 KiB in flight per CU against a
+// ~2.5 us HBM round trip under load = 4.1 TB/s; with KT = 4 the activation stage doubles too, so it goes with NTB = 12
+// (192 tokens per pass, 3 x 48 KiB of LDS) and D = 3).
+// NWV = waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (ONE per SIMD: the whole 512-entry register file,
+// room for a 4-stage ring of 8-tile stages next to 96-128 accumulator registers; 14336 rows / 64 = 224 workgroups per
+// expert x 8 experts = 1792 = exactly seven rounds on 256 CUs, where 896 eight-wave workgroups are three and a half).
+template <int NTB, int D, int KT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void ffn_gemm_ring_kernel(FfnStage s) {
   static_assert(D == 3 || D == 4, "register ring of 3 or 4 stages");
+  static_assert(KT == 2 || KT == 4, "2 or 4 k-tiles per stage");
+  static_assert(NTB % 4 == 0, "token groups are multiplied in chunks of 4");
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
-  constexpr int NWV = 8;
-  constexpr int XPW = 2 * NTB / NWV;        // activation DMA pieces (8 rows x 128 B) per wave and stage
-  constexpr int XSTAGE = 2 * NTB * 1024;    // activation bytes per stage (2 k-tiles)
+  constexpr int WL = KT * 2;                // weight tiles (1 KiB) per wave and stage: KT k-tiles x 2 matrices
+  constexpr int NLINE = KT / 2;             // full 128-byte activation lines per row and stage
+  constexpr int XPW = NLINE * 2 * NTB / NWV;  // activation DMA pieces (8 rows x 128 B) per wave and stage
+  constexpr int XSTAGE = KT * NTB * 1024;   // activation bytes per stage
   constexpr int NX = 3;                     // LDS ring
+  static_assert((NLINE * 2 * NTB) % NWV == 0, "pieces must divide over the waves");
   __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
 
   const int u = blockIdx.y;
@@ -589,7 +604,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int KB = K / EPT;
-  const int KS = KB / 2;
+  const int KS = KB / KT;
   const size_t rg_stride = (size_t)KB * 1024;
   // this wave's two weight-tile streams (a row group past the end re-reads the last one; its results are dropped)
   const int rg = min((int)blockIdx.x * NWV + wave, nrg_total - 1);
@@ -602,49 +617,54 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
 
   for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
     const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);  // token groups present in this pass (block-uniform)
+    // activation DMA pieces of this wave: piece id pid = wave + NWV*i -> (line li = pid / (2*NTB), 8-row group pg = pid % (2*NTB))
     const T* xrp[XPW];
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
-      const int trow = tile0 * 16 + (wave + NWV * i) * 8 + (lane >> 3);
+      const int pid = wave + NWV * i;
+      const int li = pid / (2 * NTB), pg = pid - li * (2 * NTB);
+      const int trow = tile0 * 16 + pg * 8 + (lane >> 3);
       const int srow = off + min(trow, cnt - 1);
       const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (((lane & 7) ^ (lane >> 3)) * EPV);
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + li * 2 * EPT + (((lane & 7) ^ (lane >> 3)) * EPV);
     }
     f32x4 acc[NTB][2];
 #pragma unroll
     for (int b = 0; b < NTB; ++b) { acc[b][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    u32x4 wr[D][4];  // [ring stage][k-tile * 2 + matrix]
-    auto issue_w = [&](int ks, u32x4 (&dst)[4]) {
-      const int kb = min(ks, KS - 1) * 2;  // past the end: re-read the last stage (never multiplied), the count stays fixed
-      ring_load(dst[0], ap[0] + (size_t)kb * 1024);
-      ring_load(dst[1], ap[1] + (size_t)kb * 1024);
-      ring_load(dst[2], ap[0] + (size_t)(kb + 1) * 1024);
-      ring_load(dst[3], ap[1] + (size_t)(kb + 1) * 1024);
+    u32x4 wr[D][WL];  // [ring stage][k-tile * 2 + matrix]
+    auto issue_w = [&](int ks, u32x4 (&dst)[WL]) {
+      const int kb = min(ks, KS - 1) * KT;  // past the end: re-read the last stage (never multiplied), the count stays fixed
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) {
+        ring_load(dst[kk * 2 + 0], ap[0] + (size_t)(kb + kk) * 1024);
+        ring_load(dst[kk * 2 + 1], ap[1] + (size_t)(kb + kk) * 1024);
+      }
     };
     auto issue_x = [&](int ks) {
       char* base = smem + (ks % NX) * XSTAGE;
       const int kc = min(ks, KS - 1);
 #pragma unroll
       for (int i = 0; i < XPW; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kc * 2 * EPT), (lptr_t)(base + (wave + NWV * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kc * KT * EPT), (lptr_t)(base + (wave + NWV * i) * 1024), 16, 0, 0);
     };
     // token groups are multiplied in chunks of 4 (absent groups of a partly filled chunk hold clamped copies of the last
     // row and are dropped by the epilogue): one wave-uniform branch per chunk instead of one per group, so the LDS
     // fragment reads of a chunk are issued together and its 8 MFMAs run back to back (a branch per group serialised
     // ds_read -> wait -> 2 MFMAs)
-    auto compute = [&](int ks, const u32x4 (&w)[4]) {
+    auto compute = [&](int ks, const u32x4 (&w)[WL]) {
       const char* base = smem + (ks % NX) * XSTAGE;
       const int r = n & 7;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ch = kk * 4 + q;
+      for (int kk = 0; kk < KT; ++kk) {
+        const int ch = (kk & 1) * 4 + q;
+        const char* lbase = base + (kk >> 1) * (2 * NTB * 1024);  // the 128-byte line this k-tile lives in
 #pragma unroll
         for (int c = 0; c < NTB / 4; ++c) {
           if (c * 4 < ntl) {
             u32x4 bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const u32x4*>(base + ((c * 4 + i) * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4));
+            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const u32x4*>(lbase + ((c * 4 + i) * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int b = c * 4 + i;
@@ -655,10 +675,15 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
         }
       }
     };
+    auto wait_stage = [&](u32x4 (&w)[WL]) {  // this wave's W(S), X(S) landed; what may stay in flight: see below
+      constexpr int N = (D - 2) * WL + XPW;
+      if constexpr (WL == 4) ring_wait<N>(w[0], w[1], w[2], w[3]);
+      else ring_wait8<N>(w);
+    };
     // Issue order of every wave: ... W(k) X(k) W(k+1) X(k+1) ...
     //   D == 4: prologue W0 X0 W1 X1 W2, step S issues X(S+2) W(S+3); before stage S is consumed W(S+1) X(S+1) W(S+2) may
-    //           be outstanding: vmcnt(8 + XPW);
-    //   D == 3: prologue W0 X0 W1 X1,    step S issues W(S+2) X(S+2); outstanding W(S+1) X(S+1): vmcnt(4 + XPW).
+    //           be outstanding: vmcnt(2*WL + XPW);
+    //   D == 3: prologue W0 X0 W1 X1,    step S issues W(S+2) X(S+2); outstanding W(S+1) X(S+1): vmcnt(WL + XPW).
     // Unrolled by D so that the register ring is indexed statically.  Past the end the issues are clamped re-reads
     // (count-preserving); the final wait below drains them.
     issue_w(0, wr[0]); issue_x(0);
@@ -666,7 +691,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
     if (D == 4) issue_w(2, wr[2]);
 #define RING_STEP(S, CUR, NXT)                                                                   \
     if ((S) < KS) {                                                                              \
-      ring_wait<(D - 2) * 4 + XPW>(wr[CUR][0], wr[CUR][1], wr[CUR][2], wr[CUR][3]); /* this wave's W(S), X(S) landed */ \
+      wait_stage(wr[CUR]);                       /* this wave's W(S), X(S) landed */               \
       __builtin_amdgcn_s_barrier();              /* everybody's X(S) landed; LDS buffer (S+2)%3 is free */        \
       if (D == 4) { issue_x((S) + 2); issue_w((S) + 3, wr[NXT]); }                                \
       else { issue_w((S) + 2, wr[NXT]); issue_x((S) + 2); }                                      \
@@ -711,7 +736,6 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring_kernel(FfnStage s) {
   }
 }
 
-
 template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
   static const int use_gemm = env_int("MOEINF_FFN_GEMM", 2);
@@ -744,8 +768,15 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
       static const int ring_wide = env_int("MOEINF_RING_WIDE", -1);
       const bool wide = ring_wide >= 0 ? ring_wide != 0 : max_rows > 128;
       const dim3 g2((grid.x + 7) / 8, grid.y);
-      if (wide) hipLaunchKernelGGL((ffn_gemm_ring_kernel<16, 3>), g2, dim3(512), 0, st, s);
-      else hipLaunchKernelGGL((ffn_gemm_ring_kernel<8, 4>), g2, dim3(512), 0, st, s);
+      // 129-200 rows per expert (a 512-token Mixtral prefill): 192 tokens per pass with FOUR k-tiles per stage — twice the
+      // weight bytes in flight per wave (MOEINF_RING_K4=0: the 256-token / 2-k-tile variant)
+      static const int k4_env = env_int("MOEINF_RING_K4", 1);  // 1: four waves, D = 4; 3: four waves, D = 3; 0: off
+      const bool k4 = k4_env && wide && max_rows <= 200 && (s.K % 128) == 0 && (s.K_sh % 128) == 0;
+      const dim3 g4((grid.x + 3) / 4, grid.y);
+      if (k4 && k4_env == 3) hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 3, 4, 4>), g4, dim3(256), 0, st, s);
+      else if (k4) hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 4, 4, 4>), g4, dim3(256), 0, st, s);
+      else if (wide) hipLaunchKernelGGL((ffn_gemm_ring_kernel<16, 3, 2, 8>), g2, dim3(512), 0, st, s);
+      else hipLaunchKernelGGL((ffn_gemm_ring_kernel<8, 4, 2, 8>), g2, dim3(512), 0, st, s);
       return true;
     }
   }
