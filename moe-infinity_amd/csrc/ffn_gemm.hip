@@ -768,9 +768,11 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
       static const int ring_wide = env_int("MOEINF_RING_WIDE", -1);
       const bool wide = ring_wide >= 0 ? ring_wide != 0 : max_rows > 128;
       const dim3 g2((grid.x + 7) / 8, grid.y);
-      // 129-200 rows per expert (a 512-token Mixtral prefill): 192 tokens per pass with FOUR k-tiles per stage — twice the
-      // weight bytes in flight per wave (MOEINF_RING_K4=0: the 256-token / 2-k-tile variant)
-      static const int k4_env = env_int("MOEINF_RING_K4", 1);  // 1: four waves, D = 4; 3: four waves, D = 3; 0: off
+      // 129-200 rows per expert (a 512-token Mixtral prefill): 192 tokens per pass with FOUR k-tiles per stage and four waves
+      // per workgroup (one per SIMD, 344-378 registers) — twice the weight bytes in flight per wave.  Measured SLOWER
+      // (profiles/r03_ffn_sweep_prefill_ring_k4.txt: 585 / 589 us vs 470 at 512 tokens): with one wave per SIMD nothing
+      // covers a wave's wait -> barrier -> issue -> multiply sequence.  Opt-in only (1: D = 4, 3: D = 3).
+      static const int k4_env = env_int("MOEINF_RING_K4", 0);
       const bool k4 = k4_env && wide && max_rows <= 200 && (s.K % 128) == 0 && (s.K_sh % 128) == 0;
       const dim3 g4((grid.x + 3) / 4, grid.y);
       if (k4 && k4_env == 3) hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 3, 4, 4>), g4, dim3(256), 0, st, s);
