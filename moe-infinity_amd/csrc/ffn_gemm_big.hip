@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // s_barrier, so the four weight DMAs of stage s+1 stay in flight across the barrier that opens stage s (weights come
 // from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
 // into slots that are already consumed, so the count never varies.
-template <int NMAT, bool RING3>
+template <int NMAT, bool RING3, int ABL = 0>
 __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map) {
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
@@ -156,10 +156,13 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
     for (int ks = 0; ks < KS; ++ks) {
       const char *abase, *bbase;
       if constexpr (RING3) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest four DMAs (the weights of stage ks+1) have landed
-        __builtin_amdgcn_s_barrier();                      // ... everybody's have, and stage ks-1 is fully consumed
-        issue_b(min(ks + 1, KS - 1), (ks + 1) & 1);
-        issue_a(min(ks + 2, KS - 1), (ks + 2) % 3);
+        if constexpr (ABL == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (ABL != 2 && ABL != 4 && ABL < 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest four DMAs (the weights of stage ks+1) have landed
+        if constexpr (ABL != 9) __builtin_amdgcn_s_barrier();                      // ... everybody's have, and stage ks-1 is fully consumed
+        if constexpr (ABL != 2 && ABL != 4 && ABL < 8) {
+        if constexpr (ABL != 6) issue_b(min(ks + 1, KS - 1), (ks + 1) & 1);
+        if constexpr (ABL != 7) issue_a(min(ks + 2, KS - 1), (ks + 2) % 3);
+        }
         abase = smem + (ks % 3) * ABYTES;
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
@@ -182,10 +185,10 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) fb[tt] = *reinterpret_cast<const u32x4*>(bbase + b_off[tt] + (((j * 2 + kg) ^ b_f[tt]) << 4));
       };
-      read_frags(0, af[0], bf[0]);
+      if (!(ABL >= 3) || ks == 0) read_frags(0, af[0], bf[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j + 1 < 4) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+        if (j + 1 < 4 && (!(ABL >= 3) || ks == 0)) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the MFMAs below
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
@@ -193,58 +196,110 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
+              if constexpr (ABL == 1 || ABL == 5) acc[m][rt][tt][0] += __builtin_bit_cast(float, af[j & 1][m][rt].x ^ bf[j & 1][tt].x);
+              else
               acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
                                                                        acc[m][rt][tt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (RING3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail issues
-    // epilogue from the accumulators: lane holds, for token (lane & 31), rows 8*(i>>2) + 4*kg + (i&3) of each 32-row tile —
-    // four consecutive rows per group of four registers = one 8-byte store
-    auto epilogue_tile = [&](auto rtc) {  // rt as a compile-time constant: the accumulator arrays must never be indexed dynamically
-      constexpr int rt = decltype(rtc)::value;
-      const int rgt = rg0 + wrg0 + rt * 2;  // first row group of this 32-row tile
+    // epilogue: the output tile goes through the (now idle) LDS so that the global stores are whole rows.  Straight from
+    // the accumulators a lane owns 4 consecutive rows of ONE token — every store instruction touches 32 token rows with
+    // 16 bytes each, 4 096 partial-line writes per workgroup: 17 us of a 86-us workgroup (ablation: 1 532 -> 1 254 us for
+    // the gated stage at 4 096 tokens without it).  Staged as [token][row] with a 16-byte pad per token, then each wave
+    // stores 32 tokens, 1 KiB (4 or 2 full token rows of this block's columns) per instruction.
+    __syncthreads();  // every wave is done with the fragment images
+    constexpr int OROWS = 256 / NMAT;     // output rows of this block (columns of `out`)
+    constexpr int OSTR = OROWS * 2 + 16;  // bytes per token in the staged tile
+    auto epilogue_tile = [&](auto rtc, auto epic) {  // rt and the epilogue kind as compile-time constants: the accumulator
+      constexpr int rt = decltype(rtc)::value;        // arrays must never be indexed dynamically, and a run-time switch on
+      constexpr int EPI = decltype(epic)::value;      // s.epi per element costs more than the arithmetic
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const int tok = tile0 * 16 + wn * 64 + tt * 32 + row32;
-        if (tok < cnt && rgt < nrg_total) {
-          const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
-          T* orow_p = reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out;
+        const int tokl = wn * 64 + tt * 32 + row32;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int orow0 = rgt * 16 + 8 * g4 + 4 * kg;
-            float v[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // lane holds, for token (lane & 31), rows 8*g4 + 4*kg + (0..3) of each 32-row tile
+          const int rowl = (wrg0 + rt * 2) * 16 + 8 * g4 + 4 * kg;
+          float v[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const int orow = orow0 + jj;
-              float a0 = DT<T>::round(acc[0][rt][tt][g4 * 4 + jj]);
-              if (s.epi == EPI_GATED_SILU) {
-                const float bb = DT<T>::round(acc[NMAT - 1][rt][tt][g4 * 4 + jj]);
-                const float sl = DT<T>::round(a0 / (1.0f + expf(-a0)));
-                a0 = DT<T>::round(sl * bb);
-              } else {
-                if ((s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU) && orow < R)
-                  a0 = DT<T>::round(a0 + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
-                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) a0 = fmaxf(a0, 0.f);
-              }
-              v[jj] = a0;
+          for (int jj = 0; jj < 4; ++jj) {
+            float a0 = acc[0][rt][tt][g4 * 4 + jj];
+            if constexpr (EPI == EPI_GATED_SILU) {
+              a0 = DT<T>::round(a0);
+              const float bb = DT<T>::round(acc[NMAT - 1][rt][tt][g4 * 4 + jj]);
+              const float sl = DT<T>::round(a0 / (1.0f + expf(-a0)));
+              a0 = sl * bb;
             }
-            if (orow0 + 3 < R) {
-              DT<T>::store4(orow_p + orow0, v);
-            } else {
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-                if (orow0 + jj < R) DT<T>::store(orow_p + orow0 + jj, v[jj]);
-            }
+            v[jj] = a0;  // rounded by the store; bias / ReLU of the plain stages are applied by the row-store loop below
           }
+          DT<T>::store4(reinterpret_cast<T*>(smem + tokl * OSTR + rowl * 2), v);
         }
       }
     };
-    epilogue_tile(std::integral_constant<int, 0>{});
-    epilogue_tile(std::integral_constant<int, 1>{});
-    if constexpr (RT == 4) {
-      epilogue_tile(std::integral_constant<int, 2>{});
-      epilogue_tile(std::integral_constant<int, 3>{});
+    auto epilogue_all = [&](auto epic) {
+      epilogue_tile(std::integral_constant<int, 0>{}, epic);
+      epilogue_tile(std::integral_constant<int, 1>{}, epic);
+      if constexpr (RT == 4) {
+        epilogue_tile(std::integral_constant<int, 2>{}, epic);
+        epilogue_tile(std::integral_constant<int, 3>{}, epic);
+      }
+    };
+    if constexpr (ABL >= 8) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc += acc[m][rt][tt][i];
+      if (sacc == 12345.678f) reinterpret_cast<float*>(s.out)[0] = sacc;
+    } else {
+      if constexpr (NMAT == 2) epilogue_all(std::integral_constant<int, EPI_GATED_SILU>{});  // the launcher admits two matrices for the gated stage only
+      else epilogue_all(std::integral_constant<int, EPI_NONE>{});
+      __syncthreads();
+      constexpr int CPR = OROWS * 2 / 16;  // 16-byte chunks per token: 16 (gated) / 32
+      constexpr int TPI = 64 / CPR;        // tokens per wave instruction
+      const int c = lane % CPR, tl = lane / CPR;
+      const int orow0 = rg0 * 16 + c * 8;
+      const bool has_bias = NMAT == 1 && (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU);
+      const bool has_relu = NMAT == 1 && (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU);
+      float bias8[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        bias8[jj] = has_bias ? DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + min(orow0 + jj, R - 1)) : 0.f;
+#pragma unroll 4
+      for (int it = 0; it < 32 / TPI; ++it) {
+        const int tokl = wave * 32 + it * TPI + tl;
+        const int tok = tile0 * 16 + tokl;
+        if (tok < cnt && orow0 < R) {
+          const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
+          T* op = reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out + orow0;
+          u32x4 v = *reinterpret_cast<const u32x4*>(smem + tokl * OSTR + c * 16);
+          if (has_bias || has_relu) {  // out = relu(Tr(Tr(acc) + bias)): the staged values are Tr(acc)
+            uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) {
+              float lo = __uint_as_float(w4[h2] << 16), hi = __uint_as_float(w4[h2] & 0xffff0000u);
+              if (has_bias) { lo += bias8[h2 * 2]; hi += bias8[h2 * 2 + 1]; }
+              if (has_relu) { lo = fmaxf(DT<T>::round(lo), 0.f); hi = fmaxf(DT<T>::round(hi), 0.f); }
+              w4[h2] = f2bf2(lo, hi);
+            }
+            v = u32x4{w4[0], w4[1], w4[2], w4[3]};
+          }
+          if (orow0 + 8 <= R) {
+            *reinterpret_cast<u32x4*>(op) = v;
+          } else {
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+              if (orow0 + jj < R) op[jj] = (T)(w4[jj >> 1] >> ((jj & 1) * 16));
+          }
+        }
+      }
     }
     __syncthreads();  // the next pass re-uses buffer 0
   }
@@ -252,13 +307,17 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 
 // max_rows: (an estimate of) the rows of the busiest expert; the kernel's pass loop covers more
 bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st) {
-  if (s.dtype != DT_BF16 || (s.K % 64) != 0 || (s.K_sh % 64) != 0) return false;
+  if (s.dtype != DT_BF16 || (s.K % 64) != 0 || (s.K_sh % 64) != 0 || (s.ld_out % 8) != 0) return false;  // 16-byte row stores
+  if ((nmat == 2) != (s.epi == EPI_GATED_SILU)) return false;
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   const int passes = max_rows <= 256 ? 1 : (max_rows + 255) / 256;
   const int nx = (rmax + 255 / nmat) / (256 / nmat), ny = (int)grid.y, nz = passes > 8 ? 8 : passes;
   const dim3 g((unsigned)(((nx * ny + 7) / 8) * nz * 8));
   static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
+  static const int abl = env_int("MOEINF_GEMM_BIG_ABL", 0);
+#define ABLGO(A) if (abl == A) { if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, true, A>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map); else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, true, A>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map); return true; }
+  ABLGO(1) ABLGO(2) ABLGO(3) ABLGO(4) ABLGO(5) ABLGO(6) ABLGO(7) ABLGO(8) ABLGO(9)
   if (ring3) {
     if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
     else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);

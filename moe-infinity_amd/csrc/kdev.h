@@ -29,11 +29,15 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // scalar helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per
+// instruction; the integer form — add 0x7fff + lsb, NaN test — is 6 VALU instructions and a compare per value, and the
+// GEMM epilogues round three or four times per output element)
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // Device-coherent accessors for data handed between workgroups INSIDE one launch (fused combine / fused router):
 // relaxed agent-scope atomics compile to sc1 loads/stores that write through / miss the per-XCD L2 for lines it
@@ -82,8 +86,8 @@ struct DT<uint16_t> {  // bf16 storage
   __device__ static __forceinline__ void store_coherent(uint16_t* p, float f) { st_coherent(p, f2bf(f)); }
   __device__ static __forceinline__ void store4(uint16_t* p, const float f[4]) {
     uint2 v;
-    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    v.x = f2bf2(f[0], f[1]);
+    v.y = f2bf2(f[2], f[3]);
     *reinterpret_cast<uint2*>(p) = v;
   }
 };
