@@ -319,33 +319,22 @@ __global__ __launch_bounds__(NWV * 64) void ffn_gemm_lds_kernel(FfnStage s) {
       }
     }
     // epilogue straight from the accumulators (no K split): lane holds 4 consecutive rows of one token
-#pragma unroll
-    for (int a = 0; a < RGW; ++a) {
-      const int r0 = (rg0 + wr * RGW + a) * 16 + q * 4;
+    epi_switch<NMAT>(s.epi, [&](auto epic) {
+      constexpr int EPI = decltype(epic)::value;
+      const T* bias = reinterpret_cast<const T*>(W + s.off_bias);
+      const bool aligned = (s.ld_out & 3) == 0;
 #pragma unroll
       for (int b = 0; b < NTW; ++b) {
         const int tok = (tile0 + wc * NTW + b) * 16 + n;
-        if (tok < cnt && rg0 + wr * RGW + a < nrg_total) {
+        if (tok < cnt) {
+          T* orow_p = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int orow = r0 + j;
-            if (orow < R) {
-              float v = DT<T>::round(acc[a][b][0][j]);
-              if (s.epi == EPI_GATED_SILU) {
-                const float bb = DT<T>::round(acc[a][b][NMAT - 1][j]);
-                const float sl = DT<T>::round(v / (1.0f + expf(-v)));
-                v = DT<T>::round(sl * bb);
-              } else {
-                if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
-                  v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
-                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-              }
-              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out + orow, v);
-            }
-          }
+          for (int a = 0; a < RGW; ++a)
+            if (rg0 + wr * RGW + a < nrg_total)
+              epi_quad<T, EPI>(acc[a][b][0], acc[a][b][NMAT - 1], bias, (rg0 + wr * RGW + a) * 16 + q * 4, R, aligned, orow_p);
         }
       }
-    }
+    });
     __syncthreads();  // the next pass re-uses buffer 0
   }
 }
@@ -495,33 +484,22 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
       }
     }
     // epilogue straight from the accumulators (no K split): lane holds 4 consecutive rows of one token
-#pragma unroll
-    for (int a = 0; a < RW; ++a) {
-      const int r0 = (rgw0 + a) * 16 + q * 4;
+    epi_switch<NMAT>(s.epi, [&](auto epic) {
+      constexpr int EPI = decltype(epic)::value;
+      const T* bias = reinterpret_cast<const T*>(W + s.off_bias);
+      const bool aligned = (s.ld_out & 3) == 0;
 #pragma unroll
       for (int b = 0; b < NTB; ++b) {
         const int tok = (tile0 + b) * 16 + n;
-        if (tok < cnt && rgw0 + a < nrg_total) {
+        if (tok < cnt) {
+          T* orow_p = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int orow = r0 + j;
-            if (orow < R) {
-              float v = DT<T>::round(acc[a][b][0][j]);
-              if (s.epi == EPI_GATED_SILU) {
-                const float bb = DT<T>::round(acc[a][b][NMAT - 1][j]);
-                const float sl = DT<T>::round(v / (1.0f + expf(-v)));
-                v = DT<T>::round(sl * bb);
-              } else {
-                if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
-                  v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));
-                if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-              }
-              DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[off + tok] : off + tok) * s.ld_out + orow, v);
-            }
-          }
+          for (int a = 0; a < RW; ++a)
+            if (rgw0 + a < nrg_total)
+              epi_quad<T, EPI>(acc[a][b][0], acc[a][b][NMAT - 1], bias, (rgw0 + a) * 16 + q * 4, R, aligned, orow_p);
         }
       }
-    }
+    });
     __syncthreads();  // the next pass re-uses LDS buffer 0
   }
 }
@@ -714,21 +692,14 @@ __global__ __launch_bounds__(NWV * 64) void ffn_gemm_ring_kernel(FfnStage s) {
 #undef RING_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail issues
     // epilogue straight from the accumulators: lane holds 4 consecutive rows of one token
+    {
+      const bool aligned = (s.ld_out & 3) == 0;
 #pragma unroll
-    for (int b = 0; b < NTB; ++b) {
-      const int tok = (tile0 + b) * 16 + n;
-      if (tok < cnt && rg_live) {
-        const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
-        const int r0 = rg * 16 + q * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (r0 + j < R) {
-            float v = DT<T>::round(acc[b][0][j]);
-            const float bb = DT<T>::round(acc[b][1][j]);
-            const float sl = DT<T>::round(v / (1.0f + expf(-v)));
-            v = DT<T>::round(sl * bb);
-            DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out + r0 + j, v);
-          }
+      for (int b = 0; b < NTB; ++b) {
+        const int tok = (tile0 + b) * 16 + n;
+        if (tok < cnt && rg_live) {
+          const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
+          epi_quad<T, EPI_GATED_SILU>(acc[b][0], acc[b][1], nullptr, rg * 16 + q * 4, R, aligned, reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out);
         }
       }
     }

@@ -5,6 +5,8 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -119,6 +121,47 @@ struct DT<float> {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
   }
 };
+
+// GEMM epilogues: four consecutive output rows r0..r0+3 of ONE token (an accumulator quad of the 16x16 MFMA) -> `orow_p`
+// (the token's output row).  The epilogue kind is a compile-time constant (a run-time switch on s.epi per element costs
+// more than the arithmetic), the quad leaves as one 8-byte (fp32: 16-byte) store when it is whole and aligned.
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_quad(const f32x4& a0, const f32x4& a1, const T* bias, int r0, int R, bool aligned, T* orow_p) {
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = a0[j];
+    if constexpr (EPI == EPI_GATED_SILU) {
+      x = DT<T>::round(x);
+      const float bb = DT<T>::round(a1[j]);
+      const float sl = DT<T>::round(x / (1.0f + expf(-x)));
+      x = sl * bb;  // rounded by the store
+    } else {
+      if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) x = DT<T>::round(DT<T>::round(x) + DT<T>::load(bias + min(r0 + j, R - 1)));
+      if constexpr (EPI == EPI_RELU || EPI == EPI_BIAS_RELU) x = fmaxf(DT<T>::round(x), 0.f);
+    }
+    v[j] = x;
+  }
+  if (aligned && r0 + 3 < R) {
+    DT<T>::store4(orow_p + r0, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r0 + j < R) DT<T>::store(orow_p + r0 + j, v[j]);
+  }
+}
+// f(std::integral_constant<int, EPI>) for the stage's epilogue kind (two matrices = the gated stage, launch_ffn_stage)
+template <int NMAT, typename F>
+__device__ __forceinline__ void epi_switch(int epi, F&& f) {
+  if constexpr (NMAT == 2) {
+    f(std::integral_constant<int, EPI_GATED_SILU>{});
+  } else {
+    if (epi == EPI_NONE) f(std::integral_constant<int, EPI_NONE>{});
+    else if (epi == EPI_BIAS) f(std::integral_constant<int, EPI_BIAS>{});
+    else if (epi == EPI_RELU) f(std::integral_constant<int, EPI_RELU>{});
+    else f(std::integral_constant<int, EPI_BIAS_RELU>{});
+  }
+}
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
