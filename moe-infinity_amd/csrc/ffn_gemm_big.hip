@@ -8,8 +8,12 @@
 //   * v_mfma_f32_32x32x16_bf16: a wave owns 128 weight rows x 64 tokens = 8 accumulator tiles of 32x32 (128 VGPRs);
 //     per 16-deep k-step 4 A + 2 B fragment reads feed 8 MFMAs of 32 cycles each — a third of the LDS bytes per flop of
 //     the 16x16x32 kernels, 32 MFMAs (1024 matrix-pipe cycles) per wave between barriers;
-//   * both operands through LDS by the asynchronous global->LDS DMA, two 64-KiB stages: the DMA of stage s+1 is
-//     issued right after the barrier that opens stage s and has a whole stage of MFMAs (~1 us) to land;
+//   * both operands through LDS by the asynchronous global->LDS DMA: weights in a 3-deep ring two stages ahead,
+//     activations in two buffers one stage ahead (RING3 below), the DMA instructions spread between the MFMAs;
+//   * ping-pong schedule (MODE 2, the default): the two waves of a SIMD alternate LOAD slots (fragment reads of one
+//     16-deep k-step) and COMPUTE slots (its 8 MFMAs + 2 DMAs), one s_barrier per slot, the second row half one slot
+//     behind — on every SIMD one wave's MFMAs run beside the other's LDS traffic (MFMA-busy 46 -> 61 % by PMC);
+//   * the output tile leaves through the idle LDS as whole rows (16-byte stores), epilogue kind compile-time;
 //   * weight tiles are already MFMA fragments in HBM (the tiled slot layout): a 32-row A fragment is two vertically
 //     adjacent 1-KiB tiles, read from the DMA image at tile[(row>>4)] + ((q*16 + (row&15)) * 16) — 256 contiguous bytes
 //     per 16 lanes, conflict-free for ds_read_b128;
@@ -29,12 +33,26 @@ namespace moeinf {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// the fragment reads of k-step J of a stage (ping-pong loop below) as inline asm, into register set J & 1
+template <int NMAT, int RT, int RGB, int J>
+__device__ __forceinline__ void big_read_frags(u32x4 (&af)[2][NMAT][RT], u32x4 (&bf)[2][2], const uint32_t (&a_addr)[NMAT][RT], const uint32_t (&b_base)[2]) {
+  constexpr int kk = J >> 1, ks2 = J & 1;
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[J & 1][m][rt]) : "v"(a_addr[m][rt]), "n"(kk * NMAT * RGB * 1024 + ks2 * 512));
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)  // chunk (2J + kg) ^ f: the (kg ^ f) part is in b_base, 2J flips bits 5-6 of the byte address
+    asm volatile("ds_read_b128 %0, %1" : "=v"(bf[J & 1][tt]) : "v"(b_base[tt] ^ (uint32_t)(J << 5)));
+}
+
 // RING3: the weight image gets a THREE-deep LDS ring (3 x 32 KiB) and is fetched two stages ahead, the activation image
 // keeps two buffers (2 x 32 KiB) one stage ahead — 160 KiB, all of a CU's LDS; counted s_waitcnt vmcnt(4) + raw
 // s_barrier, so the four weight DMAs of stage s+1 stay in flight across the barrier that opens stage s (weights come
 // from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
 // into slots that are already consumed, so the count never varies.
-template <int NMAT, bool RING3, int ABL = 0>
+template <int NMAT, bool RING3, int MODE>
 __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map) {
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
@@ -135,19 +153,102 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][rt][tt][i] = 0.f;
 
+    // DMA piece i of a stage: i < 4 activation pieces (8 token rows x 128 B each lane-group), i >= 4 weight tiles
+    auto issue_a1 = [&](int ks, int slot, int i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (size_t)ks * KK * 1024), (lptr_t)(smem + slot * ABYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
+    auto issue_b1 = [&](int ks, int slot, int i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(smem + BOFF + slot * BBYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
     auto issue_a = [&](int ks, int slot) {
-      char* base = smem + slot * ABYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (size_t)ks * KK * 1024), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) issue_a1(ks, slot, i);
     };
     auto issue_b = [&](int ks, int slot) {
-      char* base = smem + BOFF + slot * BBYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) issue_b1(ks, slot, i);
     };
 
+    if constexpr (MODE == 2) {
+      // Ping-pong: the two waves of a SIMD (wave w and w + 4, i.e. the row halves wm = 0 / 1) alternate between a LOAD
+      // slot (fragment reads of one 16-deep k-step + two DMAs, retired before the slot ends) and a COMPUTE slot (its
+      // eight MFMAs), one s_barrier per slot; the wm = 1 half runs one slot behind, so on every SIMD one wave's MFMAs run
+      // beside the other's LDS / DMA issue instead of both doing the same thing at the same time.
+      //   slot:   0   1   2   3   4   5   6   7  | 8
+      //   wm=0:   L0  C0  L1  C1  L2  C2  L3  C3 | L0'        (Lj: k-step j of the stage, Cj: its MFMAs)
+      //   wm=1:   C3p L0  C0  L1  C1  L2  C2  L3 | C3  L0' ...
+      // A wave's eight DMAs per stage (d0..d3: its share of stage s+1's activations, d4..d7: of stage s+2's weights) are
+      // issued two per COMPUTE slot.  Hazards: stage s+1 is first read in slot 8 (wm = 0), so every wave retires its share
+      // of it before the barrier that ends slot 7 — wm = 0 after C3 (all eight issued: vmcnt(4)), wm = 1 after L3 (d0..d5
+      // issued, its C3 is slot 8: vmcnt(2); the weights of stage s+1 are older and retire first).  The buffers the DMAs of
+      // stage s overwrite were last read in stage s-1's L3 of wm = 1 (slot 7), retired by that slot's lgkmcnt(0), two
+      // barriers before the first DMA issue of stage s (slot 1).
+      static_assert(MODE != 2 || RING3, "ping-pong uses the 3-deep weight ring");
+      issue_a(0, 0); issue_b(0, 0); issue_a(min(1, KS - 1), 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (wm == 1) __builtin_amdgcn_s_barrier();  // one slot behind
+      for (int ks = 0; ks < KS; ++ks) {
+        const char* abase = smem + (ks % 3) * ABYTES;
+        const char* bbase = smem + BOFF + (ks & 1) * BBYTES;
+        auto issue_next = [&](int d) {
+          if (d < 4) issue_b1(min(ks + 1, KS - 1), (ks + 1) & 1, d);
+          else issue_a1(min(ks + 2, KS - 1), (ks + 2) % 3, d - 4);
+        };
+        u32x4 af[2][NMAT][RT], bf[2][2];
+        // fragment reads as inline asm: the compiler's own wait insertion puts lgkmcnt(0) in front of every MFMA group that
+        // follows LDS reads issued after the ones it needs (it does not count reads past a pending LDS DMA), which would
+        // make each COMPUTE slot wait for the NEXT step's fragments; the counted waits below are the only ones
+        const uint32_t a_lds = (uint32_t)(uintptr_t)(lptr_t)abase, b_lds = (uint32_t)(uintptr_t)(lptr_t)bbase;
+        uint32_t a_addr[NMAT][RT], b_base[2];
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) a_addr[m][rt] = a_lds + a_off[m][rt];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) b_base[tt] = (b_lds + b_off[tt]) | (uint32_t)(((kg ^ b_f[tt]) & 7) << 4);  // 128-byte aligned base | chunk
+        auto slot_pair = [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          // LOAD slot j: the fragments of k-step j+1 are requested one slot ahead (they land under the MFMAs of step j), so
+          // only L0 waits out an LDS round trip; L3 requests nothing — the next stage is not known to have landed yet
+          big_read_frags<NMAT, RT, RGB, j>(af, bf, a_addr, b_base);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          // wm = 1 has issued d0..d5 of this stage by now (its C3 is slot 8): all but d4, d5 — i.e. its share of stage s+1's
+          // activations and, older, of stage s+1's weights — must have landed before the barrier that ends slot 7
+          if (j == 3 && wm == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt) {
+                acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
+                                                                         acc[m][rt][tt], 0, 0, 0);
+                // the stage's eight DMAs ride in the COMPUTE slots, one behind every fourth MFMA (32 matrix-pipe cycles
+                // each cover the issue): in the LOAD slot they would lengthen the slot the matrix pipe waits for
+                const int idx = (m * RT + rt) * 2 + tt;
+                if ((idx & 3) == 3) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  issue_next(j * 2 + (idx >> 2));
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+          if (j == 3 && wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        slot_pair(std::integral_constant<int, 0>{});
+        slot_pair(std::integral_constant<int, 1>{});
+        slot_pair(std::integral_constant<int, 2>{});
+        slot_pair(std::integral_constant<int, 3>{});
+      }
+      if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+    } else {
     if constexpr (RING3) {
       issue_a(0, 0); issue_b(0, 0); issue_a(min(1, KS - 1), 1);
     } else {
@@ -155,19 +256,26 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
     }
     for (int ks = 0; ks < KS; ++ks) {
       const char *abase, *bbase;
-      if constexpr (RING3) {
-        if constexpr (ABL == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (ABL != 2 && ABL != 4 && ABL < 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest four DMAs (the weights of stage ks+1) have landed
-        if constexpr (ABL != 9) __builtin_amdgcn_s_barrier();                      // ... everybody's have, and stage ks-1 is fully consumed
-        if constexpr (ABL != 2 && ABL != 4 && ABL < 8) {
-        if constexpr (ABL != 6) issue_b(min(ks + 1, KS - 1), (ks + 1) & 1);
-        if constexpr (ABL != 7) issue_a(min(ks + 2, KS - 1), (ks + 2) % 3);
+      // the eight DMAs a wave issues per stage, in issue order d = 0..7: activations of stage ks+1 first, then the weights
+      // (RING3: of stage ks+2 — the newest four, the ones vmcnt(4) leaves in flight)
+      auto issue_next = [&](int d) {
+        if constexpr (RING3) {
+          if (d < 4) issue_b1(min(ks + 1, KS - 1), (ks + 1) & 1, d);
+          else issue_a1(min(ks + 2, KS - 1), (ks + 2) % 3, d - 4);
+        } else {
+          if (ks + 1 < KS) {
+            if (d < 4) issue_b1(ks + 1, (ks + 1) & 1, d);
+            else issue_a1(ks + 1, (ks + 1) & 1, d - 4);
+          }
         }
+      };
+      if constexpr (RING3) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest four DMAs (the weights of stage ks+1) have landed
+        __builtin_amdgcn_s_barrier();                      // ... everybody's have, and stage ks-1 is fully consumed
         abase = smem + (ks % 3) * ABYTES;
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage ks has landed
         __syncthreads();                                   // ... everybody's has, and stage ks-1 is fully consumed
-        if (ks + 1 < KS) { issue_a(ks + 1, (ks + 1) & 1); issue_b(ks + 1, (ks + 1) & 1); }
         abase = smem + (ks & 1) * ABYTES;
       }
       bbase = smem + BOFF + (ks & 1) * BBYTES;
@@ -185,23 +293,35 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) fb[tt] = *reinterpret_cast<const u32x4*>(bbase + b_off[tt] + (((j * 2 + kg) ^ b_f[tt]) << 4));
       };
-      if (!(ABL >= 3) || ks == 0) read_frags(0, af[0], bf[0]);
+      read_frags(0, af[0], bf[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j + 1 < 4 && (!(ABL >= 3) || ks == 0)) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+        if (j + 1 < 4) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the MFMAs below
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              if constexpr (ABL == 1 || ABL == 5) acc[m][rt][tt][0] += __builtin_bit_cast(float, af[j & 1][m][rt].x ^ bf[j & 1][tt].x);
-              else
+            for (int tt = 0; tt < 2; ++tt) {
               acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
                                                                        acc[m][rt][tt], 0, 0, 0);
+              {
+                // one DMA behind every fourth MFMA: all eight waves issuing their eight DMAs at the top of the stage queue
+                // up at the CU's one address unit (64 x 1 KiB at 64 B/clk ~ 1 000 cycles) with nothing in the matrix pipe —
+                // measured +450 us of 1 530 for the gated stage at 4 096 tokens; spread out, a wave that waits at the
+                // address unit has four MFMAs (128 cycles) queued and its SIMD partner fills the rest
+                const int idx = (m * RT + rt) * 2 + tt;
+                if ((idx & 3) == 3) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  issue_next(j * 2 + (idx >> 2));
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
     if constexpr (RING3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail issues
     // epilogue: the output tile goes through the (now idle) LDS so that the global stores are whole rows.  Straight from
@@ -246,18 +366,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
         epilogue_tile(std::integral_constant<int, 3>{}, epic);
       }
     };
-    if constexpr (ABL >= 8) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc += acc[m][rt][tt][i];
-      if (sacc == 12345.678f) reinterpret_cast<float*>(s.out)[0] = sacc;
-    } else {
+    {
       if constexpr (NMAT == 2) epilogue_all(std::integral_constant<int, EPI_GATED_SILU>{});  // the launcher admits two matrices for the gated stage only
       else epilogue_all(std::integral_constant<int, EPI_NONE>{});
       __syncthreads();
@@ -315,16 +424,15 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   const dim3 g((unsigned)(((nx * ny + 7) / 8) * nz * 8));
   static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
-  static const int abl = env_int("MOEINF_GEMM_BIG_ABL", 0);
-#define ABLGO(A) if (abl == A) { if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, true, A>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map); else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, true, A>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map); return true; }
-  ABLGO(1) ABLGO(2) ABLGO(3) ABLGO(4) ABLGO(5) ABLGO(6) ABLGO(7) ABLGO(8) ABLGO(9)
+  static const int mode = env_int("MOEINF_GEMM_BIG_MODE", 2);  // 2: ping-pong (the two waves of a SIMD alternate load / compute slots), 1: both in step
+#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map)
   if (ring3) {
-    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
-    else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, true>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+    if (mode == 2) { if (nmat == 2) BIGGO(2, true, 2); else BIGGO(1, true, 2); }
+    else { if (nmat == 2) BIGGO(2, true, 1); else BIGGO(1, true, 1); }
   } else {
-    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<2, false>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
-    else hipLaunchKernelGGL((ffn_gemm_big_kernel<1, false>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map);
+    if (nmat == 2) BIGGO(2, false, 1); else BIGGO(1, false, 1);
   }
+#undef BIGGO
   return true;
 }
 
