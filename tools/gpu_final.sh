@@ -33,7 +33,7 @@ python tools/mfma_summary.py "$OUT/pmc_mfma/m_counter_collection.csv" "$OUT/pmc_
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/$OUT/pmc_mfma4096" -o m -- \
     python "$R/tools/prefill_once.py" mixtral_8x7b 4096 1 6 > /dev/null 2> "$R/$OUT/pmc_mfma4096.err")
 python tools/mfma_summary.py "$OUT/pmc_mfma4096/m_counter_collection.csv" "$OUT/pmc_mfma4096/m_kernel_trace.csv" "$OUT/pmc_mfma_prefill4096_mixtral8x7b.json" > /dev/null 2> "$OUT/mfma4096_summary.err"
-SWEEP_ENVS="A=1;MOEINF_GEMM_BIG=0" timeout 600 python tools/ffn_sweep.py mixtral_8x7b:512:2 mixtral_8x7b:2048:2 mixtral_8x7b:4096:2 deepseek_v2_lite:4096:4 > "$OUT/ffn_sweep_prefill_final.txt" 2>&1
+SWEEP_ENVS="A=1;MOEINF_GEMM_BIG_MODE=1;MOEINF_GEMM_BIG=0" timeout 900 python tools/ffn_sweep.py mixtral_8x7b:512:2 mixtral_8x7b:2048:2 mixtral_8x7b:4096:2 deepseek_v2_lite:4096:4 > "$OUT/ffn_sweep_prefill_final.txt" 2>&1
 for wl in mixtral-8x7b deepseek-v2-lite; do
   timeout 400 python bench.py --workload $wl --force-ep --no-other-configs --miss-heavy-frac 0 --prompt 0 > "$OUT/bench_ep1_$wl.json" 2> "$OUT/bench_ep1_$wl.err"
 done
