@@ -713,12 +713,13 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
   // long prefills: the 256 x 256 / 32x32x16-MFMA kernel (ffn_gemm_big.hip).  Measured (profiles/r03_ffn_sweep_prefill_big_*.txt):
   // it beats ffn_gemm_lds from 257 rows per expert on (Mixtral down projection at 2048 tokens 846 -> 730 us, DeepSeek-V2-Lite
-  // at 4096 tokens 2.54 -> 1.96 ms per layer), but the register-ring kernel (gated stage, K >= 4096) only above ~640 rows
-  // (Mixtral gate/up, ping-pong version of the big kernel: 2048 tokens ring 1250 us vs 1273-1281; 3072 tokens 1529 vs 1470;
-  // 4096 tokens 2485 vs 1750-1880)
+  // at 4096 tokens 2.54 -> 1.96 ms per layer).  The register-ring kernel (gated stage, K >= 4096) held out to ~640 rows
+  // against the first ping-pong version; with the short-last-pass variant the big kernel wins from 257 rows on (Mixtral
+  // gate/up: 768 tokens 503 vs 535 us, 1024 tokens 647 vs 748, 1536 tokens 845 vs 1 031, 2048 tokens 1 010 vs 1 250), so
+  // both stages switch at the same row count now; below it (512 tokens: 436 vs 450 gate/up but 324 vs 265 down) ring / lds stay
   static const int big_env = env_int("MOEINF_GEMM_BIG", 1);
   static const int big_rows = env_int("MOEINF_GEMM_BIG_ROWS", 256);
-  static const int big_rows_ring = env_int("MOEINF_GEMM_BIG_ROWS_RING", 640);
+  static const int big_rows_ring = env_int("MOEINF_GEMM_BIG_ROWS_RING", 256);
   bool ring_stage = false;
   if constexpr (sizeof(T) == 2 && NMAT == 2) {
     static const int ring_min_k0 = env_int("MOEINF_RING_MIN_K", 4096);

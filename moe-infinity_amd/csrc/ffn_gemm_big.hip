@@ -53,7 +53,7 @@ __device__ __forceinline__ void big_read_frags(u32x4 (&af)[2][NMAT][RT], u32x4 (
 // from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
 // into slots that are already consumed, so the count never varies.
 template <int NMAT, bool RING3, int MODE>
-__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map) {
+__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map, int tail_max, int chunk) {
   typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
   constexpr int RGB = 16 / NMAT;   // row groups (16 rows) of EACH matrix per block
@@ -64,16 +64,33 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
   constexpr int ABYTES = A_TILES * 1024, BBYTES = B_PIECES * 1024;  // 32 KiB each per stage
   constexpr int NA = RING3 ? 3 : 2;
   constexpr int BOFF = NA * ABYTES;  // the activation buffers start behind the weight ring
-  __shared__ __attribute__((aligned(16))) char smem[NA * ABYTES + 2 * BBYTES];  // the ONLY __shared__ object (a second one de-pipelines the DMA)
+  // the ONLY __shared__ object (a second one de-pipelines the DMA); always all 160 KiB: the short-pass ring (3 x 48 KiB) and the
+  // staged output tile (256 tokens x 528 B for the plain stage) need more than the two-buffer form's 128 KiB
+  __shared__ __attribute__((aligned(16))) char smem[3 * ABYTES + 2 * BBYTES];
 
   // 1-D grid, XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule; a wrong guess costs speed, never
-  // correctness).  The nz token passes of ONE weight slab (row block bx of expert slot u) get ids 8 apart — the same XCD,
-  // dispatched together — so the slab streams from HBM once and the other passes hit it in that XCD's L2:
-  //   id = ((g / 8) * nz + pass) * 8 + g % 8,   g = u * nx + bx
+  // correctness).  The token passes of ONE weight slab (row block bx of expert slot u, g = u * nx + bx) get ids 8 apart —
+  // the same XCD, dispatched together — so the slab streams from HBM once and the other passes hit it in that XCD's L2.
   int pass0, g;
   if (xcd_map) {
-    const int xcd = blockIdx.x & 7, tq = blockIdx.x >> 3;
-    pass0 = tq % nz; g = (tq / nz) * 8 + xcd;
+    // Slabs are dealt to the XCDs (= id % 8) in CHUNKS of `chunk` (4) consecutive slabs in (expert, row block) order, so
+    // the ~32 workgroups an XCD runs at a time are a few slabs x (nz - 1) passes of ONE expert: they stream those weight slabs
+    // and nz - 1 activation tiles between them through that XCD's L2.  Dealt one by one, the down projection (16 slabs
+    // per expert) shared each activation tile between only two workgroups of an XCD; one contiguous run per XCD puts
+    // whole experts — and the DeepSeek shared expert's 16 passes — on one XCD (measured: gate/up 586 -> 1 022 us).
+    // ... and the LAST pass of every slab (the ragged one: 1..256 tokens, or none) gets the highest ids: the full passes
+    // fill whole rounds of the chip first, the short ones pack the final partial round (longest jobs first).
+    const int per = chunk * (((nx * ny + chunk - 1) / chunk + 7) / 8);  // slab positions per XCD
+    const int nfull = per * 8 * (nz - 1);
+    int xcd, loc;
+    if ((int)blockIdx.x < nfull) {
+      const int tq = blockIdx.x >> 3;
+      xcd = blockIdx.x & 7; pass0 = tq % (nz - 1); loc = tq / (nz - 1);
+    } else {
+      const int idb = (int)blockIdx.x - nfull;
+      xcd = idb & 7; pass0 = nz - 1; loc = idb >> 3;
+    }
+    g = ((loc / chunk) * 8 + xcd) * chunk + loc % chunk;
   } else {  // MOEINF_GEMM_BIG_XCD=0 (A/B): passes adjacent in id, i.e. spread over the XCDs
     pass0 = blockIdx.x % nz; g = blockIdx.x / nz;
   }
@@ -169,6 +186,53 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
       for (int i = 0; i < 4; ++i) issue_b1(ks, slot, i);
     };
 
+    // SHORT LAST PASS.  An expert's rows are cut into 256-token passes; the last one holds anything from 1 to 256 tokens and
+    // as a full tile costs a full pass (at 4 096 Mixtral tokens half the experts have ~30 tokens in a fifth pass: 12 % of
+    // the gated stage's MFMA work, and the down projection's 576 workgroups are 2.25 rounds of 256 CUs because of them).
+    // Up to tail_max (128) tokens run this variant instead: all eight waves along the ROW dimension (wave w: 32 rows x up
+    // to four 32-token column tiles; gated stage: an A fragment made of row group w of BOTH matrices — gate rows in its
+    // first 16 rows, up rows in the last 16 land in the same lane's registers i and i + 8), a quarter or half of the
+    // MFMAs, half the activation bytes, a three-deep 48-KiB stage ring fetched two stages ahead (the pass is bound by
+    // the weight stream, not by the matrix pipe).  Accumulators: the first four tiles of acc.
+    const int ntok = min(256, cnt - tile0 * 16);
+    const bool tail = ntok <= tail_max;  // block-uniform
+    const int nct = (ntok + 31) >> 5;    // 32-token column tiles in a tail pass
+    constexpr int TSTAGE = ABYTES + 16 * 1024;
+    if (tail) {
+      const int a_off_t = (NMAT == 2 ? ((row32 >> 4) * RGB + wave) : (2 * wave + (row32 >> 4))) * 1024 + (kg * 16 + (row32 & 15)) * 16;
+      const int b_off_t = (row32 >> 3) * 1024 + (row32 & 7) * 128;  // + column tile * 4096
+      const int b_f_t = (((row32 & 7) >> 1) & 3) | (((row32 >> 3) & 1) << 2);
+      auto issue_t = [&](int ks, int slot) {
+        char* base = smem + slot * TSTAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (size_t)ks * KK * 1024), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + ABYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+      };
+      issue_t(0, 0);
+      issue_t(min(1, KS - 1), 1);
+      for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage ks landed (this wave's share); stage ks+1 may be in flight
+        __builtin_amdgcn_s_barrier();                      // ... everybody's; stage ks-1 is consumed
+        issue_t(min(ks + 2, KS - 1), (ks + 2) % 3);        // past the end: clamped re-reads into a consumed slot, the count stays fixed
+        const char* ab = smem + (ks % 3) * TSTAGE;
+        const char* bb = ab + ABYTES + b_off_t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 af = *reinterpret_cast<const u32x4*>(ab + a_off_t + (j >> 1) * NMAT * RGB * 1024 + (j & 1) * 512);
+          const int ch = ((j * 2 + kg) ^ b_f_t) << 4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < nct) {
+              const u32x4 bfr = *reinterpret_cast<const u32x4*>(bb + c * 4096 + ch);
+              acc[0][c >> 1][c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc[0][c >> 1][c & 1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else
     if constexpr (MODE == 2) {
       // Ping-pong: the two waves of a SIMD (wave w and w + 4, i.e. the row halves wm = 0 / 1) alternate between a LOAD
       // slot (fragment reads of one 16-deep k-step + two DMAs, retired before the slot ends) and a COMPUTE slot (its
@@ -323,7 +387,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
       }
     }
     }
-    if constexpr (RING3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail issues
+    if (RING3 || tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped issues past the last stage
     // epilogue: the output tile goes through the (now idle) LDS so that the global stores are whole rows.  Straight from
     // the accumulators a lane owns 4 consecutive rows of ONE token — every store instruction touches 32 token rows with
     // 16 bytes each, 4 096 partial-line writes per workgroup: 17 us of a 86-us workgroup (ablation: 1 532 -> 1 254 us for
@@ -367,8 +431,37 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
       }
     };
     {
-      if constexpr (NMAT == 2) epilogue_all(std::integral_constant<int, EPI_GATED_SILU>{});  // the launcher admits two matrices for the gated stage only
-      else epilogue_all(std::integral_constant<int, EPI_NONE>{});
+      if (tail) {
+        // wave w's tile: gated — rows 16w..16w+15 of the block's 128 (registers i < 8 gate, i + 8 up); plain — rows 32w..32w+31
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < nct) {
+            const f32x16& A = acc[0][c >> 1][c & 1];
+            const int tokl = c * 32 + row32;
+#pragma unroll
+            for (int g4 = 0; g4 < (NMAT == 2 ? 2 : 4); ++g4) {
+              const int rowl = wave * (NMAT == 2 ? 16 : 32) + 8 * g4 + 4 * kg;
+              float v[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                float a0 = A[g4 * 4 + jj];
+                if constexpr (NMAT == 2) {
+                  a0 = DT<T>::round(a0);
+                  const float bb2 = DT<T>::round(A[8 + g4 * 4 + jj]);
+                  const float sl = DT<T>::round(a0 / (1.0f + expf(-a0)));
+                  a0 = sl * bb2;
+                }
+                v[jj] = a0;
+              }
+              DT<T>::store4(reinterpret_cast<T*>(smem + tokl * OSTR + rowl * 2), v);
+            }
+          }
+        }
+      } else if constexpr (NMAT == 2) {
+        epilogue_all(std::integral_constant<int, EPI_GATED_SILU>{});  // the launcher admits two matrices for the gated stage only
+      } else {
+        epilogue_all(std::integral_constant<int, EPI_NONE>{});
+      }
       __syncthreads();
       constexpr int CPR = OROWS * 2 / 16;  // 16-byte chunks per token: 16 (gated) / 32
       constexpr int TPI = 64 / CPR;        // tokens per wave instruction
@@ -421,11 +514,14 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   const int passes = max_rows <= 256 ? 1 : (max_rows + 255) / 256;
   const int nx = (rmax + 255 / nmat) / (256 / nmat), ny = (int)grid.y, nz = passes > 8 ? 8 : passes;
-  const dim3 g((unsigned)(((nx * ny + 7) / 8) * nz * 8));
+  static const int chunk_env = env_int("MOEINF_GEMM_BIG_CHUNK", 4);
+  const int chunk = chunk_env < 1 ? 1 : chunk_env;
+  const dim3 g((unsigned)(chunk * (((nx * ny + chunk - 1) / chunk + 7) / 8) * 8 * nz));
   static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
+  static const int tail_max = env_int("MOEINF_GEMM_BIG_TAIL", 128);  // tokens up to which a last pass runs the short-pass variant (0: never)
   static const int mode = env_int("MOEINF_GEMM_BIG_MODE", 2);  // 2: ping-pong (the two waves of a SIMD alternate load / compute slots), 1: both in step
-#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map)
+#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk)
   if (ring3) {
     if (mode == 2) { if (nmat == 2) BIGGO(2, true, 2); else BIGGO(1, true, 2); }
     else { if (nmat == 2) BIGGO(2, true, 1); else BIGGO(1, true, 1); }

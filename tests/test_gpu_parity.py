@@ -693,6 +693,29 @@ def test_batch1_selfrouting_ties_lowest_index(family, e, k):
     eng.close()
 
 
+@pytest.mark.parametrize("family,t", [("mixtral", 257), ("mixtral", 288), ("mixtral", 289), ("mixtral", 356), ("mixtral", 384), ("mixtral", 385),
+                                      ("nllb", 289), ("nllb", 350), ("nllb", 384), ("nllb", 600)])
+def test_short_last_pass_of_the_256x256_kernel(family, t):
+    """The last 256-token pass of an expert with 1..128 tokens in it runs ffn_gemm_big's short-pass variant (all eight
+    waves along the row dimension, gate and up rows in one A fragment, 1-4 column tiles of 32 tokens): every tile count,
+    both sides of the 128-token switch, gated and plain (bias + ReLU) stages.  One expert (Mixtral, K = 1) / two experts
+    that both get every token (NLLB top-2 of 2), so the row counts are exact."""
+    e, k = (1, 1) if family == "mixtral" else (2, 2)
+    h, f = 256, 384
+    gate, experts, shared = make_weights(family, h, f, e, 2700 + t, torch.bfloat16, gate_std=0.5 if family == "nllb" else 0.02)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts, shared)
+    x = acts(t, h, torch.bfloat16, 2701 + t)
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k) if family == "mixtral" else R.block_nllb(x[None], gate, experts)
+    assert all(int(v.shape[0]) == t for v in ref.expert_out.values())
+    for i in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        rows = oracle_expert_rows(ref, e)
+        assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, f"expert rows, forward {i}", ulps=2.0 if family == "nllb" else 1.0)
+        assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block, forward {i}")
+    eng.close()
+
+
 @pytest.mark.parametrize("family,t,h,f,e,k,n_shared", [
     ("mixtral", 1400, 256, 384, 4, 2, 0),     # 700 rows per expert: 3 token passes, F = 3 row blocks of 128
     ("deepseek", 2000, 256, 192, 8, 3, 2),    # routed 750 rows; shared expert 2000 rows x F_shared 384 (its own K and R)
