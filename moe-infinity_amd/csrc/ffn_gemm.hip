@@ -730,7 +730,11 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
   // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
   // amortise staging the weights in LDS -> the hybrid kernel (measured -15 % on that shape, sweep in profiles/)
-  static const int hyb_rows = env_int("MOEINF_GEMM_HYB_ROWS", 64);
+  // hybrid kernel (weights -> registers) up to 64 rows per expert; up to 128 when few experts are active (<= 16: big
+  // matrices, few workgroups — Mixtral at 192 / 256 / 320 tokens: down projection 213 -> 174, 227 -> 208, 232 -> 226 us; with
+  // NLLB's 128 experts at 4096 tokens the same switch costs +11 %)
+  static const int hyb_rows_env = env_int("MOEINF_GEMM_HYB_ROWS", 0);
+  const int hyb_rows = hyb_rows_env ? hyb_rows_env : ((int)grid.y <= 16 ? 128 : 64);
   static const int ring_env = env_int("MOEINF_GEMM_RING", 1);
   if constexpr (sizeof(T) == 2 && NMAT == 2) {
     // bf16 gated stage, more than hyb_rows rows per expert, long reduction: the register-ring kernel.  With a short K
