@@ -1384,6 +1384,33 @@ static void hidden_shared_stages(const moeinf_engine* g, int layer, const void* 
   sh2.in = g->d_h_sh; sh2.ld_in = g->Fs; sh2.out = g->d_y_sh; sh2.out_map = nullptr;
 }
 
+// MOEINF_STALL_TRACE=<ms>: report (stderr) every forward whose HOST side took longer than <ms>, with the time between
+// checkpoints — for hunting one-off stalls in HIP runtime calls (debugging aid, off by default)
+struct StallTrace {
+  double limit_ms;
+  int n = 0;
+  const char* name[16];
+  std::chrono::steady_clock::time_point t[16];
+  int layer, tokens;
+  StallTrace(int layer_, int tokens_) : layer(layer_), tokens(tokens_) {
+    static const double lim = getenv("MOEINF_STALL_TRACE") ? atof(getenv("MOEINF_STALL_TRACE")) : 0.0;
+    limit_ms = lim;
+    if (limit_ms > 0) mark("enter");
+  }
+  void mark(const char* what) {
+    if (limit_ms > 0 && n < 16) { name[n] = what; t[n] = std::chrono::steady_clock::now(); ++n; }
+  }
+  ~StallTrace() {
+    if (limit_ms <= 0 || n < 1) return;
+    mark("exit");
+    const double total = std::chrono::duration<double, std::milli>(t[n - 1] - t[0]).count();
+    if (total < limit_ms) return;
+    fprintf(stderr, "[moeinf stall] forward layer %d tokens %d: %.2f ms on the host:", layer, tokens, total);
+    for (int i = 1; i < n; ++i) fprintf(stderr, " %s +%.2f", name[i], std::chrono::duration<double, std::milli>(t[i] - t[i - 1]).count());
+    fprintf(stderr, "\n");
+  }
+};
+
 extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                                   void* out_dev, void* stream, uint32_t flags) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
@@ -1395,7 +1422,9 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool route_only = flags & MOEINF_FWD_ROUTE_ONLY;
   if (!route_only && g->cfg.ep_size > 1) return fail(MOEINF_ERR_STATE, "engine is expert-parallel (ep_size %d): run ROUTE_ONLY here and moeinf_ep_pack / ep_expert_ffn / ep_combine around the all-to-alls", g->cfg.ep_size);
   if (!route_only && !(flags & MOEINF_FWD_NO_COMBINE) && !out_dev) return fail(MOEINF_ERR_INVALID, "out_dev is NULL");
+  StallTrace strace(layer, tokens);
   HIPCHK(hipSetDevice(g->cfg.device_id));
+  strace.mark("set_device");
   hipStream_t st = (hipStream_t)stream;
   const int T = tokens, K = g->K, E = g->E;
 
@@ -1409,6 +1438,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     drop_stale_prefetches(g, layer);
     CHK(plan_mirror(g, layer, mp));
   }
+  strace.mark("plan_mirror");
 
   IndexArgs ia;
   make_index_args(g, T, batch_rows, mp.target, ia);
@@ -1449,6 +1479,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
+  strace.mark("router_launches");
   if (route_only) return MOEINF_OK;
   if (prof) HIPCHK(hipEventRecord(pr.ev[1], st));
 
@@ -1472,11 +1503,13 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));
+  strace.mark("dispatch_experts");
   if (want_combine && !fused) HIPCHK(launch_combine(ca, st));
   if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
   // fence: slots used by this forward may be recycled only after this point of the stream
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  strace.mark("combine_fence");
   return pump_if_pending(g);  // the host is idle until the next layer: serve the speculative queue now
 }
 
