@@ -177,10 +177,75 @@ hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_
   return hipGetLastError();
 }
 
+// Prefill-sized router GEMM on the fp64 MATRIX instruction.  gate_logits_kernel is shaped for decode (one workgroup per
+// expert and four tokens, every product converted and accumulated on the VALU): at 4 096 DeepSeek-V2-Lite tokens it is
+// 65 536 tiny workgroups and 160 us — 11 % of the layer.  Here logits[T, E] = x[T, H] . Wg[E, H]^T runs on
+// v_mfma_f64_16x16x4_f64 (same fp64 accumulation, so the routing stays independent of the summation order): a workgroup
+// owns a 16-token x 16-expert tile, its four waves split K four ways (chunks of 64, round-robin) and wave 0 adds the
+// partials in a fixed order.  No LDS staging of the operands: the sum over a 64-wide chunk of K may visit k in any order as
+// long as both operands agree, so lane (r, q) covers k = 16 q + s for the chunk's 16 MFMA steps s — 32 contiguous bytes
+// of its row per operand (bf16).
+template <typename V>
+__device__ __forceinline__ void load16(const V* p, float out[16]) { load8<V>(p, out); load8<V>(p + 8, out + 8); }
+
+template <typename XT, typename WT>
+__global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
+                                                               int T, int H, int E, int round_bf16) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[3][64][4];  // partials of waves 1..3
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int t0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+  const XT* xrow = x + (size_t)min(t0 + r, T - 1) * H + q * 16;
+  const WT* wrow = wg + (size_t)min(e0 + r, E - 1) * H + q * 16;
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+  const int NC = H >> 6;
+  for (int c = wave; c < NC; c += 4) {
+    float xf[16], wf[16];
+    load16<XT>(xrow + c * 64, xf);
+    load16<WT>(wrow + c * 64, wf);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[s2], (double)wf[s2], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[wave - 1][lane][v] = acc[v];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // D layout of the 16x16 fp64 tile: register v of lane (r, q) is row q + 4 v (token), column r (expert) — NOT the
+  // 4 q + v of the fp32 16x16 shapes (found by the golden-vector tests)
+  const int e = e0 + r;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int t = t0 + q + 4 * v;
+    if (t < T && e < E) {
+      float f = (float)(((acc[v] + red[0][lane][v]) + red[1][lane][v]) + red[2][lane][v]);
+      if (round_bf16) f = bf2f(f2bf(f));
+      logits[(size_t)t * E + e] = f;
+    }
+  }
+}
+
 hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
   constexpr int TT = 4;
   dim3 grid(a.E, (a.T + TT - 1) / TT);
   const int rb = gate_rounds_bf16(a);
+  // the fp64-matrix form from 128 (16-token x 16-expert) tiles on — below that its few workgroups lose to the decode-shaped
+  // kernel (measured: DeepSeek-V2-Lite 4096 / 512 / 128 tokens route 207 -> 75, 58 -> 47, 36 -> 39 us; NLLB 2048 tokens
+  // 195 -> 71; Mixtral, one padded tile: 4096 tokens 46 -> 30, 512 tokens 27 -> 39).  MOEINF_GATE_MFMA_TILES=0: never
+  static const int mfma_tiles = env_int("MOEINF_GATE_MFMA_TILES", 128);
+  if (mfma_tiles > 0 && (int64_t)((a.T + 15) / 16) * ((a.E + 15) / 16) >= mfma_tiles && (a.H & 63) == 0) {
+    const dim3 g16((a.T + 15) / 16, (a.E + 15) / 16);
+#define GM(XT, WT) hipLaunchKernelGGL((gate_logits_mfma_kernel<XT, WT>), g16, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
+    if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GM(uint16_t, uint16_t);
+    else if (a.x_dtype == DT_BF16) GM(uint16_t, float);
+    else if (a.gate_dtype == DT_BF16) GM(float, uint16_t);
+    else GM(float, float);
+#undef GM
+    return hipGetLastError();
+  }
 #define GL(XT, WT) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
   if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
   else if (a.x_dtype == DT_BF16) GL(uint16_t, float);
