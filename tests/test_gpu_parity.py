@@ -721,7 +721,8 @@ def test_short_last_pass_of_the_256x256_kernel(family, t):
     ("deepseek", 2000, 256, 192, 8, 3, 2),    # routed 750 rows; shared expert 2000 rows x F_shared 384 (its own K and R)
     ("nllb", 900, 256, 320, 4, 2, 0),         # plain stages with bias: 320 = 256 + 64 rows (partly filled row block), H = 256
     ("mixtral", 300, 128, 128, 1, 1, 0),      # a single expert with 300 rows: 2 passes, the second mostly empty
-], ids=["mixtral_700_rows", "deepseek_750_rows_shared", "nllb_bias_partial_row_block", "one_expert_300_rows"])
+    ("deepseek", 1100, 256, 192, 8, 3, 2),    # shared expert 1100 rows = 4 passes + a SHORT fifth (76 tokens) with its own K and R
+], ids=["mixtral_700_rows", "deepseek_750_rows_shared", "nllb_bias_partial_row_block", "one_expert_300_rows", "deepseek_shared_short_last_pass"])
 def test_compute_bound_grouped_gemm_256x256_tiles(family, t, h, f, e, k, n_shared):
     """More than 256 rows per expert: ffn_gemm_big (256 x 256 block tile, 32x32x16 MFMA, both operands through LDS).
     Per-expert rows within 1 ulp (2 for the bias epilogues) and the block inside the bar, on the decision path (exact
