@@ -607,6 +607,38 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     eng.close()
 
 
+@pytest.mark.parametrize("family,dtype,t,e", [("switch", torch.float32, 2112, 8), ("nllb", torch.float32, 1100, 32), ("nllb", torch.bfloat16, 1100, 32),
+                                               ("mixtral", torch.bfloat16, 2100, 8), ("deepseek", torch.bfloat16, 520, 64)],
+                         ids=["switch_f32", "nllb_f32", "nllb_bf16", "mixtral_bf16", "deepseek_bf16"])
+def test_prefill_router_gemm_on_the_fp64_matrix_instruction(family, dtype, t, e):
+    """>= 128 tiles of 16 tokens x 16 experts: the gate runs as gate_logits_mfma_kernel (v_mfma_f64_16x16x4_f64, K split over
+    the four waves).  Same bit-exact routing as the decode-shaped kernel gives on small batches — every input dtype pair
+    (fp32 x fp32, bf16 x bf16), ragged last token tile, expert counts that are and are not a multiple of 16."""
+    assert ((t + 15) // 16) * ((e + 15) // 16) >= 128
+    h, f = 192, 64  # 3 chunks of 64: waves 0..2 take one each, wave 3 none
+    k = {"switch": 1, "nllb": 2, "mixtral": 2, "deepseek": 6}[family]
+    gate, experts, shared = make_weights(family, h, f, e, 3300 + e, dtype, gate_std=0.5 if family in ("switch", "nllb") else 0.02)
+    kw = dict(expert_capacity=t) if family == "switch" else {}
+    eng = engine_for(family, h, f, e, k, dtype, max_tokens=t, **kw)
+    register_all(eng, experts, shared)
+    x = acts(t, h, dtype, 3301)
+    out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    if family == "switch":
+        ref = R.block_switch(x[None], gate, experts, expert_capacity=t)
+    elif family == "nllb":
+        ref = R.block_nllb(x[None], gate, experts)
+    elif family == "mixtral":
+        ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    else:
+        ref = R.block_deepseek(x[None], gate, experts, k)
+    r = eng.routing()
+    _check_dispatch_index(r, ref)  # counts / offsets / permutation: wrong logits anywhere would move tokens between experts
+    if family in ("mixtral", "deepseek"):
+        _check_routing_exact(eng, ref, k_sorted=(family == "mixtral"))
+    assert_block_close(out, ref, dtype, f"{family} {t}-token block")
+    eng.close()
+
+
 @pytest.mark.parametrize("family,t,e,k", [("mixtral", 5000, 8, 2), ("deepseek", 3000, 64, 6)], ids=["mixtral_10000_pairs", "deepseek_18000_pairs_shared"])
 def test_long_prefill_index_over_many_workgroups(family, t, e, k):
     """T*K > 2048 pairs: the dispatch index runs as count / scan / scatter over many workgroups.  Same outputs, bit for
