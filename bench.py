@@ -350,8 +350,14 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         from oracle import parity as P
 
         ncores = os.cpu_count() or 1
-        ls = list(range(min(args.cpu_sample_layers, L)))
-        ss = list(range(warmup, warmup + min(args.cpu_sample_steps, steps)))
+        # main workload on one GPU: every layer x 5 steps (a few seconds of host time at the best thread count, nothing
+        # extrapolated over layers); the other_configs legs and expert-parallel runs (where every pass regenerates the
+        # experts other ranks own) keep a 4-layer x 3-step sample so the run stays within minutes
+        full = main and not use_ep
+        n_ls = args.cpu_sample_layers if args.cpu_sample_layers > 0 else (L if full else 4)
+        n_ss = args.cpu_sample_steps if args.cpu_sample_steps > 0 else (5 if full else 3)
+        ls = list(range(min(n_ls, L)))
+        ss = list(range(warmup, warmup + min(n_ss, steps)))
 
         def oracle_layer(l, x_cpu):
             gate = gates[l].cpu()
@@ -393,7 +399,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                    "ms_per_token": round(cpu_ms_per_token, 2), "host_cores": ncores,
                    "thread_sweep_ms_per_layer": {str(k): round(v * 1e3, 2) for k, v in sweep.items()},
                    "sample": f"{len(ss)} decode steps x layers {ls[0]}..{ls[-1]} of the same workload "
-                             f"({layer_steps} MoE-layer passes, {cpu_s:.1f}s), extrapolated x{L}/{len(ls)} layers; "
+                             f"({layer_steps} MoE-layer passes, {cpu_s:.1f}s)" + ("" if len(ls) == L else f", extrapolated x{L}/{len(ls)} layers") + "; "
                              f"torch CPU ops, {best_nt} threads (best of the sweep)"
                              + (f"; rank 0 of {world} (one rank's batch, all {E} experts)" if use_ep else "")}
         if world > 1:
@@ -522,8 +528,8 @@ def main():
     ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
     ap.add_argument("--ep-transport", default="auto", choices=["auto", "torch"],
                     help="auto: RCCL called from inside the engine (one host call per layer) if its self-test passes on every rank, else torch.distributed; torch: always torch.distributed")
-    ap.add_argument("--cpu-sample-layers", type=int, default=4)
-    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="layers of the CPU baseline / parity sample (0: all for the main workload, 4 for other_configs)")
+    ap.add_argument("--cpu-sample-steps", type=int, default=0, help="decode steps of that sample (0: 5 for the main workload, 3 for other_configs)")
     ap.add_argument("--miss-heavy-frac", type=float, default=0.5, help="miss_heavy leg: cache budget as a fraction of the expert bytes (0 = skip)")
     ap.add_argument("--miss-heavy-steps", type=int, default=6)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
