@@ -142,8 +142,8 @@ def test_errors_are_openai_error_objects(client):
 def test_concurrent_requests_are_decoded_together_and_each_gets_its_own_answer():
     """The reference serves requests one at a time (a one-element queue around generate).  Here requests that wait together
     and share sampling parameters run as one batch; a request with different parameters is not merged into it."""
-    model = EchoModel(delay=0.05)
-    app = create_app(model, CharTokenizer(), "toy-moe", max_batch=8, window_ms=100.0)
+    model = EchoModel(delay=0.2)  # requests that arrive while a batch is generating wait together for the next one
+    app = create_app(model, CharTokenizer(), "toy-moe", max_batch=8, window_ms=300.0)
     prompts = ["a", "bcd", "efghij", "kl", "mnopqrstu", "v"]
     with fastapi_testclient.TestClient(app) as c:
         def ask(p, n=5, t=0):
