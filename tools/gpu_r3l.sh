@@ -1,5 +1,7 @@
 #!/bin/bash
-# ablation timings of ffn_gemm_big (MOEINF_GEMM_BIG_ABL: 1 no MFMA, 2 no DMA, 3 no LDS reads, 4 MFMA + barrier only, 5 DMA + barrier only)
+# ablation timings of ffn_gemm_big (MOEINF_GEMM_BIG_ABL: 1 no MFMA, 2 no DMA, 3 no LDS reads, 4 MFMA + barrier only, 5 DMA + barrier only).
+# The ablation template variants lived in the tree only while this was measured (profiles/r03_ffn_gemm_big_ablation.txt);
+# at HEAD the knob does nothing — kept as the record of how the numbers were taken.
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-r3l}; mkdir -p "$OUT"
