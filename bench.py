@@ -188,9 +188,45 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
     batch_rows = B if family == "switch" else 1
 
     ep = None
+    ep_notes = []
     if use_ep:
-        ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, native=None if args.ep_transport == "auto" else False)
-        log(f"expert-parallel transport: {'native, ' if ep.native else 'torch.distributed; native: '}{ep.native_note}")
+        # Transport of the decode-sized exchange, best first: the direct peer-store exchange (no collective), RCCL called from
+        # inside the engine, torch.distributed.  A candidate must (1) pass its own bootstrap + self-test on EVERY rank
+        # (ExpertParallelMoE all-reduces every step) and (2) PROBATION: reproduce, bit for bit, what the torch.distributed
+        # transport returns for the same layers on every rank (same kernels, only the way the rows travel differs) — a
+        # transport that has never met this machine's fabric is not trusted on its self-test alone.  The oracle-checked
+        # `parity` leg below then runs over the transport that was chosen.
+        order = {"auto": ["peer-store", "rccl", "torch"], "peer-store": ["peer-store", "torch"], "rccl": ["rccl", "torch"], "torch": ["torch"]}[args.ep_transport]
+        ep_plain = None
+        for cand in order:
+            ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport=cand)
+            if ep.transport != cand:
+                ep_notes.append(f"{cand}: not available ({ep.native_note})")
+                continue
+            if cand == "torch":
+                break
+            if ep_plain is None:
+                ep_plain = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport="torch")
+            same = True
+            try:
+                for _ in range(2):  # the first pass takes the decision path, the second the sync-free one
+                    for l in range(min(2, L)):
+                        ep.forward(l, xs[0][l], gates[l], out=out)
+                        got = out.clone()
+                        ep_plain.forward(l, xs[0][l], gates[l], out=out)
+                        same &= bool(torch.equal(got, out))
+                eng.sync()  # raises if a kernel of the exchange gave up waiting
+            except Exception as ex:  # noqa: BLE001
+                same = False
+                ep_notes.append(f"{cand}: {ex}")
+            v = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            if bool(v.item()):
+                ep_notes.append(f"{cand}: self-test passed and probation passed on every rank (bit-identical to the torch.distributed transport)")
+                break
+            ep_notes.append(f"{cand}: FAILED probation (outputs differ from the torch.distributed transport on some rank)")
+        log("expert-parallel transport: " + ep.transport + " | " + " | ".join(ep_notes))
 
         def layer_fwd(l, x):
             ep.forward(l, x, gates[l], out=out)
@@ -350,24 +386,30 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         from oracle import parity as P
 
         ncores = os.cpu_count() or 1
-        # main workload on one GPU: every layer x 5 steps (a few seconds of host time at the best thread count, nothing
-        # extrapolated over layers); the other_configs legs and expert-parallel runs (where every pass regenerates the
-        # experts other ranks own) keep a 4-layer x 3-step sample so the run stays within minutes
-        full = main and not use_ep
+        # one GPU: every layer x 5 steps for the main workload, every layer x 3 steps for the other_configs legs (a few
+        # seconds of host time each at the best thread count, nothing extrapolated over layers); expert-parallel runs
+        # (where every pass regenerates the experts other ranks own) keep a 4-layer x 3-step sample
+        full = not use_ep  # (round 4: the other_configs legs check EVERY layer too — DeepSeek-V2-Lite 78 pairs, NLLB / Switch 36)
         n_ls = args.cpu_sample_layers if args.cpu_sample_layers > 0 else (L if full else 4)
-        n_ss = args.cpu_sample_steps if args.cpu_sample_steps > 0 else (5 if full else 3)
+        n_ss = args.cpu_sample_steps if args.cpu_sample_steps > 0 else (5 if (full and main) else 3)
         ls = list(range(min(n_ls, L)))
         ss = list(range(warmup, warmup + min(n_ss, steps)))
 
-        def oracle_layer(l, x_cpu):
-            gate = gates[l].cpu()
+        def layer_weights(l):
             experts = [host_expert_tensors(eng, cfg, l, e, owned=(e % world == rank), dev=dev) for e in range(E)]
-            if family == "mixtral":
-                return R.block_mixtral(x_cpu[None], gate, experts, top_k=K)
+            shared = None
             if family == "deepseek":
                 Fs, Hh = cfg.shared_inter, cfg.hidden
                 sp = shared_host[l]
                 shared = [sp[0].view(Fs, Hh), sp[1].view(Fs, Hh), sp[2].view(Hh, Fs)]
+            return experts, shared
+
+        def oracle_layer(l, x_cpu):
+            gate = gates[l].cpu()
+            experts, shared = layer_weights(l)
+            if family == "mixtral":
+                return R.block_mixtral(x_cpu[None], gate, experts, top_k=K)
+            if family == "deepseek":
                 return R.block_deepseek(x_cpu[None], gate, experts, K, shared=shared, norm_topk_prob=bool(cfg.norm_topk_prob),
                                         routed_scaling_factor=cfg.routed_scaling_factor)
             if family == "switch":
@@ -411,6 +453,8 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                         refs[(s, l)] = oracle_layer(l, xs[s][l].cpu())
         # parity of the full-size GPU path on the sampled (step, layer) pairs: the tests' own bars, asserted
         worst, exact, amb, ok, max_abs, max_rel, mean_rel = 0.0, True, 0, True, 0.0, 0.0, 0.0
+        acc_gpu, acc_ref, acc_scale, acc_ok, acc_worst = 0.0, 0.0, 0.0, True, 0.0
+        torch.set_num_threads(max(1, min(64, ncores // max(1, world))))
         for (s, l) in sorted(refs):
             ref = refs[(s, l)]
             layer_fwd(l, xs[s][l])  # the product path: local forward, or route/pack -> all-to-all -> FFN -> all-to-all -> combine
@@ -432,13 +476,26 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             mean_rel = max(mean_rel, rep["mean_rel"])
             amb += rep["passthrough_ambiguous"]
             ok &= rep["ok"]
+            # the fp32-exact arm (oracle/parity.py): the same pair once more in fp32 (fp64 for an fp32 model) with the oracle's
+            # routing; the GPU must be as close to it as the oracle in the model dtype is — per pair AND over the sample
+            ew, es_ = layer_weights(l)
+            ar = P.accuracy_report(o, ref, P.exact_block(family, xs[s][l].cpu()[None], ref, ew, shared=es_), dt)
+            acc_gpu += ar["gpu_vs_exact"]; acc_ref += ar["oracle_vs_exact"]; acc_scale += ar["oracle_vs_exact"] / max(ar["oracle_vs_exact_rel"], 1e-30)
+            acc_ok &= ar["ok"]
+            acc_worst = max(acc_worst, ar["ratio"])
         ranks_ok = 1
+        n_pairs = max(1, len(refs))
+        acc_ratio = acc_gpu / (acc_ref + 1e-30)
         if world > 1:  # one verdict for the job: every rank must be inside the bar
-            v = torch.tensor([1.0 if (ok and exact) else 0.0, -worst, -max_abs, -max_rel, -mean_rel], dtype=torch.float64, device=dev)
+            v = torch.tensor([1.0 if (ok and exact and acc_ok) else 0.0, -worst, -max_abs, -max_rel, -mean_rel, -acc_worst, -acc_ratio], dtype=torch.float64, device=dev)
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             ranks_ok = int(v[0].item())
-            worst, max_abs, max_rel, mean_rel = -v[1].item(), -v[2].item(), -v[3].item(), -v[4].item()
-        parity = {"ok": bool(ok and exact and ranks_ok), "routing_bit_exact": bool(exact), "worst_err_over_bar": round(worst, 3),
+            worst, max_abs, max_rel, mean_rel, acc_worst, acc_ratio = -v[1].item(), -v[2].item(), -v[3].item(), -v[4].item(), -v[5].item(), -v[6].item()
+        parity = {"ok": bool(ok and exact and acc_ok and ranks_ok), "routing_bit_exact": bool(exact), "worst_err_over_bar": round(worst, 3),
+                  "fp32_exact_arm": {"ok": bool(acc_ok), "mean_abs_gpu_vs_exact": float(f"{acc_gpu / n_pairs:.4e}"), "mean_abs_oracle_vs_exact": float(f"{acc_ref / n_pairs:.4e}"),
+                                     "ratio_over_the_sample": round(acc_ratio, 4), "worst_pair_ratio": round(acc_worst, 4), "bar": "every pair: mean|gpu - exact| <= 1.15 * mean|oracle - exact|",
+                                     "oracle_vs_exact_rel": float(f"{acc_ref / max(acc_scale, 1e-30):.3e}"),
+                                     "exact": "the block in fp32 (fp64 for an fp32 model) on up-cast weights with the oracle's routing: nothing rounded to the model dtype after the router"},
                   "max_abs_err": float(f"{max_abs:.3e}"), "max_rel_err": float(f"{max_rel:.3e}"), "mean_rel_err": float(f"{mean_rel:.3e}"),
                   "tolerance": ("routing indices bit-exact; block output per element |err| <= ulp*(2*sum_k|w_k*y_k| + max(|ref|, mean|ref|)), "
                                 f"ulp = {'2^-7 (bf16)' if dt == torch.bfloat16 else '2e-5 (fp32)'}, AND mean relative error <= 1e-3 (north_star's 1e-3); "
@@ -500,8 +557,12 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
            "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
            "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
            "warm": warm, "st": st, "ep_phases": ep_phases,
-           "ep_transport": None if ep is None else ("RCCL called from inside the engine, one host call per layer (moeinf_ep_moe_forward)" if ep.native
-                                                    else f"torch.distributed all_to_all_single, five host calls per layer (native: {ep.native_note})")}
+           "ep_transport": None if ep is None else {
+               "chosen": ep.transport,
+               "what": {"peer-store": "rows stored straight into the owners' / home ranks' windows by the router and FFN kernels, flag words instead of a collective; one host call per layer (moeinf_ep_moe_forward)",
+                        "rccl": "RCCL send/recv group called from inside the engine; one host call per layer (moeinf_ep_moe_forward)",
+                        "torch": "torch.distributed all_to_all_single, five host calls per layer"}[ep.transport],
+               "candidates": ep_notes}}
     eng.close()
     return res
 
@@ -526,9 +587,10 @@ def main():
     ap.add_argument("--prompt", type=int, default=512, help="prefill length run once before decoding (examples/interface_example.py protocol); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the cpu_baseline AND parity legs")
     ap.add_argument("--force-ep", action="store_true", help="exercise the expert-parallel path even with one rank (testing)")
-    ap.add_argument("--ep-transport", default="auto", choices=["auto", "torch"],
-                    help="auto: RCCL called from inside the engine (one host call per layer) if its self-test passes on every rank, else torch.distributed; torch: always torch.distributed")
-    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="layers of the CPU baseline / parity sample (0: all for the main workload, 4 for other_configs)")
+    ap.add_argument("--ep-transport", default="auto", choices=["auto", "peer-store", "rccl", "torch"],
+                    help="auto: the first of peer-store (direct stores into the peers' windows, no collective), rccl (called from inside the engine), "
+                         "torch (all_to_all_single) that passes its self-test AND reproduces the torch transport bit for bit on every rank")
+    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="layers of the CPU baseline / parity sample (0: all on one GPU; 4 in expert-parallel runs)")
     ap.add_argument("--cpu-sample-steps", type=int, default=0, help="decode steps of that sample (0: 5 for the main workload, 3 for other_configs)")
     ap.add_argument("--miss-heavy-frac", type=float, default=0.5, help="miss_heavy leg: cache budget as a fraction of the expert bytes (0 = skip)")
     ap.add_argument("--miss-heavy-steps", type=int, default=6)

@@ -222,6 +222,9 @@ int moeinf_get_routing(moeinf_engine* eng, int32_t* topk_idx, float* topk_w, int
  * what wait_expert() returns as a list of tensors (core/parallel/expert_dispatcher.cpp:436-450). */
 int moeinf_get_expert_outputs(moeinf_engine* eng, void* host_out, int64_t nbytes);
 /* router logits [tokens, E] fp32 of the last forward (Mixtral: bf16-rounded values) */
+/* wait for the stream of the last forward and report the kernels' error flag (MOEINF_ERR_STATE: an FFN workgroup found no
+ * resident blob for an active expert, or a kernel of the peer-store exchange gave up waiting for another rank) */
+int moeinf_sync(moeinf_engine* eng);
 int moeinf_get_logits(moeinf_engine* eng, float* host_out, int64_t n_floats);
 
 /* ---- prefetch / cache control --------------------------------------------------------------
@@ -442,11 +445,44 @@ int moeinf_ep_combine(moeinf_engine* eng, const void* x_dev, const void* ret_dev
  * it copies rows between GPUs from one process (core/parallel/expert_dispatcher.cpp:284,405). */
 int moeinf_ep_comm_available(int32_t* available); /* 1 if librccl could be bound in this process (no communicator is made) */
 int moeinf_ep_comm_unique_id(void* id_out, int nbytes /* 128 */);
-int moeinf_ep_comm_init(moeinf_engine* eng, const void* unique_id, int nbytes, int cap_tokens);
+/* the LOCAL half of the bootstrap (validation, library binding, exchange buffers; no collective inside): call it on every
+ * rank and agree on the outcome before any rank enters moeinf_ep_comm_init, so that a rank that fails here leaves nobody
+ * blocked in ncclCommInitRank.  moeinf_ep_comm_init runs it itself when it was not called. */
+int moeinf_ep_comm_prepare(moeinf_engine* eng, int cap_tokens);
+int moeinf_ep_comm_init(moeinf_engine* eng, const void* unique_id, int nbytes, int cap_tokens); /* collective */
 /* equal-split all-to-all of device buffers on `stream`: segment p (bytes_per_peer bytes) of send_dev goes to rank p */
 int moeinf_ep_all_to_all(moeinf_engine* eng, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
-/* moeinf_moe_forward for an expert-parallel engine: moeinf_ep_route_pack -> all-to-all -> moeinf_ep_expert_ffn ->
- * all-to-all -> moeinf_ep_combine, all enqueued on `stream` from this one call (tokens <= cap_tokens). */
+/* ---- direct peer-store exchange: expert parallelism with NO collective ----------------------------------------------
+ * Replaces the reference's peer-access set-up (cudaDeviceEnablePeerAccess for every device pair,
+ * core/prefetch/archer_prefetch_handle.cpp:37-61) and its implicit P2P row copies `tensor.to(device)`
+ * (core/parallel/expert_dispatcher.cpp:284,405).  Every rank owns one exchange window in uncached device memory; the other
+ * ranks map it (hipIpcOpenMemHandle between processes, the plain pointer inside one process).  The router's pack step and the
+ * owner's FFN stage 2 store rows STRAIGHT into the destination rank's window over xGMI and publish an exchange number in its
+ * flag words; the consumer kernels poll their own flags (bounded: MOEINF_EP_PEER_TIMEOUT_MS, default 10 000; on expiry the
+ * device error flag reads 2 at the next sync point).  Unlike RCCL it also runs between processes that SHARE a GPU.
+ * Bootstrap — every call is local and fails without blocking anyone; agree on the outcome between the steps:
+ *   1. every rank: moeinf_ep_peer_export(eng, cap_tokens, blob)        allocates the window, writes a 192-byte blob
+ *   2. exchange the blobs over any channel (torch.distributed all_gather, a file, MPI), concatenate them in rank order
+ *   3. every rank: moeinf_ep_peer_attach(eng, blobs, ep_size * 192)    maps the peers, enables peer access
+ *   4. every rank: moeinf_ep_peer_selftest(eng, stream, &ok)           tagged rows + flags both ways; ok = 0 on timeout
+ * After step 3 moeinf_ep_moe_forward takes this transport.  Ranks must stop together: a peer may store into a window until
+ * its owner's moeinf_destroy.  cap_tokens as for moeinf_ep_comm_init, the same on every rank. */
+#define MOEINF_EP_PEER_BLOB_BYTES 192
+int moeinf_ep_peer_export(moeinf_engine* eng, int cap_tokens, void* blob_out, int nbytes /* 192 */);
+int moeinf_ep_peer_attach(moeinf_engine* eng, const void* blobs, int nbytes /* ep_size * 192 */);
+int moeinf_ep_peer_selftest(moeinf_engine* eng, void* stream, int32_t* ok);
+/* out[0] = transport moeinf_ep_moe_forward will take (MOEINF_EP_TRANSPORT_*); out[1] = 1 if another rank shares this GPU
+ * (then a one-wave wait kernel runs in front of the consumers instead of polls inside them); out[2] = 1: polls inside the
+ * consumer kernels; out[3] = exchanges so far */
+#define MOEINF_EP_TRANSPORT_NONE 0
+#define MOEINF_EP_TRANSPORT_RCCL 1
+#define MOEINF_EP_TRANSPORT_PEER_STORE 2
+int moeinf_ep_transport(const moeinf_engine* eng, int32_t out[4]);
+/* with both transports set up on one engine: which one moeinf_ep_moe_forward takes (default: the one set up last) */
+int moeinf_ep_select_transport(moeinf_engine* eng, int kind);
+/* moeinf_moe_forward for an expert-parallel engine, one host call per layer, everything enqueued on `stream`
+ * (tokens <= cap_tokens).  Peer-store transport: router + pack into the peers' windows -> owner FFN -> combine (five
+ * launches).  RCCL transport: moeinf_ep_route_pack -> all-to-all -> moeinf_ep_expert_ffn -> all-to-all -> moeinf_ep_combine. */
 int moeinf_ep_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                           void* out_dev, void* stream);
 /* per-phase HIP-event times of moeinf_ep_moe_forward calls made while moeinf_set_profiling was on (synchronises, resets) */

@@ -143,6 +143,7 @@ PROTOTYPES = {
     "moeinf_pq_pop": (C.c_int, [_P, _I64P, _I32P, _I32P, _I32P]),
     "moeinf_pq_snapshot": (C.c_int, [_P, _I64P, _I32P, _I32P, C.c_int, _I32P]),
     "moeinf_priority_from_score": (C.c_int, [C.c_float, _I32P]),
+    "moeinf_sync": (C.c_int, [_P]),
     "moeinf_ep_row_elems": (C.c_int, [_P, _I32P]),
     "moeinf_ep_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "moeinf_ep_expert_ffn": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P]),
@@ -153,7 +154,13 @@ PROTOTYPES = {
     "moeinf_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "moeinf_ep_comm_available": (C.c_int, [_I32P]),
     "moeinf_ep_comm_unique_id": (C.c_int, [_P, C.c_int]),
+    "moeinf_ep_comm_prepare": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "moeinf_ep_peer_export": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "moeinf_ep_peer_attach": (C.c_int, [_P, _P, C.c_int]),
+    "moeinf_ep_peer_selftest": (C.c_int, [_P, _P, _I32P]),
+    "moeinf_ep_transport": (C.c_int, [_P, _I32P]),
+    "moeinf_ep_select_transport": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_all_to_all": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "moeinf_ep_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
     "moeinf_ep_get_profile": (C.c_int, [_P, C.POINTER(EpProfile)]),

@@ -26,6 +26,7 @@
 #include <mutex>
 #include "aio_pool.h"
 #include "ep_comm.h"
+#include "ep_peer.h"
 #include "offload_store.h"
 #include "prefetch_queue.h"
 #include "tracer.h"
@@ -267,6 +268,14 @@ struct moeinf_engine {
   RcclComm ep_comm = nullptr;
   int ep_cap_tokens = 0, ep_x_cap_rows = 0;
   void *ep_x_send = nullptr, *ep_x_recv = nullptr, *ep_x_y = nullptr, *ep_x_ret = nullptr;
+  // ... or the direct peer-store exchange (moeinf_ep_peer_export / _attach, ep_peer.h): no collective at all
+  EpPeerWindow ep_win;
+  int ep_win_cap_tokens = 0;
+  bool ep_use_peer = false;        // moeinf_ep_moe_forward takes this transport (moeinf_ep_select_transport)
+  std::vector<int32_t> ep_peer_pids;
+  std::vector<uint64_t> ep_peer_ptrs;
+  bool ep_peer_poll = true;        // consumer kernels poll their flags themselves (false: a one-wave wait kernel in front)
+  int64_t ep_peer_timeout_ticks = 0;
   struct EpProfRec { hipEvent_t ev[6]; };
   std::vector<EpProfRec> ep_prof_pending;
   moeinf_ep_profile ep_prof;
@@ -405,6 +414,11 @@ static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
   return MOEINF_OK;
 }
 
+static int sync_last(moeinf_engine* g);
+// wait for the stream of the last forward and report the kernels' error flag (no resident blob for an active expert; a
+// peer-store exchange that gave up waiting for another rank)
+extern "C" int moeinf_sync(moeinf_engine* g) { return sync_last(g); }
+
 extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
   hipSetDevice(g->cfg.device_id);
@@ -413,6 +427,8 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   g->aio.reset();
   if (g->ep_comm) { std::string e; if (const RcclApi* api = RcclApi::get(&e)) api->CommDestroy(g->ep_comm); g->ep_comm = nullptr; }
   for (void* b : {g->ep_x_send, g->ep_x_recv, g->ep_x_y, g->ep_x_ret}) if (b) hipFree(b);
+  g->ep_x_y = nullptr;
+  g->ep_win.destroy();  // (the caller's ranks have agreed to stop before any of them gets here: a peer may still store into the window)
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
   for (auto p : g->arena_chunks) hipHostFree(p);
@@ -1634,6 +1650,7 @@ static int check_device_flag(moeinf_engine* g) {
   HIPCHK(hipMemcpy(&f, g->d_miss, sizeof f, hipMemcpyDeviceToHost));
   if (f == 0) return MOEINF_OK;
   HIPCHK(hipMemset(g->d_miss, 0, sizeof f));
+  if (f == 2) return fail(MOEINF_ERR_STATE, "device error flag 2: a kernel of the peer-store exchange gave up waiting for another rank's rows (MOEINF_EP_PEER_TIMEOUT_MS), results of the last forwards are invalid");
   return fail(MOEINF_ERR_STATE, "device error flag %d: an FFN workgroup found no resident blob for an active expert, results of the last forwards are invalid", f);
 }
 
@@ -2320,7 +2337,8 @@ static int ep_min_cap(const moeinf_engine* g, int T) {
   const int per_rank = (g->E + g->cfg.ep_size - 1) / g->cfg.ep_size;
   return T * std::min(g->K, per_rank);
 }
-static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st);
+static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st, const EpPeers* pv = nullptr);
+static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream);
 
 extern "C" int moeinf_ep_row_elems(const moeinf_engine* g, int32_t* elems) {
   if (!g || !elems) return fail(MOEINF_ERR_INVALID, "NULL argument");
@@ -2337,14 +2355,14 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   CHK(ep_alloc(g, cap_rows));
   return ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st);
 }
-static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st) {
+static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st, const EpPeers* pv) {
   const int np = g->last_T * g->K, ep = g->cfg.ep_size;
   if (np <= 64) {  // decode: one launch
     EpPackArgs pa;
     memset(&pa, 0, sizeof pa);
     pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
     pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
-    HIPCHK(launch_ep_pack_small(pa, g->d_pair_valid, np, send_counts_dev, st));
+    HIPCHK(launch_ep_pack_small(pa, g->d_pair_valid, np, send_counts_dev, st, pv));
     return MOEINF_OK;
   }
   HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
@@ -2359,7 +2377,7 @@ static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, in
   pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
   pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
   pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
-  HIPCHK(launch_ep_pack(pa, st));
+  HIPCHK(launch_ep_pack(pa, st, pv));
   if (send_counts_dev) HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
   return MOEINF_OK;
 }
@@ -2367,9 +2385,17 @@ static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, in
 // Sender side of the fixed-capacity exchange in ONE call: gate (+ stage 1 of a hidden DeepSeek shared expert) -> top-k +
 // dispatch index (+ its stage 2) -> send rows.  For decode-sized forwards the send rows are written by the
 // single-workgroup router launch itself (EpFuse): two launches per layer before the all-to-all.
+static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                              void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream, const EpPeers* pv);
 extern "C" int moeinf_ep_route_pack(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                                     void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
-  if (!g || !x_dev || !gate_w_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (!g || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  return ep_route_pack_impl(g, layer, x_dev, tokens, batch_rows, gate_w_dev, send_dev, send_counts_dev, cap_rows, stream, nullptr);
+}
+// pv != nullptr: the peer-store exchange — the rows go straight into the destination ranks' windows (send_dev unused)
+static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
+                              void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream, const EpPeers* pv) {
+  if (!g || !x_dev || !gate_w_dev || (!send_dev && !pv)) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
   if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
   if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
@@ -2395,6 +2421,7 @@ extern "C" int moeinf_ep_route_pack(moeinf_engine* g, int layer, const void* x_d
   pk.a.x = x_dev; pk.a.send = send_dev; pk.a.ld_send = ep_row_elems(g); pk.a.pair_pos = g->d_ep_pair_pos; pk.a.topk_idx = g->d_topk_idx;
   pk.a.K = K; pk.a.H = g->H; pk.a.ep_size = g->cfg.ep_size; pk.a.cap_rows = cap_rows; pk.a.dtype = g->dt;
   pk.pair_valid = g->d_pair_valid; pk.send_counts = send_counts_dev; pk.on = 1;
+  if (pv) pk.peers = *pv;
   if (hide_shared) {
     FfnStage sh1, sh2;
     hidden_shared_stages(g, layer, x_dev, sh1, sh2);
@@ -2411,7 +2438,7 @@ extern "C" int moeinf_ep_route_pack(moeinf_engine* g, int layer, const void* x_d
   }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
-  if (!fuse) CHK(ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st));
+  if (!fuse) CHK(ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st, pv));
   return MOEINF_OK;
 }
 
@@ -2440,7 +2467,7 @@ extern "C" int moeinf_ep_pack_compact(moeinf_engine* g, const void* x_dev, void*
   return MOEINF_OK;
 }
 
-static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st);
+static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st, const EpPeers* pv = nullptr);
 
 extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream) {
   if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
@@ -2453,7 +2480,10 @@ extern "C" int moeinf_ep_expert_ffn_rows(moeinf_engine* g, int layer, const void
   if (nrows == 0) return MOEINF_OK;  // nothing was routed to this rank
   return ep_expert_ffn_rows(g, layer, recv_dev, y_dev, nrows, (hipStream_t)stream);
 }
-static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st) {
+// pv != nullptr (peer-store exchange): recv_dev is this rank's window; the self-indexing kernels poll the row flags and
+// store their outputs into the home ranks' windows themselves, the generic path gets a wait kernel in front and a push
+// kernel behind (y_dev = a local staging buffer there)
+static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st, const EpPeers* pv) {
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   HIPCHK(hipSetDevice(g->cfg.device_id));
   const int E = g->E;
@@ -2491,6 +2521,13 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
     memset(&o, 0, sizeof o);
     o.recv = recv_dev; o.ld_recv = ld; o.H = g->H; o.nrows = nrows; o.ep_size = g->cfg.ep_size; o.ep_rank = g->cfg.ep_rank;
     o.max_active = std::min(owned, nrows);
+    if (pv) {
+      o.peers = *pv;
+      if (!pv->poll) {  // ranks sharing a GPU: one wave waits, the wide kernel starts when the rows are there
+        EpWait w{g->ep_win.recv_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
+        HIPCHK(launch_ep_wait(w, st));
+      }
+    }
     moeinf_engine::ProfRec pr;
     const bool prof = g->profiling;
     if (prof) {
@@ -2509,6 +2546,10 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
     return pump_if_pending(g);
   }
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
+  if (pv) {  // the generic kernels know nothing of the exchange: wait in front of them ...
+    EpWait w{g->ep_win.recv_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
+    HIPCHK(launch_ep_wait(w, st));
+  }
   CHK(launch_index_auto(g, ia, st));
   // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
   // row), so the reply needs no un-sort pass
@@ -2524,6 +2565,7 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
                                   (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, prof, prof ? &pr : nullptr, mp, nullptr, nullptr);
   g->ovr_out = nullptr; g->ovr_map = nullptr;
   if (rc != MOEINF_OK) return rc;
+  if (pv) HIPCHK(launch_ep_push(y_dev, recv_dev, ld, g->H, g->dt, *pv, st));  // ... and send their outputs home behind them
   if (prof) { hipEventRecord(pr.ev[5], st); g->prof_pending.push_back(pr); }
   g->st.forwards += 1;
   g->seq += 1;
@@ -2531,7 +2573,11 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
   return pump_if_pending(g);
 }
 
+static int ep_combine_impl(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream, const EpPeers* pv);
 extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream) {
+  return ep_combine_impl(g, x_dev, ret_dev, out_dev, cap_rows, stream, nullptr);
+}
+static int ep_combine_impl(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream, const EpPeers* pv) {
   if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows (0 after ep_pack_compact)");
   HIPCHK(hipSetDevice(g->cfg.device_id));
@@ -2561,6 +2607,11 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
   ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
   ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? (g->last_hidden_shared ? g->d_y_sh : g->d_y) : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
   ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
+  if (pv) {  // the owners' outputs of exchange `epoch` must have landed in this rank's return region
+    EpWait w{g->ep_win.ret_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
+    if (pv->poll) { HIPCHK(launch_combine(ca, st, &w)); return MOEINF_OK; }
+    HIPCHK(launch_ep_wait(w, st));
+  }
   HIPCHK(launch_combine(ca, st));
   return MOEINF_OK;
 }
@@ -2586,29 +2637,52 @@ extern "C" int moeinf_ep_comm_unique_id(void* id_out, int nbytes) {
   return MOEINF_OK;
 }
 
-extern "C" int moeinf_ep_comm_init(moeinf_engine* g, const void* unique_id, int nbytes, int cap_tokens) {
-  if (!g || !unique_id || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "unique_id must be %d bytes", (int)sizeof(RcclUniqueId));
+static void ep_comm_free_buffers(moeinf_engine* g) {
+  void** bufs[] = {&g->ep_x_send, &g->ep_x_recv, &g->ep_x_ret};
+  for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+  if (g->ep_x_y && !g->ep_win.base) { (void)hipFree(g->ep_x_y); g->ep_x_y = nullptr; }  // (shared with the peer-store transport)
+  g->ep_cap_tokens = 0; g->ep_x_cap_rows = 0;
+}
+// Everything of the RCCL bootstrap that can fail on ONE rank, with no collective inside (round-3 advice: a rank that failed
+// here used to return while the others blocked in ncclCommInitRank): validation, library binding, exchange buffers.  The
+// host layer agrees on the outcome of this step before any rank enters moeinf_ep_comm_init.
+extern "C" int moeinf_ep_comm_prepare(moeinf_engine* g, int cap_tokens) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (cap_tokens <= 0 || cap_tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "cap_tokens %d not in 1..max_tokens(%d)", cap_tokens, g->cfg.max_tokens);
   if (g->ep_comm) return fail(MOEINF_ERR_STATE, "the engine already has a communicator");
   std::string err;
-  const RcclApi* api = RcclApi::get(&err);
-  if (!api) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
+  if (!RcclApi::get(&err)) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
   HIPCHK(hipSetDevice(g->cfg.device_id));
   // exchange buffers: cap_rows row slots per peer, both directions (send/recv rows carry the 16-byte id tail)
   const int cap_rows = ep_min_cap(g, cap_tokens);
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
   if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
-  HIPCHK(hipMalloc(&g->ep_x_send, n * ep_row_elems(g) * g->es));
-  HIPCHK(hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es));
-  HIPCHK(hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es));
-  HIPCHK(hipMalloc(&g->ep_x_ret, n * (size_t)g->H * g->es));
-  HIPCHK(hipMemset(g->ep_x_y, 0, n * (size_t)g->H * g->es));  // padding rows travel as they are: keep them defined
+  if (g->ep_x_cap_rows == cap_rows && g->ep_x_send) return MOEINF_OK;  // prepared already
+  ep_comm_free_buffers(g);
+  hipError_t e = hipMalloc(&g->ep_x_send, n * ep_row_elems(g) * g->es);
+  if (e == hipSuccess) e = hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es);
+  if (e == hipSuccess && !g->ep_x_y) e = hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es);
+  if (e == hipSuccess) e = hipMalloc(&g->ep_x_ret, n * (size_t)g->H * g->es);
+  if (e == hipSuccess) e = hipMemset(g->ep_x_y, 0, n * (size_t)g->H * g->es);  // padding rows travel as they are: keep them defined
+  if (e != hipSuccess) { ep_comm_free_buffers(g); (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "exchange buffers: %s", hipGetErrorString(e)); }
+  g->ep_cap_tokens = cap_tokens;
+  g->ep_x_cap_rows = cap_rows;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_comm_init(moeinf_engine* g, const void* unique_id, int nbytes, int cap_tokens) {
+  if (!g || !unique_id || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "unique_id must be %d bytes", (int)sizeof(RcclUniqueId));
+  CHK(moeinf_ep_comm_prepare(g, cap_tokens));  // (no-op after an explicit prepare with the same cap_tokens)
+  const RcclApi* api = RcclApi::get(nullptr);
   RcclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
   const int rc = api->CommInitRank(&g->ep_comm, g->cfg.ep_size, id, g->cfg.ep_rank);
-  if (rc) { g->ep_comm = nullptr; return fail(MOEINF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", g->cfg.ep_rank, g->cfg.ep_size, api->GetErrorString(rc)); }
-  g->ep_cap_tokens = cap_tokens;
-  g->ep_x_cap_rows = cap_rows;
+  if (rc) {
+    g->ep_comm = nullptr;
+    ep_comm_free_buffers(g);
+    return fail(MOEINF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", g->cfg.ep_rank, g->cfg.ep_size, api->GetErrorString(rc));
+  }
+  g->ep_use_peer = false;
   return MOEINF_OK;
 }
 
@@ -2621,12 +2695,146 @@ extern "C" int moeinf_ep_all_to_all(moeinf_engine* g, const void* send_dev, void
   return MOEINF_OK;
 }
 
+// ---- direct peer-store exchange (ep_peer.h) ------------------------------------------------------------------------
+// Bootstrap, every step LOCAL (a rank that fails returns an error and leaves nobody blocked in a collective; the host layer
+// agrees on the outcome between the steps): export -> [exchange the blobs] -> attach -> selftest.
+extern "C" int moeinf_ep_peer_export(moeinf_engine* g, int cap_tokens, void* blob_out, int nbytes) {
+  if (!g || !blob_out || nbytes != kEpPeerBlobBytes) return fail(MOEINF_ERR_INVALID, "blob_out must hold %d bytes", kEpPeerBlobBytes);
+  if (cap_tokens <= 0 || cap_tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "cap_tokens %d not in 1..max_tokens(%d)", cap_tokens, g->cfg.max_tokens);
+  if (g->ep_win.base) {  // a second host-side exchange object over the same engine: hand out the same window again
+    if (cap_tokens != g->ep_win_cap_tokens) return fail(MOEINF_ERR_STATE, "the engine already has an exchange window for cap_tokens %d", g->ep_win_cap_tokens);
+    EpPeerBlob b;
+    const std::string err = g->ep_win.export_blob(g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id, &b);
+    if (!err.empty()) return fail(MOEINF_ERR_HIP, "%s", err.c_str());
+    memset(blob_out, 0, kEpPeerBlobBytes);
+    memcpy(blob_out, &b, sizeof b);
+    return MOEINF_OK;
+  }
+  if (g->cfg.ep_size > EP_MAX_PEERS) return fail(MOEINF_ERR_UNSUPPORTED, "peer-store exchange: ep_size %d > %d", g->cfg.ep_size, EP_MAX_PEERS);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  const int cap_rows = ep_min_cap(g, cap_tokens);
+  const size_t n = (size_t)g->cfg.ep_size * cap_rows;
+  if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
+  std::string err = g->ep_win.create(g->cfg.ep_size, cap_rows, ep_row_elems(g) * g->es, (int64_t)g->H * g->es);
+  if (err.empty() && !g->ep_x_y) {  // staging of the owner's outputs on the generic path (more rows than the self-indexing kernels take)
+    if (hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es) != hipSuccess) { g->ep_x_y = nullptr; err = "hipMalloc of the output staging buffer failed"; }
+  }
+  EpPeerBlob b;
+  if (err.empty()) err = g->ep_win.export_blob(g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id, &b);
+  if (!err.empty()) { g->ep_win.destroy(); (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "%s", err.c_str()); }
+  memset(blob_out, 0, kEpPeerBlobBytes);
+  memcpy(blob_out, &b, sizeof b);
+  g->ep_win_cap_tokens = cap_tokens;
+  const char* t = getenv("MOEINF_EP_PEER_TIMEOUT_MS");
+  g->ep_peer_timeout_ticks = (int64_t)(t ? atoll(t) : 10000) * 100000;  // wall_clock64: 100 MHz
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_peer_attach(moeinf_engine* g, const void* blobs, int nbytes) {
+  if (!g || !blobs) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (nbytes != g->cfg.ep_size * kEpPeerBlobBytes) return fail(MOEINF_ERR_INVALID, "blobs must be ep_size * %d bytes, in rank order", kEpPeerBlobBytes);
+  if (!g->ep_win.base) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_export first");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  std::vector<EpPeerBlob> bs(g->cfg.ep_size);
+  for (int p = 0; p < g->cfg.ep_size; ++p) memcpy(&bs[p], (const char*)blobs + (size_t)p * kEpPeerBlobBytes, sizeof(EpPeerBlob));
+  if (g->ep_win.attached) {  // again (see moeinf_ep_peer_export): the same peers, or an error
+    for (int p = 0; p < g->cfg.ep_size; ++p)
+      if (bs[p].magic != kEpPeerMagic || bs[p].rank != p || bs[p].pid != g->ep_peer_pids[p] || bs[p].ptr != g->ep_peer_ptrs[p])
+        return fail(MOEINF_ERR_STATE, "the engine is attached to other peers already");
+    g->ep_use_peer = true;
+    return MOEINF_OK;
+  }
+  const std::string err = g->ep_win.attach(bs.data(), g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id);
+  if (!err.empty()) { (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "%s", err.c_str()); }
+  // ranks that share this GPU (tests on a one-GPU box) must not spin inside wide kernels — the rank they wait for needs CUs
+  // to run on; MOEINF_EP_PEER_POLL=0/1 overrides
+  g->ep_peer_poll = !g->ep_win.shared_device;
+  if (const char* e = getenv("MOEINF_EP_PEER_POLL")) g->ep_peer_poll = atoi(e) != 0;
+  g->ep_peer_pids.clear(); g->ep_peer_ptrs.clear();
+  for (auto& b : bs) { g->ep_peer_pids.push_back(b.pid); g->ep_peer_ptrs.push_back(b.ptr); }
+  g->ep_use_peer = true;
+  return MOEINF_OK;
+}
+
+// which bootstrapped transport moeinf_ep_moe_forward takes (the last one set up is the default)
+extern "C" int moeinf_ep_select_transport(moeinf_engine* g, int kind) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (kind == MOEINF_EP_TRANSPORT_PEER_STORE) { if (!g->ep_win.attached) return fail(MOEINF_ERR_STATE, "peer-store exchange is not set up"); g->ep_use_peer = true; return MOEINF_OK; }
+  if (kind == MOEINF_EP_TRANSPORT_RCCL) { if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no RCCL communicator"); g->ep_use_peer = false; return MOEINF_OK; }
+  return fail(MOEINF_ERR_INVALID, "kind must be MOEINF_EP_TRANSPORT_PEER_STORE or MOEINF_EP_TRANSPORT_RCCL");
+}
+
+static void ep_peer_view(moeinf_engine* g, EpPeers* pv) {
+  g->ep_win.view(pv, g->cfg.ep_rank, g->cfg.ep_size, g->d_miss, g->ep_peer_timeout_ticks, g->ep_peer_poll);
+}
+
+// Collective in effect (every rank must call it the same number of times), but bounded: a rank whose peers never
+// show up gets ok = 0 after the poll timeout instead of a hang.
+extern "C" int moeinf_ep_peer_selftest(moeinf_engine* g, void* stream, int32_t* ok) {
+  if (!g || !ok) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  *ok = 0;
+  if (!g->ep_win.attached) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_attach first");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  g->ep_win.epoch += 1;
+  EpPeers pv;
+  ep_peer_view(g, &pv);
+  const int words = (int)std::min<int64_t>(1024, std::min(pv.recv_row_bytes, pv.ret_row_bytes) * pv.cap_rows / 4);
+  int32_t* ok_dev = g->ep_win.done + 8;  // a spare word of the counter allocation
+  HIPCHK(hipMemsetAsync(ok_dev, 0, 4, st));
+  HIPCHK(launch_ep_selftest_send(pv, words, st));
+  HIPCHK(launch_ep_selftest_check(pv, words, ok_dev, st));
+  HIPCHK(hipMemcpyAsync(ok, ok_dev, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int32_t f = 0;
+  HIPCHK(hipMemcpy(&f, g->d_miss, 4, hipMemcpyDeviceToHost));
+  if (f) { HIPCHK(hipMemset(g->d_miss, 0, 4)); *ok = 0; }
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_transport(const moeinf_engine* g, int32_t out[4]) {
+  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  out[0] = (g->ep_win.attached && g->ep_use_peer) ? MOEINF_EP_TRANSPORT_PEER_STORE : (g->ep_comm ? MOEINF_EP_TRANSPORT_RCCL : MOEINF_EP_TRANSPORT_NONE);
+  out[1] = g->ep_win.shared_device ? 1 : 0;
+  out[2] = g->ep_peer_poll ? 1 : 0;
+  out[3] = (int32_t)g->ep_win.epoch;
+  return MOEINF_OK;
+}
+
+// One expert-parallel MoE layer over the peer-store exchange: router (+ pack into the destinations' windows) -> owner FFN
+// (polls the row flags; stage 2 stores its outputs into the home ranks' windows) -> combine (polls the output flags).
+// Five launches on `stream`, no collective, no copy.
+static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
+  if (tokens > g->ep_win_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the exchange window", tokens, g->ep_win_cap_tokens);
+  hipStream_t st = (hipStream_t)stream;
+  const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
+  moeinf_engine::EpProfRec pr;
+  const bool prof = g->ep_profiling;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(pr.ev[i], st); };
+  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
+  g->ep_win.epoch += 1;  // collective discipline: every rank runs the same sequence of exchanges
+  EpPeers pv;
+  ep_peer_view(g, &pv);
+  mark(0);
+  CHK(ep_route_pack_impl(g, layer, x_dev, tokens, batch_rows, gate_w_dev, nullptr, nullptr, cap, stream, &pv));
+  mark(1);
+  mark(2);  // (no dispatch collective: the rows are already on their way)
+  CHK(ep_expert_ffn_rows(g, layer, g->ep_win.recv_region(), g->ep_x_y, G * cap, st, &pv));
+  mark(3);
+  mark(4);
+  CHK(ep_combine_impl(g, x_dev, g->ep_win.ret_region(), out_dev, cap, stream, &pv));
+  mark(5);
+  if (prof) g->ep_prof_pending.push_back(pr);
+  return MOEINF_OK;
+}
+
 // One expert-parallel MoE layer in ONE host call (fixed-capacity form): router + send rows -> all-to-all -> owner FFN ->
 // all-to-all -> combine, every launch and both collectives enqueued on `stream` from here.
 extern "C" int moeinf_ep_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
                                      void* out_dev, void* stream) {
   if (!g || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no communicator: call moeinf_ep_comm_init first");
+  if (g->ep_win.attached && (g->ep_use_peer || !g->ep_comm)) return ep_peer_forward(g, layer, x_dev, tokens, batch_rows, gate_w_dev, out_dev, stream);
+  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no transport: call moeinf_ep_peer_export + moeinf_ep_peer_attach, or moeinf_ep_comm_init, first");
   if (tokens > g->ep_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the communicator's exchange buffers", tokens, g->ep_cap_tokens);
   hipStream_t st = (hipStream_t)stream;
   const RcclApi* api = RcclApi::get(nullptr);

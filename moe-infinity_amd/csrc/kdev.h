@@ -57,6 +57,58 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
 __device__ __forceinline__ void st16_coherent(void* p, u32x4_ v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// ---- peer-store exchange (kernels.h: EpPeers): rows and flags written into ANOTHER rank's window -------------------
+// System scope = sc0 sc1: the store is written through every cache level of the writer and acknowledged by the memory it
+// lands in (this device's or, over xGMI, a peer's), so "drain (s_waitcnt vmcnt(0)), then publish" orders payload before flag.
+__device__ __forceinline__ void st16_system(void* p, u32x4_ v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void st_system(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// row `row` = (destination rank d, position) of the sender's numbering -> its place in rank d's receive region
+__device__ __forceinline__ char* ep_peer_recv_row(const EpPeers& pv, const int row, const int64_t row_bytes) {
+  const int d = row / pv.cap_rows, pos = row - d * pv.cap_rows;
+  return reinterpret_cast<char*>(pv.base[d]) + pv.recv_off + ((int64_t)pv.rank * pv.cap_rows + pos) * row_bytes;
+}
+// arrival row `row` = (source rank p, position) on the owner -> its place in rank p's return region
+__device__ __forceinline__ char* ep_peer_ret_row(const EpPeers& pv, const int row, const int64_t row_bytes) {
+  const int p = row / pv.cap_rows, pos = row - p * pv.cap_rows;
+  return reinterpret_cast<char*>(pv.base[p]) + pv.ret_off + ((int64_t)pv.rank * pv.cap_rows + pos) * row_bytes;
+}
+// publish exchange `epoch` in flag word `rank` of every peer's flag set (flags_off = 0: rows, EP_RET_FLAGS_OFF: outputs);
+// call with ONE thread after every producer's stores were drained
+__device__ __forceinline__ void ep_publish(const EpPeers& pv, const int64_t flags_off) {
+  for (int p = 0; p < pv.size; ++p)
+    st_system(reinterpret_cast<uint32_t*>(pv.base[p] + flags_off) + pv.rank * EP_FLAG_WORDS, pv.epoch);
+}
+// many-workgroup producers: every workgroup drains its stores and arrives; the last one publishes (and re-arms the counter)
+__device__ __forceinline__ void ep_arrive_publish(const EpPeers& pv, const int expected, const int64_t flags_off) {
+  wait_stores_acked();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(pv.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == expected) {
+      __hip_atomic_store(pv.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ep_publish(pv, flags_off);
+    }
+  }
+}
+// consumer: lanes 0..n-1 of ONE wave poll flag words 0..n-1 until each has reached `epoch` (bounded by wall clock)
+__device__ __forceinline__ void ep_poll(const uint32_t* flags, const int n, const uint32_t epoch, const int64_t timeout_ticks, int32_t* err) {
+  const int lane = threadIdx.x & 63;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    uint32_t v = epoch;
+    if (lane < n) v = __hip_atomic_load(flags + lane * EP_FLAG_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__all((int32_t)(v - epoch) >= 0)) break;
+    if (wall_clock64() - t0 > timeout_ticks) {
+      if (lane == 0) atomicExch(err, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");  // later loads stay behind the poll
+}
 
 template <typename T>
 struct DT;
@@ -86,6 +138,7 @@ struct DT<uint16_t> {  // bf16 storage
     o[2] = __uint_as_float(y << 16); o[3] = __uint_as_float(y & 0xffff0000u);
   }
   __device__ static __forceinline__ void store_coherent(uint16_t* p, float f) { st_coherent(p, f2bf(f)); }
+  __device__ static __forceinline__ void store_system(uint16_t* p, float f) { st_system(p, f2bf(f)); }
   __device__ static __forceinline__ void store4(uint16_t* p, const float f[4]) {
     uint2 v;
     v.x = f2bf2(f[0], f[1]);
@@ -117,6 +170,7 @@ struct DT<float> {
     o[2] = __uint_as_float((uint32_t)r.b); o[3] = __uint_as_float((uint32_t)(r.b >> 32));
   }
   __device__ static __forceinline__ void store_coherent(float* p, float f) { st_coherent(p, f); }
+  __device__ static __forceinline__ void store_system(float* p, float f) { st_system(p, f); }
   __device__ static __forceinline__ void store4(float* p, const float f[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
   }
@@ -288,7 +342,8 @@ __device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, 
 template <typename T, int NMAT, int NW, int U, int NT>
 __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, const char* W, const bool sh, const int cnt, const int off,
                                               float (*red)[NMAT][256], const int xrow_fixed = -1,
-                                              const int* in_rows = nullptr, const int* out_rows = nullptr) {
+                                              const int* in_rows = nullptr, const int* out_rows = nullptr, const EpPeers* pvp = nullptr,
+                                              const bool to_peers = false) {
   constexpr int EPV = DT<T>::EPV;
   constexpr int EPT = 4 * EPV;  // k elements per tile (64 bytes per row)
   const int K = sh ? s.K_sh : s.K;
@@ -304,7 +359,10 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
   const char* a1 = NMAT == 2 ? W + (sh ? s.off_b_sh : s.off_b) + (size_t)bx * KB * 1024 + lane * 16 : nullptr;
   const int kq = q * EPV;  // this lane's k offset inside a tile
   // fused-combine hand-off rows as 16-byte stores: needs all 16 rows of the group inside the matrix and no in/out row lists
-  const bool wide_out = NMAT == 1 && NT == 1 && s.fuse_combine == 2 && r0 + 16 <= R && !out_rows;  // fuse_combine 1: narrow stores (A/B)
+  // (also how the peer-store exchange's owner writes its output rows into their home ranks' windows: pv != nullptr)
+  // (a pointer that is SELECTED between the kernel-argument struct and nullptr makes the compiler copy the struct to scratch:
+  // the caller always passes the address and says separately whether it is used)
+  const bool wide_out = NMAT == 1 && NT == 1 && r0 + 16 <= R && (to_peers ? true : (s.fuse_combine == 2 && !out_rows));  // fuse_combine 1: narrow stores (A/B)
 
   // NT token tiles (16 tokens each) share one pass over the weights: experts with many tokens
   // (prefill, big batches) re-stream their weights every 16*NT tokens instead of every 16
@@ -402,11 +460,15 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
             if (s.epi == EPI_RELU || s.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
           }
           const int srow = off + tile * 16 + tn;
-          T* op = reinterpret_cast<T*>(s.out) + (size_t)(out_rows ? out_rows[tile * 16 + tn] : (s.out_map ? s.out_map[srow] : srow)) * s.ld_out + orow;
-          if (NMAT == 1 && NT == 1 && s.fuse_combine) {
-            if (wide_out) red[0][0][i] = v; else DT<T>::store_coherent(op, v);  // wide: gathered below into 16-byte stores
+          const int drow = out_rows ? out_rows[tile * 16 + tn] : (s.out_map ? s.out_map[srow] : srow);
+          if (wide_out) {
+            red[0][0][i] = v;  // gathered below into 16-byte stores
+          } else if (to_peers) {
+            DT<T>::store_system(reinterpret_cast<T*>(ep_peer_ret_row(*pvp, drow, (int64_t)s.ld_out * sizeof(T))) + orow, v);
           } else {
-            DT<T>::store(op, v);
+            T* op = reinterpret_cast<T*>(s.out) + (size_t)drow * s.ld_out + orow;
+            if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v);
+            else DT<T>::store(op, v);
           }
         }
       }
@@ -423,7 +485,9 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
 #pragma unroll
               for (int j = 0; j < 4; ++j) v16[qq * 4 + j] = red[0][0][(qq * 16 + tn) * 4 + j];
             const int srow = off + tile * 16 + tn;
-            T* op = reinterpret_cast<T*>(s.out) + (size_t)(s.out_map ? s.out_map[srow] : srow) * s.ld_out + r0;
+            const int drow = out_rows ? out_rows[tile * 16 + tn] : (s.out_map ? s.out_map[srow] : srow);
+            T* op = to_peers ? reinterpret_cast<T*>(ep_peer_ret_row(*pvp, drow, (int64_t)s.ld_out * sizeof(T))) + r0
+                             : reinterpret_cast<T*>(s.out) + (size_t)drow * s.ld_out + r0;
             if constexpr (sizeof(T) == 2) {
               u32x4 w0, w1;
 #pragma unroll
@@ -431,15 +495,15 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
                 w0[j] = (uint32_t)f2bf(v16[2 * j]) | ((uint32_t)f2bf(v16[2 * j + 1]) << 16);
                 w1[j] = (uint32_t)f2bf(v16[8 + 2 * j]) | ((uint32_t)f2bf(v16[8 + 2 * j + 1]) << 16);
               }
-              st16_coherent(op, w0);
-              st16_coherent(op + 8, w1);
+              if (to_peers) { st16_system(op, w0); st16_system(op + 8, w1); }
+              else { st16_coherent(op, w0); st16_coherent(op + 8, w1); }
             } else {
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 u32x4 w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(v16[c * 4 + j]);
-                st16_coherent(op + c * 4, w);
+                if (to_peers) st16_system(op + c * 4, w); else st16_coherent(op + c * 4, w);
               }
             }
           }
@@ -1016,12 +1080,12 @@ __device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ log
 // topk_idx / pair_valid visible.  Same layout, bit for bit, as ep_pack_small_kernel (ep_kernels.hip).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void ep_pack_block(const EpPackArgs& a, const int32_t* pair_valid, const int n_pairs, int32_t* send_counts,
+__device__ __forceinline__ void ep_pack_block(const EpPackArgs& a, const EpPeers& pv, const int32_t* pair_valid, const int n_pairs, int32_t* send_counts,
                                               int* s_row /*LDS [64]*/) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nrows = a.ep_size * a.cap_rows;
-  T* send = reinterpret_cast<T*>(a.send);
-  for (int r = tid; r < nrows; r += nthr) reinterpret_cast<int32_t*>(send + (size_t)r * a.ld_send + a.H)[0] = -1;
+  const int64_t row_bytes = a.ld_send * (int64_t)sizeof(T);
+  const bool peer = pv.on != 0;  // block-uniform: rows go straight into the destination ranks' windows
   if (tid < 64) {
     const int lane = tid;
     int key = -1;
@@ -1038,21 +1102,35 @@ __device__ __forceinline__ void ep_pack_block(const EpPackArgs& a, const int32_t
     if (lane < n_pairs) a.pair_pos[lane] = row;
     s_row[lane] = row;
   }
-  __syncthreads();  // (also orders the -1 tails above before the occupied rows' tails below)
+  __syncthreads();
+  // tails: the expert id of the pair that occupies the row, -1 for an unused row (one store per tail)
+  for (int r = tid; r < nrows; r += nthr) {
+    int id = -1;
+    for (int p = 0; p < n_pairs; ++p)
+      if (s_row[p] == r) id = a.topk_idx[p];
+    char* dst = peer ? ep_peer_recv_row(pv, r, row_bytes) : reinterpret_cast<char*>(a.send) + (size_t)r * row_bytes;
+    int32_t* tail = reinterpret_cast<int32_t*>(dst + (size_t)a.H * sizeof(T));
+    if (peer) st_system(tail, (int32_t)id); else *tail = id;
+  }
   constexpr int EPV = DT<T>::EPV;
   const int cpr = a.H / EPV;  // 16-byte chunks per row
   for (int i = tid; i < n_pairs * cpr; i += nthr) {
     const int p = i / cpr, c = i - p * cpr;
     const int row = s_row[p];
     if (row < 0) continue;
-    T* dst = send + (size_t)row * a.ld_send;
-    *reinterpret_cast<u32x4*>(dst + c * EPV) = ld16(reinterpret_cast<const T*>(a.x) + (size_t)(p / a.K) * a.H + c * EPV);
-    if (c == 0) reinterpret_cast<int32_t*>(dst + a.H)[0] = a.topk_idx[p];
+    const u32x4 v = ld16(reinterpret_cast<const T*>(a.x) + (size_t)(p / a.K) * a.H + c * EPV);
+    if (peer) st16_system(ep_peer_recv_row(pv, row, row_bytes) + (size_t)c * 16, v);
+    else *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.send) + (size_t)row * row_bytes + (size_t)c * 16) = v;
+  }
+  if (peer) {  // drain this workgroup's stores, then tell every destination that exchange `epoch`'s rows from this rank are there
+    wait_stores_acked();
+    __syncthreads();
+    if (tid == 0) ep_publish(pv, 0);
   }
 }
 __device__ __forceinline__ void ep_pack_block_dt(const EpFuse& f, const int n_pairs, int* s_row) {
-  if (f.a.dtype == DT_BF16) ep_pack_block<uint16_t>(f.a, f.pair_valid, n_pairs, f.send_counts, s_row);
-  else ep_pack_block<float>(f.a, f.pair_valid, n_pairs, f.send_counts, s_row);
+  if (f.a.dtype == DT_BF16) ep_pack_block<uint16_t>(f.a, f.peers, f.pair_valid, n_pairs, f.send_counts, s_row);
+  else ep_pack_block<float>(f.a, f.peers, f.pair_valid, n_pairs, f.send_counts, s_row);
 }
 
 }  // namespace moeinf

@@ -9,6 +9,40 @@ namespace moeinf {
 enum { DT_BF16 = 0, DT_F32 = 1 };
 struct EpFuse;
 
+// ---- direct peer-store exchange (expert parallelism without a collective; host side: ep_peer.h) ------------------
+// Every rank owns one exchange WINDOW in uncached device memory, mapped into every other rank's address space
+// (hipIpc* between processes, plain pointers inside one process):
+//   [0, 2048)     recv flags: word p * 32 = the last exchange whose rows from rank p have landed in this window
+//   [2048, 4096)  ret flags:  word p * 32 = the last exchange whose expert outputs from owner p have landed
+//   recv_off      [ep_size][cap_rows] rows of H activations + 16-byte tail (segment p is written by rank p)
+//   ret_off       [ep_size][cap_rows] rows of H expert outputs            (segment p is written by owner p)
+// Producers store rows STRAIGHT into the consumer's window (system-scope write-through stores), drain them
+// (s_waitcnt vmcnt(0)), and publish the exchange number in the consumer's flag word; consumers poll their own flags.
+// One flag word per cache line; the number only grows, so nothing is ever reset.
+constexpr int EP_MAX_PEERS = 16;
+constexpr int EP_FLAG_WORDS = 32;  // 128 bytes between two flag words
+constexpr int64_t EP_RET_FLAGS_OFF = 2048, EP_WINDOW_HDR = 4096;
+struct EpPeers {
+  uint64_t base[EP_MAX_PEERS];  // window of rank p as mapped in THIS process (base[rank] = this rank's own)
+  int64_t recv_off, ret_off;    // byte offsets of the two regions (the same on every rank)
+  int64_t recv_row_bytes, ret_row_bytes;  // (H + tail) * element size, H * element size
+  int64_t timeout_ticks;        // bound of every poll, wall_clock64 ticks (100 MHz); on expiry *err = 2 and the kernel goes on
+  int32_t* done;                // arrival counter of many-workgroup producers (this device, zero between launches)
+  int32_t* err;
+  uint32_t epoch;               // number of this exchange (1, 2, ...)
+  int rank, size, cap_rows;
+  int on;                       // 0: the classic form (send buffer + a collective); the rest of the struct is unused
+  int poll;                     // 1: consumer kernels poll their flags themselves; 0: a one-wave wait kernel runs in front
+};
+struct EpWait {  // poll `n` flag words (stride EP_FLAG_WORDS) until each has reached `epoch`
+  const uint32_t* flags;
+  int n;
+  uint32_t epoch;
+  int64_t timeout_ticks;
+  int32_t* err;
+};
+hipError_t launch_ep_wait(const EpWait& w, hipStream_t st);
+
 // epilogues of the row-dot (weight-streaming) FFN kernel
 enum {
   EPI_NONE = 0,       // out = Tr(acc)                      (down / w2 / wo projections)
@@ -136,7 +170,7 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
 // come from the records the self-routing launch left in s2.dec_w / s2.dec_cw
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st);
 
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wait = nullptr);  // wait: poll these flags first (peer-store exchange)
 // out[i] = valid[i] ? idx[i] : -1
 hipError_t launch_masked_idx(const int32_t* idx, const int32_t* valid, int32_t* out, int n, hipStream_t st);
 // index arrays for "only the shared pseudo-expert E is active, with T rows" (expert-parallel path)
@@ -168,7 +202,7 @@ struct EpPackArgs {
   const int32_t* slot_pair;   // [T*K] destination-sorted slot -> pair id
   int K, H, ep_size, cap_rows, dtype;
 };
-hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st);
+hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st, const EpPeers* peers = nullptr);
 // the pack riding in the single-workgroup router launch of a decode-sized forward (launch_route_index /
 // launch_route_shared2): on != 0 makes the workgroup that routed and indexed the tokens write the send rows as well
 struct EpFuse {
@@ -176,12 +210,14 @@ struct EpFuse {
   const int32_t* pair_valid;
   int32_t* send_counts;  // optional [ep_size]
   int on;
+  EpPeers peers;         // peers.on: the rows go straight into the destination ranks' windows (a.send unused)
 };
 // compact, destination-sorted send rows (variable-split exchange): row r = r-th pair in destination order
 hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st);
 // n_pairs <= 64: dest keys + stable ranks + row copy in one launch (counts/offsets/slot_pair of `a` unused);
 // send_counts (optional, [ep_size]) receives the rows per destination
-hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st);
+hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st,
+                                const EpPeers* peers = nullptr);
 
 // Expert-parallel exchange, owner side, decode-sized (<= 64 received row slots, every owned expert resident): one FFN
 // stage that INDEXES FOR ITSELF — every workgroup reads the expert ids in the received rows' tails, derives "its"
@@ -197,8 +233,17 @@ struct EpOwnArgs {
   int stage;            // 1 or 2
   int max_active;       // grid.y
   int32_t* mirror;      // stage 1 only (optional): pinned routing mirror {n_active, counts[E+1], active[E+1]}
+  EpPeers peers;        // peers.on: recv = this rank's window; stage 1 polls the recv flags (peers.poll), stage 2 stores
+                        // every output row straight into its home rank's window and the last workgroup publishes
 };
 hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st);
+// peer-store exchange, owner side, generic path (more rows than the self-indexing kernel takes): copy the valid rows of
+// y [ep_size*cap_rows, H] (valid = the received row's tail >= 0) into their home ranks' windows and publish
+hipError_t launch_ep_push(const void* y, const void* recv, int64_t ld_recv, int H, int dtype, const EpPeers& peers, hipStream_t st);
+// transport self-test: rank r writes a tagged pattern into segment r of every peer's two regions and publishes `peers.epoch`
+// on both flag sets; check: after both flag sets arrived, every segment p of this rank's regions must hold rank p's tag
+hipError_t launch_ep_selftest_send(const EpPeers& peers, int words, hipStream_t st);
+hipError_t launch_ep_selftest_check(const EpPeers& peers, int words, int32_t* ok_dev, hipStream_t st);
 // [T,K] routing of a caller that kept its own router -> the engine's pair arrays (moeinf_combine): idx < 0 = dropped pair
 hipError_t launch_prep_pairs(const int32_t* idx_in, const float* w_in, int T, int K, int32_t* topk_idx, float* topk_w,
                              int32_t* pair_valid, int32_t* pair_order, hipStream_t st);

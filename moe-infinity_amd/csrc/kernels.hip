@@ -104,7 +104,8 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
     if (nw == 8) LAUNCH(8, 1, 4); else LAUNCH(4, 1, 4);
     return;
   }
-  if (nw == 8) { if (u == 2) LAUNCH(8, 2, 1); else if (u == 8) LAUNCH(8, 8, 1); else LAUNCH(8, 4, 1); }
+  if (nw == 16) { LAUNCH(16, 4, 1); }
+  else if (nw == 8) { if (u == 2) LAUNCH(8, 2, 1); else if (u == 8) LAUNCH(8, 8, 1); else LAUNCH(8, 4, 1); }
   else         { if (u == 2) LAUNCH(4, 2, 1); else if (u == 8) LAUNCH(4, 8, 1); else LAUNCH(4, 4, 1); }
 #undef LAUNCH
 }
@@ -117,7 +118,12 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   // long reductions get 8 waves per block (more bytes in flight per CU), short ones 4
   const int kmax = s.K > s.K_sh ? s.K : s.K_sh;
   const size_t kbytes = (size_t)kmax * (s.dtype == DT_BF16 ? 2 : 4);
-  const int nw = env_nw ? env_nw : (kbytes >= 16384 ? 8 : 4);
+  // ... and a grid of at most one workgroup per CU (Switch-base-8 at batch 1: 192 / 48 workgroups for 256 CUs) SIXTEEN: a CU
+  // that owns a single work item has nothing else to hide its load latency behind, so the whole item goes in flight at
+  // once (round 4: stage 2 of Switch-base-8 streamed 9.45 MB in 16.8 us = 0.07 of HBM peak with 48 four-wave workgroups)
+  const int kb_tiles = (int)(kbytes / 64);
+  const bool few = (int64_t)grid.x * grid.y <= 256 && kb_tiles >= 32 && !s.fuse_combine;
+  const int nw = env_nw ? env_nw : (few ? 16 : (kbytes >= 16384 ? 8 : 4));
   const int u = env_u ? env_u : 4;
   static const int env_nt = env_int("MOEINF_FFN_NT", 0);
   // the decode kernel re-streams an expert's weights for every 16 rows: from 17 rows on, the GEMM kernels (one pass
@@ -729,8 +735,8 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   if (half_env && s2.comb.K >= 3 && s2.comb.K <= 8 && (s2.K % 32) == 0 && s2.comb.kind <= 1 && !s2.comb.shared_offsets) {
     const dim3 g2(2 * ((s2.R + 15) / 16));
     static const int hu = env_int("MOEINF_DEC1_HALF_U", 8);
+    // (the 12-tiles-per-batch variants spilled 144 bytes per thread and were never faster: removed in round 4)
 #define HALF(KX, NWE) do { if (hu == 4) hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 4>), g2, dim3(KX * NWE * 64), 0, st, s2); \
-                           else if (hu == 12) hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 12>), g2, dim3(KX * NWE * 64), 0, st, s2); \
                            else hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 8>), g2, dim3(KX * NWE * 64), 0, st, s2); } while (0)
     switch (s2.comb.K) {
       case 3: HALF(3, 4); break;
@@ -856,8 +862,22 @@ hipError_t launch_shared_only_index(const IndexArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st) {
+// peer-store exchange: a.y is this rank's return region, filled by the owners' kernels; every workgroup polls the
+// owners' flags itself before it reads a row
+template <typename T>
+__global__ __launch_bounds__(256) void combine_wait_kernel(CombineArgs a, EpWait w) {
+  if (threadIdx.x < 64) ep_poll(w.flags, w.n, w.epoch, w.timeout_ticks, w.err);
+  __syncthreads();
+  const int h0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (h0 < a.H) combine_cols<T>(a, blockIdx.y, h0);
+}
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wait) {
   dim3 grid((a.H + 1023) / 1024, a.T);
+  if (wait) {
+    if (a.dtype == DT_BF16) hipLaunchKernelGGL(combine_wait_kernel<uint16_t>, grid, dim3(256), 0, st, a, *wait);
+    else hipLaunchKernelGGL(combine_wait_kernel<float>, grid, dim3(256), 0, st, a, *wait);
+    return hipGetLastError();
+  }
   if (a.dtype == DT_BF16) hipLaunchKernelGGL(combine_kernel<uint16_t>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(combine_kernel<float>, grid, dim3(256), 0, st, a);
   return hipGetLastError();

@@ -244,6 +244,10 @@ class MoEEngine:
         check(self.lib.moeinf_is_resident(self._h, layer, expert, C.byref(r)))
         return bool(r.value)
 
+    def sync(self):
+        """wait for the last forward's stream; raises if a kernel raised the device error flag"""
+        check(self.lib.moeinf_sync(self._h))
+
     def sync_copies(self):
         check(self.lib.moeinf_sync_copies(self._h))
 
@@ -286,6 +290,7 @@ class MoEEngine:
     def set_profiling(self, on):
         """True / 1: per-kernel events; 2: per-phase events of ep_moe_forward; 3: both"""
         check(self.lib.moeinf_set_profiling(self._h, int(on)))
+        self._profiling = int(on)
 
     def profile(self) -> dict:
         """Accumulated per-kernel event timings + algorithmic bytes since the last call (resets)."""
@@ -340,6 +345,10 @@ class MoEEngine:
         check(self.lib.moeinf_ep_comm_unique_id(buf, 128))
         return bytes(buf)
 
+    def ep_comm_prepare(self, cap_tokens: int):
+        """the local half of the RCCL bootstrap (buffers, library binding): no collective inside"""
+        check(self.lib.moeinf_ep_comm_prepare(self._h, int(cap_tokens)))
+
     def ep_comm_init(self, unique_id: bytes, cap_tokens: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(self.lib.moeinf_ep_comm_init(self._h, buf, 128, int(cap_tokens)))
@@ -357,6 +366,36 @@ class MoEEngine:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(self.lib.moeinf_ep_moe_forward(self._h, layer, _ptr(x2), x2.shape[0], batch_rows, _ptr(gate_w), _ptr(out), stream))
         self._last_T = x2.shape[0]
+
+    # ---- direct peer-store exchange (no collective; include/moeinf.h: moeinf_ep_peer_*) ---------
+    PEER_BLOB_BYTES = 192
+    EP_TRANSPORTS = {0: "none", 1: "rccl", 2: "peer-store"}
+
+    def ep_peer_export(self, cap_tokens: int) -> bytes:
+        """allocate this rank's exchange window; returns the 192-byte blob the other ranks need to map it"""
+        buf = (C.c_uint8 * self.PEER_BLOB_BYTES)()
+        check(self.lib.moeinf_ep_peer_export(self._h, int(cap_tokens), buf, self.PEER_BLOB_BYTES))
+        return bytes(buf)
+
+    def ep_peer_attach(self, blobs: bytes):
+        """map every rank's window (blobs of all ranks, concatenated in rank order)"""
+        buf = (C.c_uint8 * len(blobs)).from_buffer_copy(blobs)
+        check(self.lib.moeinf_ep_peer_attach(self._h, buf, len(blobs)))
+
+    def ep_peer_selftest(self) -> bool:
+        """tagged rows + flags to and from every peer (every rank must call it); False on a mismatch or a timeout"""
+        ok = C.c_int32()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.moeinf_ep_peer_selftest(self._h, stream, C.byref(ok)))
+        return bool(ok.value)
+
+    def ep_select_transport(self, name: str):
+        check(self.lib.moeinf_ep_select_transport(self._h, {"rccl": 1, "peer-store": 2}[name]))
+
+    def ep_transport(self) -> dict:
+        o = (C.c_int32 * 4)()
+        check(self.lib.moeinf_ep_transport(self._h, o))
+        return {"transport": self.EP_TRANSPORTS.get(o[0], "?"), "shared_device": bool(o[1]), "poll_in_kernels": bool(o[2]), "exchanges": int(o[3])}
 
     def ep_profile(self) -> dict:
         p = EpProfile()

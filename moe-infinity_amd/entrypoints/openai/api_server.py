@@ -82,6 +82,15 @@ class RequestBatcher:
         self.model = model
         self.pad = int(pad_token_id)
         self.eos = eos_token_id
+        # every id that ends a sequence: the tokenizer's EOS plus the model's generation_config.eos_token_id, which may be a
+        # LIST (Llama-3 style: several end tokens and a separate pad id)
+        self.eos_ids = set() if eos_token_id is None else {int(eos_token_id)}
+        g = getattr(getattr(model, "generation_config", None), "eos_token_id", None)
+        if g is not None:
+            self.eos_ids.update(int(t) for t in (g if isinstance(g, (list, tuple)) else [g]))
+        # encoder-decoder models (Switch-Transformers, NLLB-MoE: two of the four supported families) return the DECODER
+        # sequence only — decoder_start_token first, no echo of the prompt; decoder-only models echo the (padded) prompt
+        self.encoder_decoder = bool(getattr(getattr(model, "config", None), "is_encoder_decoder", False))
         self.max_batch = max(1, int(max_batch))
         self.window = max(0.0, float(window_ms)) / 1e3
         self.device = device
@@ -164,10 +173,12 @@ class RequestBatcher:
         self.stats["largest_batch"] = max(self.stats["largest_batch"], len(batch))
         res = []
         for r in range(len(batch)):
-            new = [int(t) for t in out[r, width:].tolist()]
-            if self.eos is not None and self.eos in new:
-                new = new[: new.index(self.eos)]  # the rest of the row is padding written after this request finished
-            elif self.eos is None:
+            # the reference's TokenStreamer skips exactly the first put() (the prompt / the decoder start token, :109-131)
+            new = [int(t) for t in (out[r, 1:] if self.encoder_decoder else out[r, width:]).tolist()]
+            ends = [i for i, t in enumerate(new) if t in self.eos_ids]
+            if ends:
+                new = new[: ends[0]]  # the rest of the row is padding written after this request finished
+            else:
                 while new and new[-1] == self.pad:
                     new.pop()
             res.append(new)

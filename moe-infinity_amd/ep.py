@@ -71,9 +71,16 @@ class ExpertParallelMoE:
 
     PHASES = ("route_pack", "a2a_dispatch", "owner_ffn", "a2a_combine", "combine")
 
+    TRANSPORTS = ("auto", "peer-store", "rccl", "torch")
+
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
                  group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None,
-                 native: Optional[bool] = False):
+                 native: Optional[bool] = False, transport: Optional[str] = None):
+        """transport (decode-sized, fixed-capacity exchanges; prefill-sized ones always go through torch.distributed):
+        "peer-store" = rows stored straight into the peers' windows, no collective (csrc/ep_peer.h); "rccl" = RCCL called from
+        inside the engine; both = ONE host call per layer; "torch" = all_to_all_single, five host calls per layer; "auto" =
+        the first of those three that passes its self-test on EVERY rank.  ``native`` is the older switch: False = "torch",
+        None / True = "auto"."""
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
@@ -100,9 +107,25 @@ class ExpertParallelMoE:
         self.last_form = None
         # native transport: RCCL called from inside the engine, a whole layer = ONE host call (moeinf_ep_moe_forward)
         self.native = False
+        self.transport = "torch"
         self.native_note = "not requested"
-        if native is not False:
-            self.native = self._try_native(max_tokens)
+        if transport is None:
+            transport = "torch" if native is False else "auto"
+        if transport not in self.TRANSPORTS:
+            raise ValueError(f"transport must be one of {self.TRANSPORTS}")
+        notes = []
+        if transport in ("auto", "peer-store"):
+            if self._try_peer_store(max_tokens):
+                self.native, self.transport = True, "peer-store"
+            notes.append(f"peer-store: {self.native_note}")
+        if not self.native and transport in ("auto", "rccl"):
+            if self._try_native(max_tokens):
+                self.native, self.transport = True, "rccl"
+            notes.append(f"rccl: {self.native_note}")
+        if notes:
+            self.native_note = "; ".join(notes)
+        if self.native:
+            self.ops.engine.ep_select_transport(self.transport)
 
     @property
     def profile(self):
@@ -111,15 +134,70 @@ class ExpertParallelMoE:
     @profile.setter
     def profile(self, on):
         self._profile = bool(on)
-        if self.native:
-            self.ops.engine.set_profiling(2 if on else 0)
+        if self.native:  # bit 1 = per-phase events of ep_moe_forward; bit 0 (per-kernel events) stays as the caller set it
+            eng = self.ops.engine
+            eng.set_profiling((getattr(eng, "_profiling", 0) & 1) | (2 if on else 0))
 
     # -- native transport -----------------------------------------------------------------------
+    def _comm_device(self):
+        """where the small bootstrap tensors live: RCCL moves device tensors, a host-side backend (gloo) host tensors"""
+        return self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
     def _agree(self, ok: bool) -> bool:
         """True only if EVERY rank says ok (a path that some ranks take and others do not would dead-lock)"""
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._comm_device())
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(t.item())
+
+    def _try_peer_store(self, cap_tokens: int) -> bool:
+        """Bootstrap the direct peer-store exchange (include/moeinf.h: moeinf_ep_peer_*): every rank allocates and exports its
+        window (local), the blobs are all-gathered through the existing process group, every rank maps its peers (local), then a
+        tagged self-test crosses every pair both ways.  The outcome of EVERY step is all-reduced, so either all ranks end up on
+        this transport or none does.  Works with any process-group backend — the group only carries 192 bytes per rank — and
+        between ranks that share one GPU."""
+        eng = getattr(self.ops, "engine", None)
+        if eng is None or self.device.type != "cuda" or not hasattr(eng, "ep_peer_export"):
+            self.native_note = "ops are not the HIP engine"
+            return False
+        blob, ok = bytes(eng.PEER_BLOB_BYTES), True
+        try:
+            blob = eng.ep_peer_export(cap_tokens)
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"window export failed: {ex}"
+        if not self._agree(ok):
+            if ok:
+                self.native_note = "window export failed on another rank"
+            return False
+        dev = self._comm_device()
+        mine = torch.tensor(list(blob), dtype=torch.uint8, device=dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        blobs = b"".join(bytes(p.cpu().tolist()) for p in parts)
+        try:
+            eng.ep_peer_attach(blobs)
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"mapping the peers' windows failed: {ex}"
+        if not self._agree(ok):
+            if ok:
+                self.native_note = "mapping the peers' windows failed on another rank"
+            return False
+        try:
+            ok = eng.ep_peer_selftest()
+            if not ok:
+                self.native_note = "self-test: wrong rows or a peer never published (timeout)"
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"self-test failed: {ex}"
+        if not self._agree(ok):
+            if ok:
+                self.native_note = "self-test failed on another rank"
+            return False
+        t = eng.ep_transport()
+        self.native_note = ("rows stored straight into the peers' windows, no collective (self-test passed on every rank; "
+                            + ("ranks share a GPU: one-wave wait kernels" if not t["poll_in_kernels"] else "consumer kernels poll their flags") + ")")
+        return True
 
     def _try_native(self, cap_tokens: int) -> bool:
         """Bootstrap the engine's own RCCL communicator through the existing process group, then PROVE it: a tagged
@@ -143,6 +221,16 @@ class ExpertParallelMoE:
         if not self._agree(ok):
             if ok:
                 self.native_note = "librccl not usable on another rank"
+            return False
+        # the local half first (buffers, validation), agreed on BEFORE anyone enters the collective ncclCommInitRank
+        try:
+            eng.ep_comm_prepare(cap_tokens)
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            self.native_note = f"exchange buffers: {ex}"
+        if not self._agree(ok):
+            if ok:
+                self.native_note = "exchange buffers could not be made on another rank"
             return False
         t = torch.tensor(list(uid), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
@@ -177,7 +265,7 @@ class ExpertParallelMoE:
 
     # -- timers ---------------------------------------------------------------------------------
     def _mark(self):
-        if not self.profile:
+        if not self.profile or (self.native and len(self._marks) >= 6 * 4096):  # bounded when nobody collects them
             return
         if self.device.type == "cuda":
             ev = torch.cuda.Event(enable_timing=True)
@@ -193,6 +281,7 @@ class ExpertParallelMoE:
         if self.native:
             p = self.ops.engine.ep_profile()
             c = max(1, p["calls"])
+            self._marks = []  # (forwards that took the variable-split path left theirs here; they are not part of this report)
             return {"calls": p["calls"], **{ph: round(p[ph + "_ms"] * 1e3 / c, 2) for ph in self.PHASES},
                     "timed_by": "HIP events inside moeinf_ep_moe_forward"}
         if self.device.type == "cuda":

@@ -12,8 +12,11 @@ the reference's *own Python blocks* executed on CPU in the build container
 (``oracle/gen_golden.py`` imports ``/root/reference/moe_infinity/models/*.py``,
 ``memory/*.py`` and the vendored ``MoEGate`` and writes ``tests/golden/*.npz``).
 The per-expert FFN lives in the reference's C++ core
-(``core/parallel/expert_module.cpp``) which cannot be compiled here (CUDA
-toolkit required); it is restated from that file as the same ATen op sequence.
+(``core/parallel/expert_module.cpp``): restated below as the same ATen op sequence AND
+pinned against that very file — it is host-only libtorch code and compiles here
+(``oracle/build_ref.py`` -> ``oracle/_ref/libmoeinf_ref.so``; ``tests/test_ref_pin_cpu.py``
+and the goldens ``tests/golden/ref_ffn_*.npz`` compare ``expert_ffn`` with the compiled
+modules' ``forward`` bit for bit).  The rest of the C++ core needs the CUDA toolkit.
 
 Every function cites the reference lines it follows (paths relative to
 ``/root/reference``).

@@ -17,6 +17,14 @@ differ by ``|x|`` — a full-size value — on such an element.  The bar handles
 pre-passthrough sum is within the combine tolerance of 0, the result must be EITHER within tolerance of that
 pre-passthrough sum OR bit-equal to the input element (the passthrough taken); everywhere else the ordinary bar
 applies.  ``block_report`` counts those elements (``passthrough_ambiguous``) so a run can show how many there were.
+
+The fp32-exact arm (``exact_block`` / ``accuracy_report``).  The bars above are multiples of the model dtype's ulp — an
+interpretation of north_star's "1e-3 fp16" for bf16 models ("What 'within 1e-3' means").  The arm that needs no
+interpretation: compute the block once more in fp32 on fp32 copies of the weights with the oracle's routing ("exact": no
+rounding to the model dtype after the router) and require the GPU result to be AS CLOSE TO IT AS THE REFERENCE'S CPU PATH IS:
+``mean |gpu - exact| <= 1.15 * mean |oracle - exact|`` (the factor: the two differ in fp32 summation order, so either may be
+the luckier one on a given sample).  A kernel that loses precision anywhere — a missing fp32 accumulation, an extra
+rounding — fails this arm even if it stays inside an ulp multiple.
 """
 from __future__ import annotations
 
@@ -78,6 +86,63 @@ def block_report(got: torch.Tensor, ref, dtype, golden: torch.Tensor = None, x: 
         rep["worst_at"] = {"flat_index": i, "got": float(got.reshape(-1)[i]), "want": float(want.reshape(-1)[i]),
                            "tol": float(tol.reshape(-1)[i])}
     return rep
+
+
+def exact_block(family: str, x3d: torch.Tensor, ref, experts, shared=None) -> dict:
+    """The block in fp32 on fp32 copies of the weights, with the ORACLE'S routing (``ref.router_mask`` / ``weights_mask`` /
+    Switch ``router_probs``): nothing is rounded to the model dtype after the router.  Returns {"out": [.., H] fp32 (NLLB: the
+    pre-passthrough sum), "rows": {expert: [t_e, H] fp32}}.  Combine rules as the blocks in moe_ref.py."""
+    from . import moe_ref as R
+
+    et = {"mixtral": R.MIXTRAL_DENSE_ACT_DENSE, "deepseek": R.DEEPSEEK_DENSE_ACT_DENSE, "switch": R.SWITCH_DENSE_ACT_DENSE,
+          "nllb": R.NLLB_DENSE_ACT_DENSE}[family]
+    h = x3d.shape[-1]
+    hp = torch.float64 if x3d.dtype == torch.float32 else torch.float32  # one step above the model dtype's arithmetic
+    x = x3d.reshape(-1, h).to(hp)
+    rm = ref.router_mask.reshape(x.shape[0], -1).bool()
+    out = x.clone() if family == "switch" else torch.zeros_like(x)
+    rows = {}
+    for e in sorted(ref.expert_out):
+        tok = rm[:, e]
+        y = R.expert_ffn(x[tok], [t.to(hp) for t in experts[e]], et)
+        rows[e] = y
+        if family == "switch":
+            out[tok] = y
+        else:
+            out[tok] += y * ref.weights_mask.reshape(x.shape[0], -1)[tok, e].to(hp)[:, None]
+    if family == "switch":
+        out = ref.extra["router_probs"].reshape(-1, 1).to(hp) * out
+    if family == "deepseek" and shared is not None:
+        out = out + R.expert_ffn(x, [t.to(hp) for t in shared], et)
+    return {"out": out.reshape(ref.out.shape), "rows": rows}
+
+
+def accuracy_report(got: torch.Tensor, ref, exact: dict, dtype, factor: float = 1.15) -> dict:
+    """mean |gpu - exact| against mean |oracle - exact| over the block output (NLLB: elements on the `== 0` passthrough
+    discontinuity, where either side may legitimately return the input instead, are left out of both means)."""
+    ex = exact["out"]
+    want = ref.out.to(ex.dtype).cpu().reshape(ref.out.shape)
+    got = got.to(ex.dtype).cpu().reshape(ref.out.shape)
+    keep = torch.ones_like(ex, dtype=torch.bool)
+    if "pre_passthrough" in ref.extra:
+        pre = ref.extra["pre_passthrough"].float().reshape(ref.out.shape)
+        mag = block_magnitude(ref)
+        keep = pre.abs() > (2.0 * mag + torch.maximum(pre.abs(), want.abs().mean())) * ulp_of(dtype) + 1e-30
+        keep &= (pre == want)  # the oracle did not take the passthrough there either
+    e_gpu = (got - ex).abs()[keep].mean().item() if keep.any() else 0.0
+    e_ref = (want - ex).abs()[keep].mean().item() if keep.any() else 0.0
+    scale = ex.abs()[keep].mean().item() + 1e-30 if keep.any() else 1.0
+    return {"gpu_vs_exact": e_gpu, "oracle_vs_exact": e_ref, "ratio": e_gpu / (e_ref + 1e-30), "factor": factor,
+            "gpu_vs_exact_rel": e_gpu / scale, "oracle_vs_exact_rel": e_ref / scale,
+            "ok": e_gpu <= factor * e_ref + 1e-12 * scale, "elements": int(keep.sum())}
+
+
+def rows_accuracy_report(got_rows: torch.Tensor, ref_rows: torch.Tensor, exact_rows: torch.Tensor, factor: float = 1.15) -> dict:
+    """the same arm for the per-expert FFN rows (expert-sorted, concatenated)"""
+    x = exact_rows.cpu()
+    g, r = got_rows.to(x.dtype).cpu(), ref_rows.to(x.dtype).cpu()
+    e_gpu, e_ref = (g - x).abs().mean().item(), (r - x).abs().mean().item()
+    return {"gpu_vs_exact": e_gpu, "oracle_vs_exact": e_ref, "ratio": e_gpu / (e_ref + 1e-30), "ok": e_gpu <= factor * e_ref + 1e-30}
 
 
 def rows_report(got: torch.Tensor, ref: torch.Tensor, dtype, ulps: float = 1.0) -> dict:

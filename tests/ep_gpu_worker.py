@@ -1,6 +1,8 @@
 """Worker of tests/test_gpu_ep_processes.py: one expert-parallel rank (its own process, its own HIP engine) on GPU 0.
-Launched by torch.distributed.run with the gloo backend (RCCL refuses two ranks on one GPU); ExpertParallelMoE then
-stages the exchange through host memory, everything else is the product path: HipEpOps over the C ABI."""
+Launched by torch.distributed.run with the gloo backend (RCCL refuses two ranks on one GPU).  EP_TRANSPORT=peer-store
+(default): the product's direct exchange — every rank maps the other processes' windows with hipIpc* and stores its rows
+straight into them; the process group only carries the 192-byte bootstrap blobs and the all-reduced verdicts.
+EP_TRANSPORT=torch: all_to_all_single with the rows staged through host memory (the older form of this test)."""
 import os
 import sys
 
@@ -15,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    transport = os.environ.get("EP_TRANSPORT", "peer-store")
     from helpers import R, acts, assert_block_close, make_weights
     from moe_infinity_amd import MoEEngine
     from moe_infinity_amd import config as Cf
@@ -35,7 +38,12 @@ def main():
                     eng.register_expert(l, i, ex)
             if ws[l][2]:
                 eng.register_shared(l, ws[l][2])
-        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64, num_experts=e)
+        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64, num_experts=e, transport=transport)
+        assert ep.transport == transport, f"rank {rank}: wanted {transport}, got {ep.transport}: {ep.native_note}"
+        if transport == "peer-store":
+            t = eng.ep_transport()  # the ranks share GPU 0: detected from the PCI bus ids in the blobs
+            assert t["transport"] == "peer-store" and t["shared_device"] and not t["poll_in_kernels"], t
+        dist.barrier()
         for t in (1, 3 + rank, tmax - 3 * rank):  # batch 1, ragged small batches (fixed form), prefill-sized (variable split)
             for l in range(L):
                 x = acts(t, h, torch.bfloat16, 3200 + 7 * t + l + 1000 * rank)
@@ -46,9 +54,11 @@ def main():
                     ref = R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2])
                 assert_block_close(out, ref, torch.bfloat16, f"rank {rank} {family} t={t} layer {l} ({ep.last_form})")
                 assert ep.last_form == ("variable" if t * k > 64 else "fixed")
+        eng.sync()      # a peer-store poll that timed out would raise here
+        dist.barrier()  # nobody frees a window another rank may still store into
         eng.close()
         dist.barrier()
-    print(f"EP_WORKER_OK rank {rank} of {world}", flush=True)
+    print(f"EP_WORKER_OK rank {rank} of {world} transport {transport}", flush=True)
     dist.destroy_process_group()
 
 

@@ -93,3 +93,19 @@ def fill_layer_on_gpu(eng, family, layer, seed, dev="cuda:0", std=0.02):
         eng.register_shared(layer, shared)
     torch.cuda.synchronize()
     return experts, shared
+
+
+def assert_as_accurate_as_the_oracle(got, ref: R.BlockResult, family, x3d, experts, dtype, what, shared=None, rows=None):
+    """The fp32-exact arm (oracle/parity.py): the GPU block output — and, with ``rows`` = the GPU's per-expert FFN rows in
+    expert-sorted order, those rows too — must be as close to the fp32 computation as the reference's CPU path (the oracle in
+    the model dtype) is: mean |gpu - exact| <= 1.15 x mean |oracle - exact|."""
+    ex = P.exact_block(family, x3d, ref, experts, shared=shared)
+    rep = P.accuracy_report(got, ref, ex, dtype)
+    assert rep["ok"], (f"{what}: the GPU result is further from the fp32-exact block ({rep['gpu_vs_exact']:.3e}) than the oracle in the model dtype "
+                       f"({rep['oracle_vs_exact']:.3e}), ratio {rep['ratio']:.3f} > {rep['factor']}")
+    if rows is not None:
+        order = [e for e in sorted(ref.expert_out)]
+        rr = P.rows_accuracy_report(rows, torch.cat([ref.expert_out[e] for e in order], 0), torch.cat([ex["rows"][e] for e in order], 0))
+        assert rr["ok"], f"{what}: expert FFN rows further from fp32-exact ({rr['gpu_vs_exact']:.3e}) than the oracle's ({rr['oracle_vs_exact']:.3e})"
+        rep["rows"] = rr
+    return rep

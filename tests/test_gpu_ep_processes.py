@@ -1,9 +1,10 @@
 """Expert parallelism with REAL processes on the GPU: two (and three) ranks, each its own process with its own HIP
-engine holding the experts e % world == rank, all on GPU 0 of a one-GPU box.  RCCL refuses several ranks per GPU
-("Duplicate GPU detected"), so the ranks talk through gloo and ExpertParallelMoE stages the all-to-all rows through
-host memory — the only difference from the multi-GPU product path (HipEpOps, the moeinf_ep_* kernels, fixed and
-variable-split exchange, the shared expert on the home rank, ragged token counts).  Every rank checks its own tokens
-against the oracle with the block bar."""
+engine holding the experts e % world == rank, all on GPU 0 of a one-GPU box.  The decode-sized exchanges run over the
+product's own transport, the direct peer-store exchange (moeinf_ep_peer_*): every process maps the others' windows with
+hipIpcOpenMemHandle and its kernels store rows straight into them — the multi-rank path of the product, executed between
+real processes (RCCL refuses several ranks per GPU, "Duplicate GPU detected"; gloo only carries the bootstrap blobs and the
+prefill-sized, variable-split exchanges, staged through host memory).  One case keeps the older all-host-staged form.
+Every rank checks its own tokens against the oracle with the block bar."""
 import os
 import socket
 import subprocess
@@ -23,11 +24,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_expert_parallel_ranks_as_processes_on_one_gpu(world):
+@pytest.mark.parametrize("world,transport", [(2, "peer-store"), (3, "peer-store"), (2, "torch")])
+def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ep_gpu_worker.py")]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EP_TRANSPORT=transport)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     # the ranks share one stdout: their lines can run together
-    assert r.returncode == 0 and r.stdout.count("EP_WORKER_OK") == world, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
+    assert r.returncode == 0 and r.stdout.count("EP_WORKER_OK") == world and r.stdout.count(f"transport {transport}") == world, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])

@@ -236,10 +236,13 @@ def test_expert_parallel_module_through_rccl_world_size_1():
             register_all(eng, experts, shared)
             # torch.distributed transport (five host calls per layer), then the engine's own RCCL communicator (one host call
             # per layer: moeinf_ep_moe_forward) — bootstrapped through the process group and self-tested before use
-            for native in (False, None):
-                ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, DEV, num_experts=e, native=native)
-                if native is None:
-                    assert ep.native, f"native transport not available: {ep.native_note}"
+            # and the direct peer-store exchange (no collective; at world size 1 the rank stores into its own window)
+            for transport in ("torch", "rccl", "peer-store", "auto"):
+                ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, DEV, num_experts=e, transport=transport)
+                assert ep.transport == ("peer-store" if transport == "auto" else transport), f"{transport}: {ep.native_note}"
+                assert ep.native == (transport != "torch")
+                if ep.native:
+                    assert eng.ep_transport()["transport"] == ep.transport
                 g = gate.to(DEV)
                 for t in (1, 3, 40):
                     x = acts(t, h, torch.bfloat16, 541 + t)
@@ -249,7 +252,7 @@ def test_expert_parallel_module_through_rccl_world_size_1():
                         ref = R.block_mixtral(x[None], gate, experts, top_k=k)
                     else:
                         ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
-                    assert_block_close(out, ref, torch.bfloat16, f"EP module, {family}, {t} tokens, native={ep.native}")
+                    assert_block_close(out, ref, torch.bfloat16, f"EP module, {family}, {t} tokens, transport={ep.transport}")
                 if ep.native:
                     ep.profile = True
                     ep.forward(0, x.to(DEV), g)

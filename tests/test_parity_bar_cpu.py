@@ -61,3 +61,48 @@ def test_rows_bar_is_one_ulp():
     assert P.rows_report(b, a, torch.bfloat16)["ok"]
     b[1, 1] = b[1, 1].float() * 1.1 + 0.5
     assert not P.rows_report(b, a, torch.bfloat16)["ok"]
+
+
+def test_the_fp32_exact_arm_accepts_the_oracle_and_rejects_a_lossy_kernel():
+    """oracle/parity.py exact_block / accuracy_report: a result as accurate as the reference's CPU path passes; one that rounds
+    the FFN's hidden activations to bf16 a second time with TRUNCATION (a kernel that loses half a bit) stays inside a few ulps
+    elementwise yet is measurably further from the fp32 computation — the arm names it."""
+    import torch.nn.functional as F
+
+    for family in ("mixtral", "deepseek", "nllb", "switch"):
+        dt = torch.float32 if family == "switch" else torch.bfloat16
+        e, k, n_shared = (16, 4, 2) if family == "deepseek" else (8, 2, 0)
+        gate, experts, shared = make_weights(family, 256, 512, e, 77, dt, n_shared=n_shared, **({"gate_std": 0.5} if family in ("nllb", "switch") else {}))
+        x = acts(24, 256, dt, 78)[None]
+        if family == "mixtral":
+            ref = R.block_mixtral(x, gate, experts, top_k=k)
+        elif family == "deepseek":
+            ref = R.block_deepseek(x, gate, experts, k, shared=shared)
+        elif family == "nllb":
+            ref = R.block_nllb(x, gate, experts)
+        else:
+            ref = R.block_switch(x, gate, experts, expert_capacity=64)
+        ex = P.exact_block(family, x, ref, experts, shared=shared)
+        rep = P.accuracy_report(ref.out, ref, ex, dt)
+        assert rep["ok"] and abs(rep["ratio"] - 1.0) < 1e-9 and rep["oracle_vs_exact"] > 0, (family, rep)
+        # rows arm, same identity
+        order = sorted(ref.expert_out)
+        rows_ref = torch.cat([ref.expert_out[i] for i in order], 0)
+        assert P.rows_accuracy_report(rows_ref, rows_ref, torch.cat([ex["rows"][i] for i in order], 0))["ok"]
+    # the lossy kernel (Mixtral): hidden activations truncated instead of rounded
+    gate, experts, _ = make_weights("mixtral", 256, 512, 8, 79, torch.bfloat16)
+    x = acts(64, 256, torch.bfloat16, 80)[None]
+    ref = R.block_mixtral(x, gate, experts, top_k=2)
+    ex = P.exact_block("mixtral", x, ref, experts)
+    trunc = lambda t: (t.float().view(torch.int32) & ~0xFFFF).view(torch.float32).to(torch.bfloat16)  # noqa: E731
+    lossy = torch.zeros_like(ref.out[0])
+    for i in sorted(ref.expert_out):  # the oracle's op sequence (expert_module.cpp:147-175 in bf16) with truncation at two rounding points
+        tok = ref.router_mask[:, i].bool()
+        w1, w2, w3 = experts[i]
+        xi = x[0][tok]
+        hcur = trunc(F.silu(torch.matmul(xi, w1.t())).float() * torch.matmul(xi, w3.t()).float())
+        y = trunc(torch.matmul(hcur.float(), w2.float().t()))
+        lossy[tok] += y * ref.weights_mask[tok, i][:, None]
+    assert P.block_report(lossy[None], ref, torch.bfloat16)["worst"] < 4.0  # a few ulps elementwise: the ulp bars barely notice
+    rep = P.accuracy_report(lossy[None], ref, ex, torch.bfloat16)
+    assert not rep["ok"] and rep["ratio"] > 1.15, rep

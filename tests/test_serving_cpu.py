@@ -192,3 +192,54 @@ def test_a_failing_generate_fails_its_requests_not_the_worker():
     with pytest.raises(ValueError):
         b.submit([], {"max_new_tokens": 2})
     b.close()
+
+
+def test_encoder_decoder_models_return_the_decoder_sequence_only():
+    """Switch-Transformers and NLLB-MoE are encoder-decoder models: HF generate returns decoder_start_token + the new tokens,
+    no echo of the prompt (round-3 advice: slicing at the prompt width dropped the first `width` generated tokens).  The
+    reference's TokenStreamer skips exactly its first put() (api_server.py:109-131), which is right for both kinds."""
+    import types
+
+    class Seq2Seq(EchoModel):
+        config = types.SimpleNamespace(is_encoder_decoder=True)
+
+        def generate(self, input_ids, attention_mask=None, max_new_tokens=16, pad_token_id=PAD, **kw):
+            full = super().generate(input_ids, attention_mask=attention_mask, max_new_tokens=max_new_tokens, pad_token_id=pad_token_id, **kw)
+            start = torch.full((input_ids.shape[0], 1), 2, dtype=torch.long)  # decoder_start_token_id
+            return torch.cat([start, full[:, input_ids.shape[1]:]], dim=1)
+
+    tok = CharTokenizer()
+    b = RequestBatcher(Seq2Seq(), pad_token_id=PAD, eos_token_id=EOS, max_batch=4, window_ms=50.0)
+    try:
+        prompts = ["a much longer prompt than the answer", "bc", "\x07"]  # the last one stops early (token sum 7)
+        futs = [b.submit(tok.encode(p), {"max_new_tokens": 5}) for p in prompts]
+        for p, f in zip(prompts, futs):
+            assert "".join(chr(t) for t in f.result(timeout=10)) == expected(tok.encode(p), 5), p
+    finally:
+        b.close()
+
+
+def test_rows_are_cut_at_any_of_the_models_eos_ids_and_trailing_padding_is_stripped():
+    """generation_config.eos_token_id may be a LIST and the pad id a different token (Llama-3 style): a row that ends on the
+    second EOS must be cut there (finish_reason "stop", completion_tokens without the padding)."""
+    import types
+
+    EOT, PAD2 = 3, 4
+
+    class M:
+        generation_config = types.SimpleNamespace(eos_token_id=[EOS, EOT])
+
+        def generate(self, input_ids, attention_mask=None, max_new_tokens=6, pad_token_id=PAD2, **kw):
+            rows = []
+            for r in range(input_ids.shape[0]):
+                new = [70, 71, EOT] + [pad_token_id] * (max_new_tokens - 3) if r == 0 else [72] * (max_new_tokens - 2) + [pad_token_id] * 2
+                rows.append(torch.tensor(new, dtype=torch.long))
+            return torch.cat([input_ids, torch.stack(rows)], dim=1)
+
+    b = RequestBatcher(M(), pad_token_id=PAD2, eos_token_id=EOS, max_batch=2, window_ms=100.0)
+    try:
+        f0, f1 = b.submit([65, 66], {"max_new_tokens": 6}), b.submit([67], {"max_new_tokens": 6})
+        assert f0.result(timeout=10) == [70, 71]           # cut at EOT, which is not the tokenizer's eos
+        assert f1.result(timeout=10) == [72, 72, 72, 72]   # no EOS: trailing pad tokens are not completion tokens
+    finally:
+        b.close()

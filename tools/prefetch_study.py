@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--seqs", type=int, default=8)
     ap.add_argument("--seq-len", type=int, default=10)
     ap.add_argument("--policies", default="", help="comma-separated subset of the policies")
+    ap.add_argument("--batch", type=int, default=1, help="decode batch: row i of a step belongs to a sequence of type (seq + i) %% types; ONE trace entry per batch")
+    ap.add_argument("--note", default="", help="free text copied into every result line (e.g. where --attn-us comes from)")
     args = ap.parse_args()
 
     from moe_infinity_amd import MoEEngine
@@ -72,7 +74,7 @@ def main():
     if args.policies:
         policies = tuple(args.policies.split(","))
     for policy_name in policies:
-        cfg = getattr(Cf, args.workload)(device_memory_ratio=0.5, max_tokens=1,
+        cfg = getattr(Cf, args.workload)(device_memory_ratio=0.5, max_tokens=args.batch,
                                          policy=Cf.POLICY_LRU if policy_name == "lru" else Cf.POLICY_LFU_INCACHE)
         cfg.num_layers = L
         E, K, H = cfg.num_experts, cfg.top_k, cfg.hidden
@@ -104,9 +106,10 @@ def main():
             gates.append(gw.to(eng.gate_dtype).to(dev))
 
         def x_of(seq, step, l):
-            x = acts(1, H, eng.dtype, 2024 + l + 1000 * step + 100000 * seq)
+            x = acts(args.batch, H, eng.dtype, 2024 + l + 1000 * step + 100000 * seq)
             x[:, : args.types] = 0.0
-            x[:, seq % args.types] = 1.0
+            for i in range(args.batch):
+                x[i, (seq + i) % args.types] = 1.0
             return x.to(dev)
 
         tracer = ExpertTracer(max(args.hist_seqs, 4), L, E)
@@ -135,7 +138,7 @@ def main():
         pf.set_archer_engine(eng)
         if policy_name.endswith("+governor"):
             eng.set_prefetch_governor(0.5, 16)
-        out = torch.empty(1, H, dtype=eng.dtype, device=dev)
+        out = torch.empty(args.batch, H, dtype=eng.dtype, device=dev)
         naive = policy_name.endswith("_all")
 
         def run_sequence(sid, steps, prefetch):
@@ -179,9 +182,10 @@ def main():
         eng.sync_copies()
         st = eng.stats()
         args.steps = args.seqs * args.seq_len
-        res = {"policy": policy_name, "workload": args.workload, "layers": L, "cache_slots": st["slots_total"], "experts": L * E,
+        res = {"policy": policy_name, "workload": args.workload, "batch": args.batch, "note": args.note, "layers": L, "cache_slots": st["slots_total"], "experts": L * E,
                "sequence_types": args.types, "sequences": args.seqs, "tokens": args.steps,
                "zipf": args.zipf, "attn_standin_us": round(one * reps, 1), "ms_per_token": round(el * 1e3 / args.steps, 3),
+               "compute_only_ms_per_token": round(L * one * reps / 1e3, 3),
                "hit_rate": round(st["expert_hits"] / max(1, st["expert_hits"] + st["expert_misses"]), 4),
                "misses": st["expert_misses"], "prefetch_issued": st["prefetch_issued"], "prefetch_useful": st["prefetch_useful"],
                "prefetch_throttled": st["prefetch_throttled"],
