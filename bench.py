@@ -354,7 +354,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         k1 = kernels["ffn_stage1"]
         traffic, traffic_src = (None, None)
         # batch-1 decode of the gated families runs the self-routing form of FFN stage 1
-        selfroute = (B == 1 and not use_ep and family in ("mixtral", "deepseek") and E <= 64
+        selfroute = (B == 1 and not use_ep and family in ("mixtral", "deepseek", "switch") and E <= 64
                      and os.environ.get("MOEINF_SELFROUTE", "1") != "0")
         if B == 1 and not use_ep:
             wl_key = workload.replace("-", "").replace(".", "")
@@ -364,8 +364,9 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 traffic, traffic_src = latest_pmc_traffic(wl_key, "ffn_rows_kernel<unsigned short, 2"
                                                           if family in ("mixtral", "deepseek") else "ffn_rows_kernel<")
         if k1:
-            kname = ("ffn1_selfroute_kernel: FFN stage 1 (gate/up rows of the chosen experts, SiLU*mul) with the token's top-k in its "
-                     "prologue" + (" and the shared expert's stage 2 riding along" if cfg.shared_inter else "")) if selfroute else \
+            kname = (("ffn1_selfroute_kernel: FFN stage 1 (wi rows of the chosen expert, ReLU) with the token's top-1 in its prologue" if family == "switch" else
+                      "ffn1_selfroute_kernel: FFN stage 1 (gate/up rows of the chosen experts, SiLU*mul) with the token's top-k in its "
+                      "prologue" + (" and the shared expert's stage 2 riding along" if cfg.shared_inter else ""))) if selfroute else \
                     "ffn_rows_kernel stage 1 (gate/up rows of the active experts, fused gather + act)"
             roof = {"bound": "hbm", "kernel": kname + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
@@ -493,7 +494,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             worst, max_abs, max_rel, mean_rel, acc_worst, acc_ratio = -v[1].item(), -v[2].item(), -v[3].item(), -v[4].item(), -v[5].item(), -v[6].item()
         parity = {"ok": bool(ok and exact and acc_ok and ranks_ok), "routing_bit_exact": bool(exact), "worst_err_over_bar": round(worst, 3),
                   "fp32_exact_arm": {"ok": bool(acc_ok), "mean_abs_gpu_vs_exact": float(f"{acc_gpu / n_pairs:.4e}"), "mean_abs_oracle_vs_exact": float(f"{acc_ref / n_pairs:.4e}"),
-                                     "ratio_over_the_sample": round(acc_ratio, 4), "worst_pair_ratio": round(acc_worst, 4), "bar": "every pair: mean|gpu - exact| <= 1.15 * mean|oracle - exact|",
+                                     "ratio_over_the_sample": round(acc_ratio, 4), "worst_pair_ratio": round(acc_worst, 4), "bar": f"every pair: mean|gpu - exact| <= {P.exact_arm_factor(dt)} * mean|oracle - exact|" + (" (fp32 model: summation order against fp64, oracle/parity.py exact_arm_factor)" if dt == torch.float32 else ""),
                                      "oracle_vs_exact_rel": float(f"{acc_ref / max(acc_scale, 1e-30):.3e}"),
                                      "exact": "the block in fp32 (fp64 for an fp32 model) on up-cast weights with the oracle's routing: nothing rounded to the model dtype after the router"},
                   "max_abs_err": float(f"{max_abs:.3e}"), "max_rel_err": float(f"{max_rel:.3e}"), "mean_rel_err": float(f"{mean_rel:.3e}"),

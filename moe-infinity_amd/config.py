@@ -81,10 +81,10 @@ class EngineConfig:
         return asdict(self)
 
 
-def mixtral_8x7b(**kw):
-    """Mixtral-8x7B shapes: H=4096 F=14336 E=8 K=2 L=32 bf16."""
+def mixtral_8x7b(dtype=DTYPE_BF16, **kw):
+    """Mixtral-8x7B shapes: H=4096 F=14336 E=8 K=2 L=32 bf16 (dtype=DTYPE_F16: fp16 experts)."""
     return EngineConfig(num_layers=32, num_experts=8, expert_type=EXPERT_MIXTRAL, hidden=4096, inter=14336, top_k=2,
-                        router_kind=ROUTER_MIXTRAL, dtype=DTYPE_BF16, **kw)
+                        router_kind=ROUTER_MIXTRAL, dtype=dtype, **kw)
 
 
 def deepseek_v2_lite(**kw):

@@ -358,13 +358,16 @@ static int validate(const moeinf_config* c) {
   if (!c) return fail(MOEINF_ERR_INVALID, "cfg is NULL");
   if (c->abi_version != MOEINF_ABI_VERSION) return fail(MOEINF_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOEINF_ABI_VERSION);
   if (c->num_layers <= 0 || c->num_experts <= 0 || c->num_experts > 256) return fail(MOEINF_ERR_INVALID, "num_layers/num_experts out of range (experts <= 256)");
-  if (c->dtype != MOEINF_DTYPE_BF16 && c->dtype != MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "dtype %d: only bf16 (0) and fp32 (1) are built", c->dtype);
-  if (c->gate_dtype != MOEINF_DTYPE_BF16 && c->gate_dtype != MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "gate_dtype %d", c->gate_dtype);
+  if (c->dtype != MOEINF_DTYPE_BF16 && c->dtype != MOEINF_DTYPE_F32 && c->dtype != MOEINF_DTYPE_F16) return fail(MOEINF_ERR_UNSUPPORTED, "dtype %d: bf16 (0), fp32 (1) and fp16 (2) are built (fp8, id 3, is not)", c->dtype);
+  if (c->gate_dtype != MOEINF_DTYPE_BF16 && c->gate_dtype != MOEINF_DTYPE_F32 && c->gate_dtype != MOEINF_DTYPE_F16) return fail(MOEINF_ERR_UNSUPPORTED, "gate_dtype %d", c->gate_dtype);
+  // the gate is either in the model dtype or fp32 (DeepSeek); bf16 <-> fp16 mixes are not built
+  if (c->gate_dtype != MOEINF_DTYPE_F32 && c->dtype != MOEINF_DTYPE_F32 && c->gate_dtype != c->dtype) return fail(MOEINF_ERR_UNSUPPORTED, "gate_dtype %d with dtype %d", c->gate_dtype, c->dtype);
+  if (c->gate_dtype == MOEINF_DTYPE_F16 && c->dtype == MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "an fp16 gate with fp32 activations is not built");
   switch (c->expert_type) {
     case MOEINF_EXPERT_SWITCH: case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: case MOEINF_EXPERT_MIXTRAL: case MOEINF_EXPERT_DEEPSEEK: break;
     default: return fail(MOEINF_ERR_UNSUPPORTED, "expert_type %d is not built (switch-gated/gelu is outside BASELINE's configs)", c->expert_type);
   }
-  const int ev = c->dtype == MOEINF_DTYPE_BF16 ? 8 : 4;
+  const int ev = c->dtype == MOEINF_DTYPE_F32 ? 4 : 8;
   if (c->hidden <= 0 || c->inter <= 0 || c->hidden % ev || c->inter % ev) return fail(MOEINF_ERR_INVALID, "hidden/inter must be positive multiples of %d", ev);
   if (c->shared_inter < 0 || c->shared_inter % ev) return fail(MOEINF_ERR_INVALID, "shared_inter must be a multiple of %d", ev);
   if (c->top_k <= 0 || c->top_k > 8 || c->top_k > c->num_experts) return fail(MOEINF_ERR_INVALID, "top_k must be in 1..min(8,E)");
@@ -475,8 +478,8 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   for (int i = 0; i < kFenceRing; ++i) g->fence_ev[i] = nullptr;
   g->L = cfg->num_layers; g->E = cfg->num_experts; g->K = cfg->top_k; g->H = cfg->hidden; g->F = cfg->inter; g->Fs = cfg->shared_inter;
   g->has_shared = cfg->shared_inter > 0;
-  g->dt = cfg->dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
-  g->es = g->dt == DT_BF16 ? 2 : 4;
+  g->dt = cfg->dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : (cfg->dtype == MOEINF_DTYPE_F16 ? DT_F16 : DT_F32);
+  g->es = dt_bytes(g->dt);
   g->lay = make_layout(cfg->expert_type, g->H, g->F, g->es);
   if (g->has_shared) g->lay_sh = make_layout(cfg->expert_type, g->H, g->Fs, g->es);
   g->dlay = make_dev_layout(cfg->expert_type, g->H, g->F, g->dt, g->es);
@@ -1373,7 +1376,7 @@ static void make_route_args(const moeinf_engine* g, const void* x_dev, const voi
   memset(&ra, 0, sizeof ra);
   ra.x = x_dev; ra.gate_w = gate_w_dev; ra.logits = g->d_logits;
   ra.T = T; ra.H = g->H; ra.E = g->E; ra.K = g->K;
-  ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : DT_F32;
+  ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : (g->cfg.gate_dtype == MOEINF_DTYPE_F16 ? DT_F16 : DT_F32);
   ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
   ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
   ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
@@ -1466,9 +1469,13 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // itself from the gate logits (ffn1_selfroute_kernel) and one extra block of it writes the routing outputs
   static const bool selfroute_env = getenv("MOEINF_SELFROUTE") ? atoi(getenv("MOEINF_SELFROUTE")) != 0 : true;
   const int et_ = g->cfg.expert_type;
-  const bool selfroute = selfroute_env && !route_only && mp.fast && T == 1 && K <= 8 && E <= 64 && g->dt == DT_BF16 && !g->ovr_out &&
-                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
-                         (et_ == MOEINF_EXPERT_MIXTRAL || et_ == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || hide_shared);
+  const bool sr_gated = g->dt != DT_F32 &&
+                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
+                        (et_ == MOEINF_EXPERT_MIXTRAL || et_ == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || hide_shared);
+  // (round 4) Switch: top-1, plain ReLU experts, bf16 or fp32; a single token can never exceed the per-row capacity
+  const bool sr_switch = g->cfg.router_kind == MOEINF_ROUTER_SWITCH && et_ == MOEINF_EXPERT_SWITCH && K == 1 && !g->has_shared &&
+                         (flags & MOEINF_FWD_NO_COMBINE) == 0 && ia.capacity != 0 && fuse_mode() != 0;
+  const bool selfroute = selfroute_env && !route_only && mp.fast && T == 1 && K <= 8 && E <= 64 && !g->ovr_out && (sr_gated || sr_switch);
   g->last_selfroute = selfroute;
   FfnStage sh1, sh2;
   if (hide_shared) {
@@ -1513,7 +1520,8 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // rides in the epilogue of FFN stage 2
   static const bool fuse_combine = getenv("MOEINF_FUSE_COMBINE") ? atoi(getenv("MOEINF_FUSE_COMBINE")) != 0 : true;
   const bool can_fuse = fuse_combine && want_combine && T <= 16 &&
-                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK);
+                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK ||
+                         (selfroute && sr_switch));  // (Switch: only the batch-1 stage 2 knows its combine)
   bool fused = false;
   SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ep_pack_compact_kernel(EpPackArgs a, int 
   for (int h = threadIdx.x * EPV; h < a.H; h += 256 * EPV) *reinterpret_cast<u32x4*>(dst + h) = ld16(src + h);
 }
 hipError_t launch_ep_pack_compact(const EpPackArgs& a, int n_pairs, hipStream_t st) {
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_compact_kernel<uint16_t>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
+  if (a.dtype != DT_F32) hipLaunchKernelGGL(ep_pack_compact_kernel<uint16_t>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
   else hipLaunchKernelGGL(ep_pack_compact_kernel<float>, dim3(n_pairs), dim3(256), 0, st, a, n_pairs);
   return hipGetLastError();
 }
@@ -114,14 +114,14 @@ static EpPeers no_peers() {
 }
 hipError_t launch_ep_pack_small(const EpPackArgs& a, const int32_t* pair_valid, int n_pairs, int32_t* send_counts, hipStream_t st, const EpPeers* peers) {
   const EpPeers pv = peers ? *peers : no_peers();
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_small_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts, pv);
+  if (a.dtype != DT_F32) hipLaunchKernelGGL(ep_pack_small_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts, pv);
   else hipLaunchKernelGGL(ep_pack_small_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pair_valid, n_pairs, send_counts, pv);
   return hipGetLastError();
 }
 
 hipError_t launch_ep_pack(const EpPackArgs& a, hipStream_t st, const EpPeers* peers) {
   const EpPeers pv = peers ? *peers : no_peers();
-  if (a.dtype == DT_BF16) hipLaunchKernelGGL(ep_pack_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pv);
+  if (a.dtype != DT_F32) hipLaunchKernelGGL(ep_pack_kernel<uint16_t>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pv);
   else hipLaunchKernelGGL(ep_pack_kernel<float>, dim3(a.ep_size * a.cap_rows), dim3(256), 0, st, a, pv);
   return hipGetLastError();
 }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void ep_push_kernel(const void* y, const void*
 }
 hipError_t launch_ep_push(const void* y, const void* recv, int64_t ld_recv, int H, int dtype, const EpPeers& peers, hipStream_t st) {
   const dim3 grid(peers.size * peers.cap_rows);
-  if (dtype == DT_BF16) hipLaunchKernelGGL(ep_push_kernel<uint16_t>, grid, dim3(256), 0, st, y, recv, ld_recv, H, peers);
+  if (dtype != DT_F32) hipLaunchKernelGGL(ep_push_kernel<uint16_t>, grid, dim3(256), 0, st, y, recv, ld_recv, H, peers);
   else hipLaunchKernelGGL(ep_push_kernel<float>, grid, dim3(256), 0, st, y, recv, ld_recv, H, peers);
   return hipGetLastError();
 }
@@ -290,12 +290,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_ep_kernel(FfnStage s, EpOwnArgs o
 hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st) {
   const dim3 grid((s.R + 15) / 16 + ((o.stage == 1 && o.mirror) ? 1 : 0), o.max_active);
   const bool gated = (s.epi == EPI_GATED_SILU);
-  const size_t kbytes = (size_t)s.K * (s.dtype == DT_BF16 ? 2 : 4);
+  const size_t kbytes = (size_t)s.K * dt_bytes(s.dtype);
   const bool nw8 = kbytes >= 16384;  // long reductions: 8 waves per workgroup (as launch_ffn_stage)
 #define EPK(TT, NM, NWV) hipLaunchKernelGGL((ffn_ep_kernel<TT, NM, NWV, 4>), grid, dim3(NWV * 64), 0, st, s, o)
   if (s.dtype == DT_BF16) {
     if (gated) { if (nw8) EPK(uint16_t, 2, 8); else EPK(uint16_t, 2, 4); }
     else       { if (nw8) EPK(uint16_t, 1, 8); else EPK(uint16_t, 1, 4); }
+  } else if (s.dtype == DT_F16) {
+    if (gated) { if (nw8) EPK(half_t, 2, 8); else EPK(half_t, 2, 4); }
+    else       { if (nw8) EPK(half_t, 1, 8); else EPK(half_t, 1, 4); }
   } else {
     if (gated) { if (nw8) EPK(float, 2, 8); else EPK(float, 2, 4); }
     else       { if (nw8) EPK(float, 1, 8); else EPK(float, 1, 4); }

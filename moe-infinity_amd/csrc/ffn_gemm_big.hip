@@ -31,7 +31,7 @@
 
 namespace moeinf {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef f32x16_ f32x16;
 
 // the fragment reads of k-step J of a stage (ping-pong loop below) as inline asm, into register set J & 1
 template <int NMAT, int RT, int RGB, int J>
@@ -52,9 +52,8 @@ __device__ __forceinline__ void big_read_frags(u32x4 (&af)[2][NMAT][RT], u32x4 (
 // s_barrier, so the four weight DMAs of stage s+1 stay in flight across the barrier that opens stage s (weights come
 // from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
 // into slots that are already consumed, so the count never varies.
-template <int NMAT, bool RING3, int MODE>
+template <typename T, int NMAT, bool RING3, int MODE>  // T: uint16_t = bf16, half_t = fp16 (the same tiles, the f16 matrix instruction)
 __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map, int tail_max, int chunk) {
-  typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
   constexpr int RGB = 16 / NMAT;   // row groups (16 rows) of EACH matrix per block
   constexpr int RT = 4 / NMAT;     // 32-row tiles of each matrix per wave
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
           for (int c = 0; c < 4; ++c) {
             if (c < nct) {
               const u32x4 bfr = *reinterpret_cast<const u32x4*>(bb + c * 4096 + ch);
-              acc[0][c >> 1][c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc[0][c >> 1][c & 1], 0, 0, 0);
+              acc[0][c >> 1][c & 1] = mma32<T>(af, bfr, acc[0][c >> 1][c & 1]);
             }
           }
         }
@@ -290,8 +289,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
-                acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
-                                                                         acc[m][rt][tt], 0, 0, 0);
+                acc[m][rt][tt] = mma32<T>(af[j & 1][m][rt], bf[j & 1][tt], acc[m][rt][tt]);
                 // the stage's eight DMAs ride in the COMPUTE slots, one behind every fourth MFMA (32 matrix-pipe cycles
                 // each cover the issue): in the LOAD slot they would lengthen the slot the matrix pipe waits for
                 const int idx = (m * RT + rt) * 2 + tt;
@@ -368,8 +366,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-              acc[m][rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j & 1][m][rt]), __builtin_bit_cast(bf16x8, bf[j & 1][tt]),
-                                                                       acc[m][rt][tt], 0, 0, 0);
+              acc[m][rt][tt] = mma32<T>(af[j & 1][m][rt], bf[j & 1][tt], acc[m][rt][tt]);
               {
                 // one DMA behind every fourth MFMA: all eight waves issuing their eight DMAs at the top of the stage queue
                 // up at the CU's one address unit (64 x 1 KiB at 64 B/clk ~ 1 000 cycles) with nothing in the matrix pipe —
@@ -485,10 +482,11 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
             uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int h2 = 0; h2 < 4; ++h2) {
-              float lo = __uint_as_float(w4[h2] << 16), hi = __uint_as_float(w4[h2] & 0xffff0000u);
+              float lo, hi;
+              DT<T>::unpack2(w4[h2], lo, hi);
               if (has_bias) { lo += bias8[h2 * 2]; hi += bias8[h2 * 2 + 1]; }
               if (has_relu) { lo = fmaxf(DT<T>::round(lo), 0.f); hi = fmaxf(DT<T>::round(hi), 0.f); }
-              w4[h2] = f2bf2(lo, hi);
+              w4[h2] = DT<T>::pack2(lo, hi);
             }
             v = u32x4{w4[0], w4[1], w4[2], w4[3]};
           }
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
-              if (orow0 + jj < R) op[jj] = (T)(w4[jj >> 1] >> ((jj & 1) * 16));
+              if (orow0 + jj < R) op[jj] = DT<T>::from_bits((uint16_t)(w4[jj >> 1] >> ((jj & 1) * 16)));
           }
         }
       }
@@ -509,7 +507,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
 
 // max_rows: (an estimate of) the rows of the busiest expert; the kernel's pass loop covers more
 bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st) {
-  if (s.dtype != DT_BF16 || (s.K % 64) != 0 || (s.K_sh % 64) != 0 || (s.ld_out % 8) != 0) return false;  // 16-byte row stores
+  if (s.dtype == DT_F32 || (s.K % 64) != 0 || (s.K_sh % 64) != 0 || (s.ld_out % 8) != 0) return false;  // 16-byte row stores
   if ((nmat == 2) != (s.epi == EPI_GATED_SILU)) return false;
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   const int passes = max_rows <= 256 ? 1 : (max_rows + 255) / 256;
@@ -521,7 +519,12 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
   static const int tail_max = env_int("MOEINF_GEMM_BIG_TAIL", 128);  // tokens up to which a last pass runs the short-pass variant (0: never)
   static const int mode = env_int("MOEINF_GEMM_BIG_MODE", 2);  // 2: ping-pong (the two waves of a SIMD alternate load / compute slots), 1: both in step
-#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk)
+#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<uint16_t, NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk)
+  if (s.dtype == DT_F16) {  // fp16 experts: the default schedule only (three-deep weight ring, ping-pong)
+    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 2, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk);
+    else hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 1, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk);
+    return true;
+  }
   if (ring3) {
     if (mode == 2) { if (nmat == 2) BIGGO(2, true, 2); else BIGGO(1, true, 2); }
     else { if (nmat == 2) BIGGO(2, true, 1); else BIGGO(1, true, 1); }

@@ -41,6 +41,16 @@ __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// fp16 storage (the reference's expert dtype id 2, core/parallel/expert_module.h:20-23): _Float16 is a distinct 2-byte type,
+// so the kernel templates tell it from bf16 (uint16_t); conversions are the hardware's (v_cvt_f16_f32 / v_cvt_f32_f16, RNE)
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }
+// round a router quantity to the MODEL dtype (DT_BF16 / DT_F16; DT_F32: unchanged)
+__device__ __forceinline__ float round_model(int dtype, float f) {
+  return dtype == 0 /*DT_BF16*/ ? bf2f(f2bf(f)) : (dtype == 2 /*DT_F16*/ ? h2f(f2h(f)) : f);
+}
 // Device-coherent accessors for data handed between workgroups INSIDE one launch (fused combine / fused router):
 // relaxed agent-scope atomics compile to sc1 loads/stores that write through / miss the per-XCD L2 for lines it
 // does not own, so no agent-scope fence (= a full L2 write-back + invalidate, tens of us on 8 XCDs) is needed;
@@ -137,6 +147,10 @@ struct DT<uint16_t> {  // bf16 storage
     o[0] = __uint_as_float(x << 16); o[1] = __uint_as_float(x & 0xffff0000u);
     o[2] = __uint_as_float(y << 16); o[3] = __uint_as_float(y & 0xffff0000u);
   }
+  // two elements in one 32-bit word (low half first), and one element from its bit pattern
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf2(lo, hi); }
+  __device__ static __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+  __device__ static __forceinline__ uint16_t from_bits(uint16_t b) { return b; }
   __device__ static __forceinline__ void store_coherent(uint16_t* p, float f) { st_coherent(p, f2bf(f)); }
   __device__ static __forceinline__ void store_system(uint16_t* p, float f) { st_system(p, f2bf(f)); }
   __device__ static __forceinline__ void store4(uint16_t* p, const float f[4]) {
@@ -144,6 +158,41 @@ struct DT<uint16_t> {  // bf16 storage
     v.x = f2bf2(f[0], f[1]);
     v.y = f2bf2(f[2], f[3]);
     *reinterpret_cast<uint2*>(p) = v;
+  }
+};
+template <>
+struct DT<half_t> {  // fp16 storage
+  static constexpr int EPV = 8;
+  __device__ static __forceinline__ float round(float f) { return h2f(f2h(f)); }
+  __device__ static __forceinline__ float load(const half_t* p) { return h2f(*p); }
+  __device__ static __forceinline__ void store(half_t* p, float f) { *p = f2h(f); }
+  __device__ static __forceinline__ void load4(const half_t* p, float o[4]) {
+    const half4_t v = *reinterpret_cast<const half4_t*>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+  }
+  struct Raw4 { unsigned long long v; };
+  template <bool COH>
+  __device__ static __forceinline__ Raw4 fetch4(const half_t* p) {
+    Raw4 r;
+    r.v = COH ? ld_coherent(reinterpret_cast<const unsigned long long*>(p)) : *reinterpret_cast<const unsigned long long*>(p);
+    return r;
+  }
+  __device__ static __forceinline__ void unpack4(const Raw4& r, float o[4]) {
+    const half4_t v = __builtin_bit_cast(half4_t, r.v);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+  }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, f2h(lo)) | ((uint32_t)__builtin_bit_cast(uint16_t, f2h(hi)) << 16);
+  }
+  __device__ static __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    lo = h2f(__builtin_bit_cast(half_t, (uint16_t)(w & 0xffffu))); hi = h2f(__builtin_bit_cast(half_t, (uint16_t)(w >> 16)));
+  }
+  __device__ static __forceinline__ half_t from_bits(uint16_t b) { return __builtin_bit_cast(half_t, b); }
+  __device__ static __forceinline__ void store_coherent(half_t* p, float f) { st_coherent(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, f2h(f))); }
+  __device__ static __forceinline__ void store_system(half_t* p, float f) { st_system(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, f2h(f))); }
+  __device__ static __forceinline__ void store4(half_t* p, const float f[4]) {
+    const half4_t v = {f2h(f[0]), f2h(f[1]), f2h(f[2]), f2h(f[3])};
+    *reinterpret_cast<half4_t*>(p) = v;
   }
 };
 template <>
@@ -238,6 +287,24 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 template <>
 __device__ __forceinline__ void mma16<uint16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<half_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+// 32x32x16 (the compute-bound GEMM, ffn_gemm_big.hip): 16 accumulator floats per lane
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+template <typename T>
+__device__ __forceinline__ f32x16_ mma32(const u32x4& a, const u32x4& b, const f32x16_& acc);
+template <>
+__device__ __forceinline__ f32x16_ mma32<uint16_t>(const u32x4& a, const u32x4& b, const f32x16_& acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16_ mma32<half_t>(const u32x4& a, const u32x4& b, const f32x16_& acc) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -531,6 +598,13 @@ __device__ __forceinline__ void load8<uint16_t>(const uint16_t* p, float out[8])
   }
 }
 template <>
+__device__ __forceinline__ void load8<half_t>(const half_t* p, float out[8]) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  const f16x8 v = __builtin_bit_cast(f16x8, ld16(p));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (float)v[j];
+}
+template <>
 __device__ __forceinline__ void load8<float>(const float* p, float out[8]) {
   const u32x4 a = ld16(p), b = ld16(p + 4);
 #pragma unroll
@@ -569,7 +643,7 @@ __device__ __forceinline__ void gate_body(const XT* __restrict__ x, const WT* __
   if (tid < TT && t0 + tid < T) {
     const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     float f = (float)v;
-    if (round_bf16) f = bf2f(f2bf(f));
+    if (round_bf16 == 1) f = bf2f(f2bf(f)); else if (round_bf16 == 2) f = h2f(f2h(f));  // (1: bf16, 2: fp16 — the model dtype of Mixtral's gate)
     logits[(size_t)(t0 + tid) * E + e] = f;
   }
 }
@@ -687,7 +761,7 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
 #pragma unroll
   for (int j = 0; j < 4; ++j) p[j] = p[j] / ssum;
 
-  const bool x_bf16 = (a.x_dtype == DT_BF16);
+  const int xdt = a.x_dtype;  // the model dtype: quantities the reference keeps in it are rounded to it
   int sel[8];
   float val[8];
   int valid[8];
@@ -739,14 +813,14 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
   } else if (a.kind == 2 /*SWITCH*/) {
     float pin[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pin[j] = x_bf16 ? bf2f(f2bf(p[j])) : p[j];
+    for (int j = 0; j < 4; ++j) pin[j] = round_model(xdt, p[j]);
     float bv; int bi;
     pick_best(pin, 0u, lane, E, bv, bi);
     sel[0] = bi; val[0] = bv;
   } else {  /*NLLB*/
     float pin[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pin[j] = x_bf16 ? bf2f(f2bf(p[j])) : p[j];
+    for (int j = 0; j < 4; ++j) pin[j] = round_model(xdt, p[j]);
     float bv; int bi;
     pick_best(pin, 0u, lane, E, bv, bi);  // top-1 over probabilities cast to the input dtype
     sel[0] = bi; val[0] = bv;
@@ -770,7 +844,7 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
   if (a.kind == 0) {
     float den = 0.f;
     for (int k = 0; k < K; ++k) den += val[k];
-    for (int k = 0; k < K; ++k) { w[k] = val[k] / den; if (x_bf16) w[k] = bf2f(f2bf(w[k])); }
+    for (int k = 0; k < K; ++k) w[k] = round_model(xdt, val[k] / den);
   } else if (a.kind == 1) {
     if (K > 1 && a.norm_topk_prob) {
       float den = 0.f;
@@ -784,12 +858,11 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
     w[0] = val[0];
   } else {
     // normalize_router_probabilities in the input dtype (nllb router, eval: capacity never drops)
-    const float eps = x_bf16 ? 0.0078125f : 1.1920928955078125e-07f;
-    float den = val[0] + val[1];
-    if (x_bf16) den = bf2f(f2bf(den));
+    const float eps = xdt == DT_BF16 ? 0.0078125f : (xdt == DT_F16 ? 0.0009765625f : 1.1920928955078125e-07f);  // torch.finfo(dtype).eps
+    float den = round_model(xdt, val[0] + val[1]);
     den = fmaxf(den, eps);
     w[0] = val[0] / den; w[1] = val[1] / den;
-    if (x_bf16) { w[0] = bf2f(f2bf(w[0])); w[1] = bf2f(f2bf(w[1])); }
+    w[0] = round_model(xdt, w[0]); w[1] = round_model(xdt, w[1]);
     valid[0] = (w[0] != 0.f); valid[1] = (w[1] != 0.f);  // router_mask = combining_weights.bool()
   }
 
@@ -1050,13 +1123,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   r = max(r, (uint32_t)__builtin_amdgcn_readlane((int)v, 48));
   return r;
 }
-__device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ logits, const int E, const int K, const int lane) {
+// round_p_dtype: Switch's top-1 runs on probabilities cast to the model's dtype (route_core, kind 2)
+__device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ logits, const int E, const int K, const int lane, const int round_p_dtype = 1 /*DT_F32: none*/) {
   const bool in = lane < E;
   const float l = in ? logits[lane] : -INFINITY;
   const float m = wave_max(l);
   float p = in ? expf(l - m) : 0.f;
   const float ssum = wave_sum(p);
   p = p / ssum;
+  p = round_model(round_p_dtype, p);
   const uint32_t key = in ? __float_as_uint(p) : 0u;
   uint64_t chosen = 0, avail = __ballot(in);
   for (int k = 0; k < K && avail; ++k) {
@@ -1129,7 +1204,7 @@ __device__ __forceinline__ void ep_pack_block(const EpPackArgs& a, const EpPeers
   }
 }
 __device__ __forceinline__ void ep_pack_block_dt(const EpFuse& f, const int n_pairs, int* s_row) {
-  if (f.a.dtype == DT_BF16) ep_pack_block<uint16_t>(f.a, f.peers, f.pair_valid, n_pairs, f.send_counts, s_row);
+  if (f.a.dtype != DT_F32) ep_pack_block<uint16_t>(f.a, f.peers, f.pair_valid, n_pairs, f.send_counts, s_row);  // (a row copy: any 2-byte dtype)
   else ep_pack_block<float>(f.a, f.peers, f.pair_valid, n_pairs, f.send_counts, s_row);
 }
 

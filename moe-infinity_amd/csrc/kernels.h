@@ -6,7 +6,8 @@
 
 namespace moeinf {
 
-enum { DT_BF16 = 0, DT_F32 = 1 };
+enum { DT_BF16 = 0, DT_F32 = 1, DT_F16 = 2 };  // = the reference's dtype ids (core/parallel/expert_module.h:20-23)
+inline int dt_bytes(int dtype) { return dtype == DT_F32 ? 4 : 2; }
 struct EpFuse;
 
 // ---- direct peer-store exchange (expert parallelism without a collective; host side: ep_peer.h) ------------------
@@ -106,7 +107,7 @@ struct FfnStage {
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
 // row-major [R,K] -> MFMA A-operand tiles (see kernels.hip); dst needs tiled_bytes(R,K) bytes
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st);
-inline int64_t tiled_bytes(int64_t R, int64_t K, int dtype) { const int64_t ept = dtype == DT_BF16 ? 32 : 16; return ((R + 15) / 16) * ((K + ept - 1) / ept) * 1024; }
+inline int64_t tiled_bytes(int64_t R, int64_t K, int dtype) { const int64_t ept = dtype == DT_F32 ? 16 : 32; return ((R + 15) / 16) * ((K + ept - 1) / ept) * 1024; }
 
 struct RouteArgs {
   const void* x;        // [T,H] dtype x_dtype

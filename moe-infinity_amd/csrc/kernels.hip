@@ -14,6 +14,8 @@
 // are reproduced (Tr() below) so results match its CPU path to accumulation-order noise.
 #include "kdev.h"
 
+#include <type_traits>
+
 #include <string.h>
 
 namespace moeinf {
@@ -43,9 +45,9 @@ __global__ __launch_bounds__(256) void retile_kernel(const T* __restrict__ src, 
   *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = v;
 }
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st) {
-  const int ept = dtype == DT_BF16 ? 32 : 16;
+  const int ept = dtype == DT_F32 ? 16 : 32;
   dim3 grid(((K + ept - 1) / ept + 3) / 4, (R + 15) / 16);
-  if (dtype == DT_BF16) hipLaunchKernelGGL(retile_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, (char*)dst, R, K);
+  if (dtype != DT_F32) hipLaunchKernelGGL(retile_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, (char*)dst, R, K);
   else hipLaunchKernelGGL(retile_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (char*)dst, R, K);
   return hipGetLastError();
 }
@@ -95,12 +97,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
 // grouped GEMM variants for experts with many rows (ffn_gemm.hip); false: not handled (MOEINF_FFN_GEMM=0)
 template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st);
+bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st);  // ffn_gemm_big.hip (bf16, fp16)
 
 template <typename T, int NMAT>
 static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, int max_rows, hipStream_t st) {
 #define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
   if (many_tokens) {  // grouped GEMM kernels (ffn_gemm.hip); MOEINF_FFN_GEMM=0: the decode kernel looping 4 token tiles
-    if (launch_ffn_gemm<T, NMAT>(s, grid, max_rows, st)) return;
+    if constexpr (sizeof(T) == 2 && !std::is_same<T, uint16_t>::value) {
+      // fp16 experts: of the GEMM kernels only the 256 x 256 one is built for the f16 matrix instruction; it takes over from
+      // 65 rows per expert (below that the decode kernel looping token tiles re-streams the weights at most 4 times)
+      if (max_rows > 64 && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return;
+    } else {
+      if (launch_ffn_gemm<T, NMAT>(s, grid, max_rows, st)) return;
+    }
     if (nw == 8) LAUNCH(8, 1, 4); else LAUNCH(4, 1, 4);
     return;
   }
@@ -117,7 +126,7 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   const bool gated = (s.epi == EPI_GATED_SILU);
   // long reductions get 8 waves per block (more bytes in flight per CU), short ones 4
   const int kmax = s.K > s.K_sh ? s.K : s.K_sh;
-  const size_t kbytes = (size_t)kmax * (s.dtype == DT_BF16 ? 2 : 4);
+  const size_t kbytes = (size_t)kmax * dt_bytes(s.dtype);
   // ... and a grid of at most one workgroup per CU (Switch-base-8 at batch 1: 192 / 48 workgroups for 256 CUs) SIXTEEN: a CU
   // that owns a single work item has nothing else to hide its load latency behind, so the whole item goes in flight at
   // once (round 4: stage 2 of Switch-base-8 streamed 9.45 MB in 16.8 us = 0.07 of HBM peak with 48 four-wave workgroups)
@@ -132,6 +141,8 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   const bool many = s.fuse_combine ? false : (env_nt ? env_nt > 1 : max_rows_per_expert > many_rows);
   if (s.dtype == DT_BF16) {
     if (gated) launch_ffn_t<uint16_t, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<uint16_t, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
+  } else if (s.dtype == DT_F16) {
+    if (gated) launch_ffn_t<half_t, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<half_t, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   } else {
     if (gated) launch_ffn_t<float, 2>(s, grid, nw, u, many, max_rows_per_expert, st); else launch_ffn_t<float, 1>(s, grid, nw, u, many, max_rows_per_expert, st);
   }
@@ -167,7 +178,8 @@ __global__ __launch_bounds__(256) void gate_shared1_kernel(const XT* __restrict_
 
 // Mixtral's gate is an nn.Linear in the model dtype (mixtral.py:46): its output is rounded to
 // that dtype.  The other routers compute fp32 logits from (exactly) up-cast inputs.
-static inline int gate_rounds_bf16(const RouteArgs& a) { return (a.kind == 0 /*MIXTRAL*/ && a.x_dtype == DT_BF16) ? 1 : 0; }
+// (1: to bf16, 2: to fp16, 0: fp32 logits)
+static inline int gate_rounds_bf16(const RouteArgs& a) { return a.kind != 0 /*MIXTRAL*/ ? 0 : (a.x_dtype == DT_BF16 ? 1 : (a.x_dtype == DT_F16 ? 2 : 0)); }
 
 hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_t st) {
   constexpr int TT = 4;
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const XT* __restr
     const int t = t0 + q + 4 * v;
     if (t < T && e < E) {
       float f = (float)(((acc[v] + red[0][lane][v]) + red[1][lane][v]) + red[2][lane][v]);
-      if (round_bf16) f = bf2f(f2bf(f));
+      if (round_bf16 == 1) f = bf2f(f2bf(f)); else if (round_bf16 == 2) f = h2f(f2h(f));
       logits[(size_t)t * E + e] = f;
     }
   }
@@ -245,7 +257,8 @@ hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
   if (mfma_tiles > 0 && (int64_t)((a.T + 15) / 16) * ((a.E + 15) / 16) >= mfma_tiles && (a.H & 63) == 0) {
     const dim3 g16((a.T + 15) / 16, (a.E + 15) / 16);
 #define GM(XT, WT) hipLaunchKernelGGL((gate_logits_mfma_kernel<XT, WT>), g16, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
-    if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GM(uint16_t, uint16_t);
+    if (a.x_dtype == DT_F16) { if (a.gate_dtype == DT_F16) GM(half_t, half_t); else GM(half_t, float); }
+    else if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GM(uint16_t, uint16_t);
     else if (a.x_dtype == DT_BF16) GM(uint16_t, float);
     else if (a.gate_dtype == DT_BF16) GM(float, uint16_t);
     else GM(float, float);
@@ -253,7 +266,8 @@ hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
     return hipGetLastError();
   }
 #define GL(XT, WT) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
-  if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
+  if (a.x_dtype == DT_F16) { if (a.gate_dtype == DT_F16) GL(half_t, half_t); else GL(half_t, float); }
+  else if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
   else if (a.x_dtype == DT_BF16) GL(uint16_t, float);
   else if (a.gate_dtype == DT_BF16) GL(float, uint16_t);
   else GL(float, float);
@@ -458,12 +472,14 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
 // 96, and 256-thread blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) (MI355X_MICROARCH.md): 106 SGPRs
 // = 6 blocks per CU.  No VGPR cap: 76 VGPRs = 6 workgroups per CU is more than either model uses (a 72-VGPR cap for 7
 // per CU spilled 12 bytes per thread = 2 MB of scratch writes per launch, for nothing once four per CU proved best).
-template <typename T, int NW, int U>
+// NMAT = 2: the gated families (Mixtral, DeepSeek); NMAT = 1 (round 4): Switch's plain ReLU experts, top-1 — the same three
+// launches per layer (gate, this, ffn2_decode1) instead of five (gate, route_index, two FFN stages, combine).
+template <typename T, int NMAT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void ffn1_selfroute_kernel(RouteArgs r, IndexArgs a, FfnStage s, FfnStage sh2, int n_rg, int n_sh2) {
-  __shared__ float red[NW][2][256];
+  __shared__ float red[NW][NMAT][256];
   __shared__ unsigned long long sh_w;
   __shared__ int sh_rank_ok;
-  static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
+  static_assert(sizeof(float) * NW * NMAT * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
   const int lane = threadIdx.x & 63;
   const int K = r.K, E = r.E;
   // block 0 is the meta block: it must be dispatched FIRST — when the grid exceeds one resident wave of blocks
@@ -501,7 +517,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
     // independent first round: the token's logits and all blob pointers
     uint64_t wp = 0;
     if (lane < E) wp = s.wptr[lane];
-    uint64_t chosen = route_set_lean(r.logits, E, K, lane);
+    uint64_t chosen = route_set_lean(r.logits, E, K, lane, r.kind == 2 /*SWITCH*/ ? r.x_dtype : DT_F32);
     for (int i = 0; i < u; ++i) chosen &= chosen - 1;  // drop the u smallest ids
     const int e = chosen ? (int)__builtin_ctzll(chosen) : -1;
     uint64_t wsel = 0;
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
     return;
   }
   // T == 1: expert-sorted row of (token 0, expert e) = its rank u; the B operand is token 0
-  ffn_rows_item<T, 2, NW, U, 1>(s, rg, W, false, 1, u, red, 0);
+  ffn_rows_item<T, NMAT, NW, U, 1>(s, rg, W, false, 1, u, red, 0);
 }
 
 hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st) {
@@ -537,8 +553,21 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
   // workgroups, 1.035 -> 1.009 ms/token), 4 for multi-round grids (Mixtral: 1793 workgroups at four per CU)
   static const int sr_u_env = env_int("MOEINF_SR_U", 0);
   const int sr_u = sr_u_env ? sr_u_env : (grid.x > 4 * 256 ? 4 : 8);
-  if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
-  else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+  if (s1.epi != EPI_GATED_SILU) {
+    // plain experts (Switch, top-1): a grid of at most one workgroup per CU gets sixteen waves per workgroup — the whole
+    // work item in flight at once (see launch_ffn_stage)
+    if (s1.dtype == DT_BF16) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    else if (s1.dtype == DT_F16) hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    else hipLaunchKernelGGL((ffn1_selfroute_kernel<float, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    return hipGetLastError();
+  }
+  if (s1.dtype == DT_F16) {  // fp16 gated families: the same kernel on the f16 matrix instruction
+    if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+    else hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+    return hipGetLastError();
+  }
+  if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+  else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
   return hipGetLastError();
 }
 
@@ -564,7 +593,19 @@ __global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
   if (tid == 0) is_last = (__hip_atomic_fetch_add(&s.tile_done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == K - 1);
   __syncthreads();
   if (is_last) {
-    if (tid < 4) combine_apply<T, true>(s.comb, 0, r0 + tid * 4, m);
+    if (s.comb.kind == 2 /*SWITCH: out = Tr(router_prob * expert output), switch_transformers.py:99-109; K == 1*/) {
+      if (tid < 4 && r0 + tid * 4 < s.R) {
+        const int h0 = r0 + tid * 4;
+        float v[4], o[4];
+        DT<T>::unpack4(DT<T>::template fetch4<true>(reinterpret_cast<const T*>(s.comb.y) + h0), v);  // row 0 = (token 0, its expert)
+        const float pr = s.comb.router_prob[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = DT<T>::round(pr * v[j]);
+        DT<T>::store4(reinterpret_cast<T*>(s.comb.out) + h0, o);
+      }
+    } else if (tid < 4) {
+      combine_apply<T, true>(s.comb, 0, r0 + tid * 4, m);
+    }
     if (tid == 0) s.tile_done[blockIdx.x] = 0;
   }
 }
@@ -715,7 +756,7 @@ __global__ __launch_bounds__(KX * NWE * 64) void ffn2_decode1_half_kernel(FfnSta
 
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   static const int pair_env = env_int("MOEINF_DEC1_PAIR", 1);  // 0: always the arrival-counter form; 4 / 8: waves per expert
-  if (pair_env && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
+  if (pair_env && s2.dtype == DT_BF16 && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
     const dim3 g1((s2.R + 15) / 16);
     // 4 waves per expert (8 per CU), batches of 4 tiles: 38.9 us per Mixtral launch; 8 waves per expert 40.5; the
     // arrival-counter form 41.9
@@ -732,7 +773,7 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   static const int half_env = env_int("MOEINF_DEC1_HALF", 0);
   // y_shared of a hidden shared expert is written by the previous launch (stage 1 carries its stage 2); a NON-hidden one
   // (shared_offsets set: its rows are produced by THIS stage) cannot be combined inside the workgroup
-  if (half_env && s2.comb.K >= 3 && s2.comb.K <= 8 && (s2.K % 32) == 0 && s2.comb.kind <= 1 && !s2.comb.shared_offsets) {
+  if (half_env && s2.dtype == DT_BF16 && s2.comb.K >= 3 && s2.comb.K <= 8 && (s2.K % 32) == 0 && s2.comb.kind <= 1 && !s2.comb.shared_offsets) {
     const dim3 g2(2 * ((s2.R + 15) / 16));
     static const int hu = env_int("MOEINF_DEC1_HALF_U", 8);
     // (the 12-tiles-per-batch variants spilled 144 bytes per thread and were never faster: removed in round 4)
@@ -750,6 +791,17 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
     return hipGetLastError();
   }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
+  if (s2.comb.kind == 2) {  // Switch, top-1: H/16 workgroups (48 for Switch-base) of sixteen waves
+    if (s2.dtype == DT_BF16) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 16, 4>), grid, dim3(1024), 0, st, s2);
+    else if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 16, 4>), grid, dim3(1024), 0, st, s2);
+    else hipLaunchKernelGGL((ffn2_decode1_kernel<float, 16, 4>), grid, dim3(1024), 0, st, s2);
+    return hipGetLastError();
+  }
+  if (s2.dtype == DT_F16) {  // fp16 gated families: the arrival-counter form
+    if ((size_t)s2.K * 2 >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 8, 4>), grid, dim3(512), 0, st, s2);
+    else hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 4, 4>), grid, dim3(256), 0, st, s2);
+    return hipGetLastError();
+  }
   const size_t kbytes = (size_t)s2.K * 2;
   static const int du = env_int("MOEINF_DEC1_U", 4);  // k-tiles per wave fetched per batch (short reductions)
   if (kbytes >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);
@@ -875,10 +927,12 @@ hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wa
   dim3 grid((a.H + 1023) / 1024, a.T);
   if (wait) {
     if (a.dtype == DT_BF16) hipLaunchKernelGGL(combine_wait_kernel<uint16_t>, grid, dim3(256), 0, st, a, *wait);
+    else if (a.dtype == DT_F16) hipLaunchKernelGGL(combine_wait_kernel<half_t>, grid, dim3(256), 0, st, a, *wait);
     else hipLaunchKernelGGL(combine_wait_kernel<float>, grid, dim3(256), 0, st, a, *wait);
     return hipGetLastError();
   }
   if (a.dtype == DT_BF16) hipLaunchKernelGGL(combine_kernel<uint16_t>, grid, dim3(256), 0, st, a);
+  else if (a.dtype == DT_F16) hipLaunchKernelGGL(combine_kernel<half_t>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(combine_kernel<float>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

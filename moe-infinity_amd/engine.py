@@ -14,10 +14,10 @@ import torch
 
 from . import _lib
 from ._lib import Config, EpProfile, MoeInfError, Profile, Stats, check, load_library
-from .config import DTYPE_BF16, DTYPE_F32, EngineConfig
+from .config import DTYPE_BF16, DTYPE_F16, DTYPE_F32, EngineConfig
 
 FWD_DEFAULT, FWD_ROUTE_ONLY, FWD_NO_COMBINE = 0, 1, 2
-_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
+_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32, DTYPE_F16: torch.float16}
 _ALIGN = 4096
 
 

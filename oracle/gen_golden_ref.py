@@ -25,13 +25,13 @@ ET = {"mixtral": 4, "deepseek": 5, "nllb": 2, "switch": 0}
 
 
 def to_np(t):
-    return t.float().numpy() if t.dtype == torch.bfloat16 else t.numpy()
+    return t.float().numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.numpy()
 
 
 def main():
     build_ref.build()
     for fam in ("mixtral", "deepseek", "nllb", "switch"):
-        for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32"), (torch.float16, "f16")):  # f16: round 4 (dtype id 2)
             h, f, e, seed = 256, 352, 3, 4100 + ET[fam]
             kw = {"gate_std": 0.5} if fam in ("nllb", "switch") else {}
             gate, experts, _ = make_weights(fam, h, f, e, seed, dt, **kw)

@@ -30,7 +30,7 @@ def engine_for(family, h, f, e, k, dtype, n_shared=0, max_tokens=64, **kw):
     from moe_infinity_amd import MoEEngine
     from moe_infinity_amd import config as Cf
 
-    dt = Cf.DTYPE_BF16 if dtype == torch.bfloat16 else Cf.DTYPE_F32
+    dt = Cf.DTYPE_BF16 if dtype == torch.bfloat16 else (Cf.DTYPE_F16 if dtype == torch.float16 else Cf.DTYPE_F32)
     et = {"mixtral": Cf.EXPERT_MIXTRAL, "deepseek": Cf.EXPERT_DEEPSEEK, "switch": Cf.EXPERT_SWITCH, "nllb": Cf.EXPERT_NLLB}[family]
     rk = {"mixtral": Cf.ROUTER_MIXTRAL, "deepseek": Cf.ROUTER_DEEPSEEK, "switch": Cf.ROUTER_SWITCH, "nllb": Cf.ROUTER_NLLB}[family]
     base = dict(num_layers=1, num_experts=e, expert_type=et, hidden=h, inter=f, top_k=k, router_kind=rk, dtype=dt,
@@ -74,7 +74,7 @@ def fill_layer_on_gpu(eng, family, layer, seed, dev="cuda:0", std=0.02):
     cfg = eng.cfg
     off, siz, tot = eng.expert_layout(0)
     dt = eng.dtype
-    es = 2 if dt == torch.bfloat16 else 4
+    es = 4 if dt == torch.float32 else 2
     g = torch.Generator(device=dev)
     experts = []
     for e in range(cfg.num_experts):
@@ -98,7 +98,7 @@ def fill_layer_on_gpu(eng, family, layer, seed, dev="cuda:0", std=0.02):
 def assert_as_accurate_as_the_oracle(got, ref: R.BlockResult, family, x3d, experts, dtype, what, shared=None, rows=None):
     """The fp32-exact arm (oracle/parity.py): the GPU block output — and, with ``rows`` = the GPU's per-expert FFN rows in
     expert-sorted order, those rows too — must be as close to the fp32 computation as the reference's CPU path (the oracle in
-    the model dtype) is: mean |gpu - exact| <= 1.15 x mean |oracle - exact|."""
+    the model dtype) is: mean |gpu - exact| <= 1.15 x mean |oracle - exact| (fp32 models: 4 x, oracle/parity.py exact_arm_factor)."""
     ex = P.exact_block(family, x3d, ref, experts, shared=shared)
     rep = P.accuracy_report(got, ref, ex, dtype)
     assert rep["ok"], (f"{what}: the GPU result is further from the fp32-exact block ({rep['gpu_vs_exact']:.3e}) than the oracle in the model dtype "

@@ -304,7 +304,7 @@ def test_prefetch_op_under_the_reference_offload_engines_own_call_sequence(tmp_p
         # 2. and the logits match what the reference's code computed on the CPU
         want = torch.tensor(gold["output"]).reshape(gold["out_shape"])
         rel = (y.float().cpu() - want).abs().mean().item() / want.abs().mean().item()
-        assert rel <= 1e-2, f"logits differ from the reference run: mean relative {rel:.3e}"
+        assert rel <= 2e-3, f"logits differ from the reference run: mean relative {rel:.3e}"  # (measured on the box: 0.0 — bit-identical logits)
         # ... with the fp32-exact arm as the bar that needs no tuning: the same toy decoder once more in fp32 end to end (dense
         # layers, router, experts, combine; plain torch on the CPU) — the replay on the GPU must be as close to it as the
         # reference's own bf16 CPU run is.  (The mean-relative figure above compares two bf16 chains of 2 x (Linear + MoE) +

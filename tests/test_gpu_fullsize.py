@@ -144,3 +144,29 @@ def test_switch_base_8_layer_fp32(b, s):
     acc = assert_as_accurate_as_the_oracle(out, ref, "switch", x, experts, torch.float32, f"Switch-base-8 layer, {b}x{s} tokens", rows=got_rows)
     print(f"switch {b}x{s}: |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f} (block; exact = fp64)")
     eng.close()
+
+
+def test_mixtral_8x7b_layer_fp16_decode_and_prefill():
+    """fp16 experts (dtype id 2) at Mixtral-8x7B's full shape: batch 1 (the self-routing kernels on the f16 matrix
+    instruction) and a 512-token prefill (ffn_gemm_big for fp16).  north_star's "within 1e-3 fp16" applies literally here:
+    fp16 ulp 2^-10 in every bar, mean relative error <= 1e-3, and the fp32-exact arm."""
+    from moe_infinity_amd import config as Cf
+
+    for t in (1, 512):
+        eng, cfg = _engine("mixtral_8x7b", t, dtype=Cf.DTYPE_F16)
+        experts, _ = fill_layer_on_gpu(eng, "mixtral", 0, 1234)
+        gate = _gate(cfg.num_experts, cfg.hidden, torch.float16, 4321, 0.02)
+        x = acts(t, cfg.hidden, torch.float16, 2024)
+        for _ in range(2):
+            out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        ref = R.block_mixtral(x[None], gate, experts, top_k=cfg.top_k)
+        r = _check_index(eng, ref)
+        assert np.array_equal(r["topk_idx"], ref.topk_idx.numpy().astype(np.int32)), "routing indices must be bit-exact"
+        rows = oracle_expert_rows(ref, cfg.num_experts)
+        got_rows = eng.expert_outputs(rows.shape[0])
+        assert_model_close(got_rows, rows, torch.float16, "fp16 expert FFN outputs")
+        rep = assert_block_close(out, ref, torch.float16, f"Mixtral-8x7B fp16 layer, {t} tokens")
+        acc = assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.float16, f"Mixtral-8x7B fp16 layer, {t} tokens", rows=got_rows)
+        print(f"mixtral fp16 t={t}: mean rel err {rep['mean_rel']:.2e}, max rel err {rep['max_rel_err']:.2e}; |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f}")
+        assert rep["mean_rel"] <= 1e-3
+        eng.close()

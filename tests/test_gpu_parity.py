@@ -585,7 +585,7 @@ def test_ep_two_ranks_variable_split_emulated_on_one_gpu():
 
 
 @pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch")
-                                        for d, t in ((torch.bfloat16, "bf16"), (torch.float32, "f32"))])
+                                        for d, t in ((torch.bfloat16, "bf16"), (torch.float32, "f32"), (torch.float16, "f16"))])
 def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     """R6 pinned to real reference code: tests/golden/ffn_ref_*.npz hold y = <module>.forward(x) computed by the
     reference's core/parallel/expert_module.cpp (oracle/_ref, oracle/gen_golden_ref.py).  The HIP grouped FFN
@@ -775,4 +775,54 @@ def test_compute_bound_grouped_gemm_256x256_tiles(family, t, h, f, e, k, n_share
         rows = oracle_expert_rows(ref, e)
         assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, f"expert rows, forward {i}", ulps=2.0 if family == "nllb" else 1.0)
         assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block, forward {i}")
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 experts (the reference's dtype id 2, core/parallel/expert_module.h:20-23; round 4).  north_star states its tolerance
+# for fp16 ("within 1e-3 fp16"): with 10 mantissa bits one rounding is 4.9e-4, so here the literal figure applies — the
+# block bar's ulp is 2^-10 and, on top of it, mean relative error <= 1e-3 AND the plain elementwise check below.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fp16_block(family, x, gate, experts, k, shared):
+    if family == "mixtral":
+        return R.block_mixtral(x[None], gate, experts, top_k=k)
+    if family == "deepseek":
+        return R.block_deepseek(x[None], gate, experts, k, shared=shared)
+    if family == "nllb":
+        return R.block_nllb(x[None], gate, experts)
+    return R.block_switch(x[None], gate, experts, expert_capacity=64)
+
+
+@pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2), ("nllb", 16, 2, 0), ("switch", 8, 1, 0)])
+@pytest.mark.parametrize("t", [1, 7, 40, 300], ids=["batch1_selfrouting_or_generic", "decode_batch", "many_rows_token_tiles", "compute_bound_gemm_on_the_f16_matrix_instruction"])
+def test_fp16_experts_all_families(family, e, k, n_shared, t):
+    dt = torch.float16
+    h, f = 512, 384
+    gate, experts, shared = make_weights(family, h, f, e, 9100 + e + t, dt, n_shared=n_shared, **({"gate_std": 0.5} if family in ("nllb", "switch") else {}))
+    eng = engine_for(family, h, f, e, k, dt, n_shared=n_shared, max_tokens=max(t, 4))
+    register_all(eng, experts, shared)
+    g = gate.to(DEV)
+    x = acts(t, h, dt, 9200 + t)
+    ref = _fp16_block(family, x, gate, experts, k, shared)
+    outs = []
+    for _ in range(3):  # decision path, then the sync-free path (batch 1: the self-routing kernels), then again: bit-stable
+        outs.append(eng.forward(0, x.to(DEV), g).clone())
+    assert torch.equal(outs[1], outs[2])
+    r = eng.routing()
+    got_mask = np.zeros((t, e), bool)
+    for i in range(t):
+        for j in r["topk_idx"][i]:
+            if j >= 0:
+                got_mask[i, j] = True
+    assert np.array_equal(got_mask, ref.router_mask.reshape(t, e).numpy().astype(bool)), "routing sets must be bit-exact"
+    rows = oracle_expert_rows(ref, e)
+    if rows is not None:
+        assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dt, f"fp16 {family} expert rows, {t} tokens", ulps=2.0 if family == "nllb" else 1.0)
+    for out in outs[:2]:
+        assert_block_close(out, ref, dt, f"fp16 {family} block, {t} tokens")
+    if family in ("mixtral", "deepseek"):  # north_star's figure, literally: |err| <= 1e-3 * max(|ref|, mean|ref|) + the combine's own two roundings
+        err = (outs[1].float().cpu() - ref.out[0].float()).abs()
+        floor = torch.maximum(ref.out[0].float().abs(), ref.out[0].float().abs().mean())
+        assert float((err / floor).mean()) <= 1e-3
+        assert float((err / floor).max()) <= 4e-3, float((err / floor).max())
     eng.close()
