@@ -248,6 +248,7 @@ struct moeinf_engine {
   int owned_experts = 0;
 
   // EP workspace (lazily allocated)
+  EpOwnArgs::Rec* d_ep_rec = nullptr;  // [64] stage 1 -> stage 2 records of the self-indexing owner kernels
   int32_t *d_ep_key = nullptr, *d_ep_counts = nullptr, *d_ep_offsets = nullptr, *d_ep_active = nullptr,
           *d_ep_nactive = nullptr, *d_ep_pair_slot = nullptr, *d_ep_slot_token = nullptr, *d_ep_slot_pair = nullptr,
           *d_ep_pair_pos = nullptr;
@@ -299,6 +300,13 @@ struct moeinf_engine {
   std::vector<ProfRec> prof_pending;
   moeinf_profile prof;
 };
+
+// Events that only TIME things (profiling intervals, exposed-wait timers): a record that fails must not fail the forward it
+// brackets — the interval is simply lost (hipEventElapsedTime on it fails and the reader skips it) — but its error must not
+// linger in the runtime's sticky last-error slot either.
+static inline void record_timing(hipEvent_t ev, hipStream_t st) {
+  if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError();
+}
 
 static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }
 // a node's disk backing, reference-counted on the store so that it cannot be closed under a live engine
@@ -440,7 +448,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -523,6 +531,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMemset(g->d_wptr, 0, (size_t)g->L * E1 * sizeof(uint64_t)));
   TRY(dmalloc(&g->d_counts, E1)); TRY(dmalloc(&g->d_offsets, E1 + 1)); TRY(dmalloc(&g->d_active, E1)); TRY(dmalloc(&g->d_n_active, 1));
   TRY(dmalloc(&g->d_arrive, (g->H + 15) / 16)); TRY(dmalloc(&g->d_miss, 1));
+  TRY(dmalloc(&g->d_ep_rec, 64));
   TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
   TRY(dmalloc(&g->d_dec_w, 8)); TRY(dmalloc(&g->d_dec_cw, 8));
@@ -559,7 +568,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
 }
 
 static int retile_tensor(const moeinf_engine* g, const DevLayout& dl, int i, const void* staged, void* slot, hipStream_t cs);
-static int alloc_host_block(moeinf_engine* g, int idx, void** out);
+static int alloc_host_block(moeinf_engine* g, int idx, void** out, bool may_block = true);
 static int invalidate_resident(moeinf_engine* g, int idx);
 
 // ---- registration --------------------------------------------------------------------------
@@ -877,7 +886,9 @@ static PrioAioPool* aio_pool(moeinf_engine* g) {
 
 // an arena block for node idx's host blob: free list -> grow under the cap -> drop the least recently needed host blob
 // that can be re-read from disk
-static int alloc_host_block(moeinf_engine* g, int idx, void** out) {
+// may_block = false (the speculative pump, which is documented never to block): no waiting for a transfer or a disk read —
+// the caller drops the request instead (MOEINF_ERR_OOM)
+static int alloc_host_block(moeinf_engine* g, int idx, void** out, bool may_block) {
   void* blk = nullptr;
   if (!g->host_free.empty()) {
     blk = g->host_free.back();
@@ -899,19 +910,24 @@ static int alloc_host_block(moeinf_engine* g, int idx, void** out) {
       }
       if (victim < 0 || v.host_clock < g->nodes[victim].host_clock) victim = i;
     }
-    if (victim < 0 && busy >= 0) {  // every droppable blob is still being copied: wait for the oldest transfer
+    if (victim < 0 && busy >= 0 && may_block) {  // every droppable blob is still being copied: wait for the oldest transfer
       HIPCHK(hipEventSynchronize(g->nodes[busy].ready));
       g->nodes[busy].copy_inflight = false;
       victim = busy;
     }
-    if (victim < 0 && (!g->disk_inflight.empty() || !g->stale_disk.empty())) {
-      // every block is held by a speculative disk read that has not been adopted yet: the oldest one (stale ones
-      // first) is promoted, waited for and gives up its block (its task is dropped — the expert stays on disk)
-      int di;
-      if (!g->stale_disk.empty()) { di = g->stale_disk.front(); g->stale_disk.erase(g->stale_disk.begin()); }
-      else { di = (int)g->disk_inflight.front().node; g->disk_inflight.pop_front(); }
-      Node& dn = g->nodes[di];
-      if (di != idx && dn.host_pending) {
+    if (victim < 0 && may_block) {
+      // every block is held by a speculative disk read that has not been adopted yet: the oldest one that can give up a block
+      // (stale ones first) is promoted, waited for and gives up its block (its task is dropped — the expert stays on disk).
+      // Candidates that cannot (the requester itself, a read that was adopted meanwhile) keep their place in their list
+      // (round-3 advice: the first candidate used to be popped, and lost, whether or not it yielded a block).
+      int di = -1;
+      for (auto it = g->stale_disk.begin(); it != g->stale_disk.end(); ++it)
+        if (*it != idx && g->nodes[*it].host_pending) { di = *it; g->stale_disk.erase(it); break; }
+      if (di < 0)
+        for (auto it = g->disk_inflight.begin(); it != g->disk_inflight.end(); ++it)
+          if ((int)it->node != idx && g->nodes[(int)it->node].host_pending) { di = (int)it->node; g->disk_inflight.erase(it); break; }
+      if (di >= 0) {
+        Node& dn = g->nodes[di];
         for (auto& h : dn.disk_reqs) g->aio->promote(h);
         for (auto& h : dn.disk_reqs) PrioAioPool::wait(h);
         dn.disk_reqs.clear();
@@ -1213,7 +1229,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
   bool will_wait = false;
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) { const Node& n = g->nodes[node_index(g, layer, e)]; if (n.slot < 0 || !n.waited1) will_wait = true; } }
   hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (will_wait) { w0 = get_event(g); w1 = get_event(g); if (w0 && w1) hipEventRecord(w0, st); }
+  if (will_wait) { w0 = get_event(g); w1 = get_event(g); if (w0 && w1) record_timing(w0, st); }
   for (int i = a0; i < na && rc == MOEINF_OK; ++i) {
     const int e = active[i];
     if (e >= g->E) continue;  // shared pseudo-expert
@@ -1246,7 +1262,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
     g->slots[n.slot].last_use_seq = g->seq + 1;
   }
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
-  if (w0 && w1) { hipEventRecord(w1, st); g->wait_timers.push_back({w0, w1}); }
+  if (w0 && w1) { record_timing(w1, st); g->wait_timers.push_back({w0, w1}); }
   return rc;
 }
 
@@ -1254,7 +1270,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
 static int wait_late(moeinf_engine* g, int layer, hipStream_t st, std::vector<int>& late) {
   if (late.empty()) return MOEINF_OK;
   hipEvent_t w0 = get_event(g), w1 = get_event(g);
-  if (w0 && w1) hipEventRecord(w0, st);
+  if (w0 && w1) record_timing(w0, st);
   for (int idx : late) {
     Node& n = g->nodes[idx];
     if (n.ready_waited || n.slot < 0) continue;
@@ -1262,7 +1278,7 @@ static int wait_late(moeinf_engine* g, int layer, hipStream_t st, std::vector<in
     n.ready_waited = true;
     g->resident_per_layer[layer] += 1;
   }
-  if (w0 && w1) { hipEventRecord(w1, st); g->wait_timers.push_back({w0, w1}); }
+  if (w0 && w1) { record_timing(w1, st); g->wait_timers.push_back({w0, w1}); }
   late.clear();
   return MOEINF_OK;
 }
@@ -1763,7 +1779,7 @@ static int pump_prefetch(moeinf_engine* g) {
       // the H2D copy is issued by a later pump once the blob has landed
       if ((int)g->disk_inflight.size() >= g->disk_window) { g->pq.enqueue(t.node, t.layer, t.priority); break; }
       void* blk = nullptr;
-      const int arc = alloc_host_block(g, idx, &blk);
+      const int arc = alloc_host_block(g, idx, &blk, /*may_block=*/false);  // the pump never waits: no block free right now = the request is dropped
       if (arc == MOEINF_ERR_OOM) { g->st.prefetch_dropped += 1; continue; }
       if (arc != MOEINF_OK) return arc;
       const int src = submit_host_read(g, idx, blk, /*high=*/false);
@@ -2529,8 +2545,10 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
     memset(&o, 0, sizeof o);
     o.recv = recv_dev; o.ld_recv = ld; o.H = g->H; o.nrows = nrows; o.ep_size = g->cfg.ep_size; o.ep_rank = g->cfg.ep_rank;
     o.max_active = std::min(owned, nrows);
+    o.rec = g->d_ep_rec;
     if (pv) {
       o.peers = *pv;
+      o.tile_done = g->d_arrive;
       if (!pv->poll) {  // ranks sharing a GPU: one wave waits, the wide kernel starts when the rows are there
         EpWait w{g->ep_win.recv_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
         HIPCHK(launch_ep_wait(w, st));
@@ -2540,14 +2558,14 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
     const bool prof = g->profiling;
     if (prof) {
       for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-      hipEventRecord(pr.ev[0], st); hipEventRecord(pr.ev[1], st); hipEventRecord(pr.ev[2], st);
+      record_timing(pr.ev[0], st); record_timing(pr.ev[1], st); record_timing(pr.ev[2], st);
     }
     o.stage = 1; o.mirror = mp.target;
     HIPCHK(launch_ffn_ep_stage(s1, o, st));
-    if (prof) hipEventRecord(pr.ev[3], st);
+    if (prof) record_timing(pr.ev[3], st);
     o.stage = 2; o.mirror = nullptr;
     HIPCHK(launch_ffn_ep_stage(s2, o, st));
-    if (prof) { hipEventRecord(pr.ev[4], st); hipEventRecord(pr.ev[5], st); g->prof_pending.push_back(pr); }
+    if (prof) { record_timing(pr.ev[4], st); record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
     g->st.forwards += 1;
     g->seq += 1;
     HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
@@ -2567,14 +2585,14 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
   const bool prof = g->profiling;
   if (prof) {
     for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) { g->ovr_out = nullptr; g->ovr_map = nullptr; return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } }
-    hipEventRecord(pr.ev[0], st); hipEventRecord(pr.ev[1], st);
+    record_timing(pr.ev[0], st); record_timing(pr.ev[1], st);
   }
   const int rc = dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
                                   (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, prof, prof ? &pr : nullptr, mp, nullptr, nullptr);
   g->ovr_out = nullptr; g->ovr_map = nullptr;
   if (rc != MOEINF_OK) return rc;
   if (pv) HIPCHK(launch_ep_push(y_dev, recv_dev, ld, g->H, g->dt, *pv, st));  // ... and send their outputs home behind them
-  if (prof) { hipEventRecord(pr.ev[5], st); g->prof_pending.push_back(pr); }
+  if (prof) { record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
   g->st.forwards += 1;
   g->seq += 1;
   HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
@@ -2818,7 +2836,7 @@ static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int t
   const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
   moeinf_engine::EpProfRec pr;
   const bool prof = g->ep_profiling;
-  auto mark = [&](int i) { if (prof) (void)hipEventRecord(pr.ev[i], st); };
+  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
   if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
   g->ep_win.epoch += 1;  // collective discipline: every rank runs the same sequence of exchanges
   EpPeers pv;
@@ -2849,7 +2867,7 @@ extern "C" int moeinf_ep_moe_forward(moeinf_engine* g, int layer, const void* x_
   const int cap = g->ep_x_cap_rows, G = g->cfg.ep_size;
   moeinf_engine::EpProfRec pr;
   const bool prof = g->ep_profiling;
-  auto mark = [&](int i) { if (prof) hipEventRecord(pr.ev[i], st); };
+  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
   if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
   mark(0);
   CHK(moeinf_ep_route_pack(g, layer, x_dev, tokens, batch_rows, gate_w_dev, g->ep_x_send, nullptr, cap, stream));

@@ -219,6 +219,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_ep_kernel(FfnStage s, EpOwnArgs o
   const bool meta = o.stage == 1 && o.mirror && blockIdx.x == gridDim.x - 1;
   if (meta && u != 0) return;
   const bool peer = o.peers.on != 0;  // peer-store exchange: recv is this rank's window, written by the other ranks' kernels
+  const bool from_rec = o.stage == 2 && o.rec != nullptr;  // stage 2 reads what stage 1 derived
+  if (from_rec) {
+    if (threadIdx.x < 64) {
+      const EpOwnArgs::Rec* rc = o.rec + u;
+      const int c = rc->cnt;
+      if (threadIdx.x < c) s_rows[threadIdx.x] = rc->rows[threadIdx.x];
+      if (threadIdx.x == 0) { s_w = rc->w; s_cnt = c; s_off = rc->off; s_present = rc->present; }
+    }
+  } else
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     // the rows of exchange `epoch` must have landed before their tails are read (stage 2 runs behind stage 1: they have)
@@ -263,6 +272,11 @@ __global__ __launch_bounds__(NW * 64) void ffn_ep_kernel(FfnStage s, EpOwnArgs o
         wsel = ((uint64_t)hi << 32) | lo;
       }
       if (lane == 0) { s_w = wsel; s_cnt = j >= 0 ? __popcll(rows) : 0; s_off = off; s_present = __popcll(mask); }
+      if (o.stage == 1 && o.rec && blockIdx.x == 0) {  // one workgroup per expert slot leaves the record for stage 2
+        EpOwnArgs::Rec* rc = o.rec + u;
+        if (valid && key == e) rc->rows[__popcll(rows & lanes_below(lane))] = lane;
+        if (lane == 0) { rc->w = wsel; rc->cnt = j >= 0 ? __popcll(rows) : 0; rc->off = off; rc->present = __popcll(mask); }
+      }
     }
   }
   if (meta) return;
@@ -284,7 +298,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_ep_kernel(FfnStage s, EpOwnArgs o
                                       &o.peers, push);
   }
   // every workgroup that owns (expert present, row group) arrives; the last one publishes this owner's outputs
-  if (push) ep_arrive_publish(o.peers, s_present * (int)gridDim.x, EP_RET_FLAGS_OFF);
+  if (push) {
+    if (o.tile_done) ep_arrive_publish2(o.peers, o.tile_done + rg, s_present, (int)gridDim.x, EP_RET_FLAGS_OFF);
+    else ep_arrive_publish(o.peers, s_present * (int)gridDim.x, EP_RET_FLAGS_OFF);
+  }
 }
 
 hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st) {

@@ -103,6 +103,22 @@ __device__ __forceinline__ void ep_arrive_publish(const EpPeers& pv, const int e
     }
   }
 }
+// ... in two levels for grids of many hundreds of workgroups (one hot counter serialises them: 768 adds on one address cost
+// the owner's stage 2 several microseconds): `per_tile` workgroups share a tile counter, the last of a tile arrives at the
+// launch-wide counter, the last of those publishes
+__device__ __forceinline__ void ep_arrive_publish2(const EpPeers& pv, int32_t* tile_counter, const int per_tile, const int tiles, const int64_t flags_off) {
+  wait_stores_acked();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(tile_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == per_tile) {
+      __hip_atomic_store(tile_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(pv.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == tiles) {
+        __hip_atomic_store(pv.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ep_publish(pv, flags_off);
+      }
+    }
+  }
+}
 // consumer: lanes 0..n-1 of ONE wave poll flag words 0..n-1 until each has reached `epoch` (bounded by wall clock)
 __device__ __forceinline__ void ep_poll(const uint32_t* flags, const int n, const uint32_t epoch, const int64_t timeout_ticks, int32_t* err) {
   const int lane = threadIdx.x & 63;

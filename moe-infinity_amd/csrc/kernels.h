@@ -234,6 +234,11 @@ struct EpOwnArgs {
   int stage;            // 1 or 2
   int max_active;       // grid.y
   int32_t* mirror;      // stage 1 only (optional): pinned routing mirror {n_active, counts[E+1], active[E+1]}
+  // stage 1 leaves, per expert slot u, what stage 2 needs ("decode record", as dec_w / dec_cw of the local batch-1 path): stage 2
+  // then starts with one round of loads from ordinary memory instead of re-deriving the index from the row tails
+  struct Rec { uint64_t w; int32_t cnt, off, present, pad; int32_t rows[64]; };
+  Rec* rec;             // [max_active] (nullptr: both stages index for themselves)
+  int32_t* tile_done;   // [ceil(R/16)] zeroed counters: stage 2 of the peer-store exchange arrives per column tile first
   EpPeers peers;        // peers.on: recv = this rank's window; stage 1 polls the recv flags (peers.poll), stage 2 stores
                         // every output row straight into its home rank's window and the last workgroup publishes
 };

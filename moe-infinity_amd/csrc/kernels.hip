@@ -162,17 +162,20 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const XT* __restrict__
 // gate blocks, the rest own 16 rows of the shared gate/up projections), stage 2 in the route/index launch
 // (route_shared2_kernel).  The two router launches are latency-bound and leave HBM idle; the shared expert is a
 // quarter of the layer's weight bytes (34.6 of 138 MB for DeepSeek-V2-Lite).
-template <typename XT, typename WT, int TT, typename T, int U>
-__global__ __launch_bounds__(256) void gate_shared1_kernel(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
-                                                           int T_, int H, int E, int round_bf16, int n_gate, FfnStage s) {
+// NW: waves of a workgroup; the gate blocks always work with four (waves 4.. of a wider workgroup leave at once — a
+// terminated wave does not count at the barriers of gate_body)
+template <typename XT, typename WT, int TT, typename T, int U, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gate_shared1_kernel(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
+                                                               int T_, int H, int E, int round_bf16, int n_gate, FfnStage s) {
   __shared__ double redg[4][TT];
-  __shared__ float red[4][2][256];
+  __shared__ float red[NW][2][256];
   const int b = blockIdx.x;
   if (b < n_gate) {
+    if (NW > 4 && threadIdx.x >= 256) return;
     gate_body<XT, WT, TT>(x, wg, logits, T_, H, E, round_bf16, redg, b % E, (b / E) * TT);
   } else {
     const char* W = reinterpret_cast<const char*>(s.wptr[s.E]);
-    ffn_rows_item<T, 2, 4, U, 1>(s, b - n_gate, W, true, T_, 0, red);
+    ffn_rows_item<T, 2, NW, U, 1>(s, b - n_gate, W, true, T_, 0, red);
   }
 }
 
@@ -188,10 +191,17 @@ hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_
   const int rb = gate_rounds_bf16(a);
   // bf16 model (DeepSeek): activations bf16, gate bf16 or fp32
   static const int u8 = env_int("MOEINF_SH1_U", 8) == 8;  // 8 tiles per wave and matrix per batch: 1.035 -> 1.007 ms/token (DeepSeek-V2-Lite)
+  // MOEINF_SH1_NW=8: eight waves per workgroup (a shared-expert work item of 16 rows x 2 matrices x K = 128 KB for
+  // DeepSeek-V2-Lite then goes in flight in ONE batch of loads per wave instead of two)
+  static const int nw8 = env_int("MOEINF_SH1_NW", 8) == 8;  // round 4: 0.984 -> 0.968 ms/token (A/B/A in one run); 4 = the four-wave form
 #define GS1(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU>), grid, dim3(256), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
-  if (a.gate_dtype == DT_BF16) { if (u8) GS1(uint16_t, 8); else GS1(uint16_t, 4); }
+#define GS8(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU, 8>), grid, dim3(512), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
+  if (nw8) {
+    if (a.gate_dtype == DT_BF16) GS8(uint16_t, 8); else GS8(float, 8);
+  } else if (a.gate_dtype == DT_BF16) { if (u8) GS1(uint16_t, 8); else GS1(uint16_t, 4); }
   else { if (u8) GS1(float, 8); else GS1(float, 4); }
 #undef GS1
+#undef GS8
   return hipGetLastError();
 }
 
@@ -486,6 +496,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
   // (Mixtral: 1793 blocks, 6 per CU) a meta block at the end of the grid would start only when a slot frees up and
   // put its ~5 us of serial work (generic router, index, PCIe mirror writes) behind the weight stream's tail
   int b = (int)blockIdx.x - 1;
+  // n_sh2 < 0 (MOEINF_SR_ORDER=1): the shared expert's (lighter) work items are dispatched LAST instead of first
+  if (n_sh2 < 0) {
+    n_sh2 = -n_sh2;
+    if (b >= 0) { const int n_routed = (int)gridDim.x - 1 - n_sh2; b = b < n_routed ? b + n_sh2 : b - n_routed; }
+  }
   if (b >= 0 && b < n_sh2) {  // shared expert, stage 2 (h_shared was written by the gate launch)
     const char* Wsh = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
     ffn_rows_item<T, 1, NW, U, 1>(sh2, b, Wsh, true, 1, 0, reinterpret_cast<float (*)[1][256]>(&red[0][0][0]));
@@ -566,8 +581,10 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
     else hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
     return hipGetLastError();
   }
-  if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
-  else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+  static const int sr_order = env_int("MOEINF_SR_ORDER", 0);
+  const int n_sh2_arg = (sr_order && n_sh2 > 0) ? -n_sh2 : n_sh2;
+  if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
+  else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
   return hipGetLastError();
 }
 
@@ -792,6 +809,15 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
   if (s2.comb.kind == 2) {  // Switch, top-1: H/16 workgroups (48 for Switch-base) of sixteen waves
+    // twelve tiles per wave and batch: Switch-base's down projection is 192 tiles per row group = 16 waves x 12, i.e. the
+    // workgroup's whole 197 KB in flight at once (MOEINF_DEC1_SWITCH_U=4: three batches of four, 10.6 us per launch)
+    static const int su = env_int("MOEINF_DEC1_SWITCH_U", 12);
+    if (su == 12) {
+      if (s2.dtype == DT_BF16) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 16, 12>), grid, dim3(1024), 0, st, s2);
+      else if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 16, 12>), grid, dim3(1024), 0, st, s2);
+      else hipLaunchKernelGGL((ffn2_decode1_kernel<float, 16, 12>), grid, dim3(1024), 0, st, s2);
+      return hipGetLastError();
+    }
     if (s2.dtype == DT_BF16) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 16, 4>), grid, dim3(1024), 0, st, s2);
     else if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 16, 4>), grid, dim3(1024), 0, st, s2);
     else hipLaunchKernelGGL((ffn2_decode1_kernel<float, 16, 4>), grid, dim3(1024), 0, st, s2);

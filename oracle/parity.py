@@ -46,6 +46,14 @@ def block_magnitude(ref) -> torch.Tensor:
         for e, y in ref.expert_out.items():
             tok = rm[:, e]
             mag[tok] += (y.float() * wm[tok, e][:, None]).abs()
+    elif "router_probs" in ref.extra and ref.expert_out:
+        # Switch (no weights mask): a routed token's output is router_prob * expert output — a one-flip difference in the expert
+        # output passes through that one more rounding, at a scale that may sit one binade below the expert output's
+        rm = ref.router_mask.reshape(out.shape[0], -1).bool()
+        pr = ref.extra["router_probs"].reshape(out.shape[0], -1).float()
+        for e, y in ref.expert_out.items():
+            tok = rm[:, e]
+            mag[tok] += (y.float() * pr[tok]).abs()
     if "shared_out" in ref.extra:
         mag += ref.extra["shared_out"].reshape(out.shape).float().abs()
     return mag.reshape(ref.out.shape)

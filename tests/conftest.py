@@ -9,11 +9,6 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Several "ranks" inside ONE process (tests/test_gpu_ep_peer.py) wait for each other on the GPU: their compute streams must
-# sit on DIFFERENT hardware queues, or a waiting kernel can sit in front of the kernel it waits for.  The HIP runtime shares
-# its hardware queues between streams beyond GPU_MAX_HW_QUEUES (default 4) per priority; read once, at device init.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -1,14 +1,13 @@
-"""The direct peer-store exchange of expert parallelism (include/moeinf.h: moeinf_ep_peer_*, csrc/ep_peer.h) with REAL
-cross-rank traffic inside one process: two (three) engines = ranks on GPU 0, each driven by its own host thread on its own
-stream — like the one-process-per-GPU product, minus hipIpc (ranks inside one process map each other's windows by pointer;
-the process test, tests/test_gpu_ep_processes.py, covers the IPC mapping).  Every rank stores its routed rows straight into
-the owners' windows, the owners' FFN stage 2 stores the outputs straight into the home ranks' windows, consumers wait on
-flag words — no collective, no host staging.  Each rank's output must equal the oracle block of its own tokens.
+"""The direct peer-store exchange of expert parallelism (include/moeinf.h: moeinf_ep_peer_*, csrc/ep_peer.h) inside one
+process: every kernel path of the exchange at world size 1 (the rank stores into its own window), and the bootstrap's error
+behaviour.  Ranks that wait for each other ON the GPU need hardware queues of their own — guaranteed between processes, not
+between streams of one process (the HIP runtime shares its queues between streams: a waiting kernel can sit in front of the
+kernel it waits for) — so the multi-rank runs, with hipIpc-mapped windows and both consumer modes, are
+tests/test_gpu_ep_processes.py.
 
 Replaces in the reference: cudaDeviceEnablePeerAccess + implicit P2P `tensor.to(device)` row copies
 (core/prefetch/archer_prefetch_handle.cpp:37-61, core/parallel/expert_dispatcher.cpp:284,405)."""
 import os
-import threading
 
 import pytest
 import torch
@@ -40,85 +39,53 @@ def _engines(family, world, h, f, e, k, n_shared, L, max_tokens, seed):
     return ws, engs
 
 
-_STREAMS = []  # one compute stream per rank, shared by every test of this file: each stream that has ever launched work holds
-#                a hardware queue, and ranks that wait for each other ON the GPU must not share one (tests/conftest.py)
-
-
-def _run_ranks(world, fn):
-    """fn(rank) on one host thread per rank (ctypes releases the GIL inside the engine); re-raises the first failure"""
-    errs = [None] * world
-    while len(_STREAMS) < world:
-        _STREAMS.append(torch.cuda.Stream(device=DEV, priority=-1))
-
-    def body(r):
-        try:
-            torch.cuda.set_device(0)
-            with torch.cuda.stream(_STREAMS[r]):
-                fn(r)
-                torch.cuda.current_stream().synchronize()
-        except BaseException as ex:  # noqa: BLE001
-            errs[r] = ex
-
-    ths = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join(timeout=120)
-    assert not any(t.is_alive() for t in ths), "a rank did not finish: the ranks are waiting for each other (a poll of the exchange ran into its timeout?)"
-    for ex in errs:
-        if ex is not None:
-            raise ex
-
-
-@pytest.mark.parametrize("poll", [1, 0], ids=["consumers_poll_in_kernel", "one_wave_wait_kernels"])
-@pytest.mark.parametrize("family,world", [("mixtral", 2), ("deepseek", 2), ("mixtral", 3)])
-def test_peer_store_exchange_between_engines_of_one_process(family, world, poll, monkeypatch):
-    monkeypatch.setenv("MOEINF_EP_PEER_POLL", str(poll))
-    monkeypatch.setenv("MOEINF_EP_PEER_TIMEOUT_MS", "4000")
-    e, k, n_shared = (8, 2, 0) if family == "mixtral" else (16, 4, 2)
-    h, f, L, cap_tokens = 1024, 512, 2, 40
-    per_rank = min(k, -(-e // world))
-    ws, engs = _engines(family, world, h, f, e, k, n_shared, L, max_tokens=world * cap_tokens * per_rank, seed=5100)
-    blobs = [eng.ep_peer_export(cap_tokens) for eng in engs]
-    assert all(len(b) == 192 for b in blobs)
-    for eng in engs:
-        eng.ep_peer_attach(b"".join(blobs))
-        t = eng.ep_transport()
-        assert t["transport"] == "peer-store" and not t["shared_device"] and t["poll_in_kernels"] == bool(poll), t
-    # token counts per call (every rank makes the same calls; its own count may differ): batch 1 (fused pack, self-indexing
-    # owner), ragged small batches, 20 tokens (more rows than the self-indexing owner takes: wait + generic kernels + push;
-    # pack as a launch of its own: > 64 KiB of rows), 40 tokens (> 64 pairs: indexed pack kernel)
-    calls = [lambda r: 1, lambda r: 1, lambda r: 3 + r, lambda r: 20 - r, lambda r: 40 - 2 * r, lambda r: 2]
-    outs = [[] for _ in range(world)]
-    xs = [[] for _ in range(world)]
-    oks = [False] * world
-
-    def rank_body(r):
-        oks[r] = engs[r].ep_peer_selftest()
-        g = [w[0].to(DEV) for w in ws]
-        for ci, tf in enumerate(calls):
-            for l in range(L):
-                x = acts(tf(r), h, torch.bfloat16, 5200 + 31 * ci + 7 * l + 1000 * r)
-                xd = x.to(DEV)
-                out = torch.empty_like(xd)
-                engs[r].ep_moe_forward(l, xd, g[l], out)
-                xs[r].append((l, x))
-                outs[r].append(out)
-
-    _run_ranks(world, rank_body)
-    assert all(oks), f"self-test: {oks}"
-    for r in range(world):
-        for (l, x), out in zip(xs[r], outs[r]):
-            if family == "mixtral":
-                ref = R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k)
-            else:
-                ref = R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2])
-            assert_block_close(out.cpu(), ref, torch.bfloat16, f"peer-store, {family}, rank {r} of {world}, layer {l}, {x.shape[0]} tokens")
-        assert engs[r].ep_transport()["exchanges"] == 1 + len(calls) * L
-    for eng in engs:
-        eng.sync()  # reads the device error flag: a poll that timed out would be reported here
-    for eng in engs:
-        eng.close()
+def test_peer_store_at_world_size_one_takes_every_owner_path():
+    """One rank storing into its own window (no second stream, no second process: nothing here can wait for anything that is not
+    already enqueued in front of it): fused and separate pack launches, the self-indexing owner kernels (polls inside the
+    kernels) and the generic owner path (wait kernel + index + FFN + push kernel), both consumer modes — each against the oracle
+    block.  The multi-rank runs are tests/test_gpu_ep_processes.py: real processes, hipIpc-mapped windows."""
+    for family, e, k, n_shared in (("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2)):
+        for poll in ("1", "0"):
+            os.environ["MOEINF_EP_PEER_POLL"] = poll
+            os.environ["MOEINF_EP_PEER_TIMEOUT_MS"] = "2000"
+            try:
+                h, f, L = 1024, 512, 2
+                ws, engs = _engines(family, 1, h, f, e, k, n_shared, L, max_tokens=40 * k, seed=5100)
+                eng = engs[0]
+                for cap_tokens, calls in ((8, (1, 1, 3, 8)), ):  # cap 8 tokens -> at most 8*k <= 64 received rows: the self-indexing kernels
+                    eng.ep_peer_attach(eng.ep_peer_export(cap_tokens))
+                    assert eng.ep_peer_selftest()
+                    t = eng.ep_transport()
+                    assert t["transport"] == "peer-store" and t["poll_in_kernels"] == (poll == "1"), t
+                    for ci, tok in enumerate(calls):
+                        for l in range(L):
+                            x = acts(tok, h, torch.bfloat16, 5200 + 31 * ci + 7 * l)
+                            out = torch.empty(tok, h, dtype=torch.bfloat16, device=DEV)
+                            for _ in range(2):  # decision path first, then the sync-free path
+                                eng.ep_moe_forward(l, x.to(DEV), ws[l][0].to(DEV), out)
+                            eng.sync()
+                            ref = (R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k) if family == "mixtral"
+                                   else R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2]))
+                            assert_block_close(out.cpu(), ref, torch.bfloat16, f"peer-store world 1, {family}, poll={poll}, layer {l}, {tok} tokens")
+                eng.close()
+                # a window for 40 tokens: 40*k > 64 rows -> the generic owner path; 40 tokens x K = 80 pairs -> the indexed pack kernel
+                ws, engs = _engines(family, 1, h, f, e, k, n_shared, L, max_tokens=40 * k, seed=5100)
+                eng = engs[0]
+                eng.ep_peer_attach(eng.ep_peer_export(40))
+                assert eng.ep_peer_selftest()
+                for ci, tok in enumerate((1, 20, 40)):
+                    for l in range(L):
+                        x = acts(tok, h, torch.bfloat16, 5300 + 31 * ci + 7 * l)
+                        out = torch.empty(tok, h, dtype=torch.bfloat16, device=DEV)
+                        eng.ep_moe_forward(l, x.to(DEV), ws[l][0].to(DEV), out)
+                        eng.sync()
+                        ref = (R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k) if family == "mixtral"
+                               else R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2]))
+                        assert_block_close(out.cpu(), ref, torch.bfloat16, f"peer-store world 1 (generic owner path), {family}, poll={poll}, layer {l}, {tok} tokens")
+                eng.close()
+            finally:
+                os.environ.pop("MOEINF_EP_PEER_POLL", None)
+                os.environ.pop("MOEINF_EP_PEER_TIMEOUT_MS", None)
 
 
 def test_peer_store_bootstrap_errors_are_local_and_never_block():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (R, acts, assert_block_close, assert_model_close, checksum, engine_for, load_golden, make_weights, oracle_expert_rows,
+from helpers import (assert_as_accurate_as_the_oracle, R, acts, assert_block_close, assert_model_close, checksum, engine_for, load_golden, make_weights, oracle_expert_rows,
                      register_all, tt)
 
 pytestmark = pytest.mark.gpu
@@ -817,7 +817,12 @@ def test_fp16_experts_all_families(family, e, k, n_shared, t):
     assert np.array_equal(got_mask, ref.router_mask.reshape(t, e).numpy().astype(bool)), "routing sets must be bit-exact"
     rows = oracle_expert_rows(ref, e)
     if rows is not None:
-        assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dt, f"fp16 {family} expert rows, {t} tokens", ulps=2.0 if family == "nllb" else 1.0)
+        # one ulp up to a decode batch; with many rows the three rounding points of a gated epilogue / the two of a bias
+        # epilogue let a handful of flips reach 2 ulps (28 of 307 200 at 300 tokens) — that these are flips, not lost
+        # precision, is what the fp32-exact arm asserts on the same rows
+        got_rows = eng.expert_outputs(rows.shape[0])
+        assert_model_close(got_rows, rows, dt, f"fp16 {family} expert rows, {t} tokens", ulps=2.0 if (family == "nllb" or t >= 40) else 1.0)
+        assert_as_accurate_as_the_oracle(outs[1], ref, family, x[None], experts, dt, f"fp16 {family}, {t} tokens", shared=shared, rows=got_rows)
     for out in outs[:2]:
         assert_block_close(out, ref, dt, f"fp16 {family} block, {t} tokens")
     if family in ("mixtral", "deepseek"):  # north_star's figure, literally: |err| <= 1e-3 * max(|ref|, mean|ref|) + the combine's own two roundings
