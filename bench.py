@@ -199,7 +199,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         order = {"auto": ["peer-store", "rccl", "torch"], "peer-store": ["peer-store", "torch"], "rccl": ["rccl", "torch"], "torch": ["torch"]}[args.ep_transport]
         ep_plain = None
         for cand in order:
-            ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport=cand)
+            ep = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport=cand, uniform_tokens=True)  # every rank decodes B tokens per step
             if ep.transport != cand:
                 ep_notes.append(f"{cand}: not available ({ep.native_note})")
                 continue

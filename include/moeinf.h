@@ -480,6 +480,12 @@ int moeinf_ep_peer_selftest(moeinf_engine* eng, void* stream, int32_t* ok);
 int moeinf_ep_transport(const moeinf_engine* eng, int32_t out[4]);
 /* with both transports set up on one engine: which one moeinf_ep_moe_forward takes (default: the one set up last) */
 int moeinf_ep_select_transport(moeinf_engine* eng, int kind);
+/* on != 0: the caller guarantees that EVERY rank passes the same token count to every moeinf_ep_moe_forward (decode loops do).
+ * With it, a ONE-token forward over the peer-store transport takes the broadcast form: the home rank sends its row and its E gate
+ * logits to every rank and every owner's FFN stage 1 routes for itself (as the local batch-1 path does) — four launches per
+ * layer instead of five, no router launch between the gate and the exchange.  All ranks must be in that form together, hence
+ * the explicit promise.  Default off. */
+int moeinf_ep_set_uniform_tokens(moeinf_engine* eng, int on);
 /* moeinf_moe_forward for an expert-parallel engine, one host call per layer, everything enqueued on `stream`
  * (tokens <= cap_tokens).  Peer-store transport: router + pack into the peers' windows -> owner FFN -> combine (five
  * launches).  RCCL transport: moeinf_ep_route_pack -> all-to-all -> moeinf_ep_expert_ffn -> all-to-all -> moeinf_ep_combine. */

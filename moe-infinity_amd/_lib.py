@@ -161,6 +161,7 @@ PROTOTYPES = {
     "moeinf_ep_peer_selftest": (C.c_int, [_P, _P, _I32P]),
     "moeinf_ep_transport": (C.c_int, [_P, _I32P]),
     "moeinf_ep_select_transport": (C.c_int, [_P, C.c_int]),
+    "moeinf_ep_set_uniform_tokens": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_all_to_all": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "moeinf_ep_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
     "moeinf_ep_get_profile": (C.c_int, [_P, C.POINTER(EpProfile)]),

@@ -273,6 +273,7 @@ struct moeinf_engine {
   EpPeerWindow ep_win;
   int ep_win_cap_tokens = 0;
   bool ep_use_peer = false;        // moeinf_ep_moe_forward takes this transport (moeinf_ep_select_transport)
+  bool ep_uniform = false;         // the caller guarantees equal token counts on every rank (moeinf_ep_set_uniform_tokens): batch 1 = broadcast form
   std::vector<int32_t> ep_peer_pids;
   std::vector<uint64_t> ep_peer_ptrs;
   bool ep_peer_poll = true;        // consumer kernels poll their flags themselves (false: a one-wave wait kernel in front)
@@ -2664,8 +2665,9 @@ extern "C" int moeinf_ep_comm_unique_id(void* id_out, int nbytes) {
 }
 
 static void ep_comm_free_buffers(moeinf_engine* g) {
-  void** bufs[] = {&g->ep_x_send, &g->ep_x_recv, &g->ep_x_ret};
+  void** bufs[] = {&g->ep_x_send, &g->ep_x_ret};
   for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+  if (g->ep_x_recv && !g->ep_win.base) { (void)hipFree(g->ep_x_recv); g->ep_x_recv = nullptr; }  // (shared with the peer-store transport)
   if (g->ep_x_y && !g->ep_win.base) { (void)hipFree(g->ep_x_y); g->ep_x_y = nullptr; }  // (shared with the peer-store transport)
   g->ep_cap_tokens = 0; g->ep_x_cap_rows = 0;
 }
@@ -2684,9 +2686,10 @@ extern "C" int moeinf_ep_comm_prepare(moeinf_engine* g, int cap_tokens) {
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
   if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
   if (g->ep_x_cap_rows == cap_rows && g->ep_x_send) return MOEINF_OK;  // prepared already
+  if (g->ep_win.base && cap_rows != g->ep_win.cap_rows) return fail(MOEINF_ERR_STATE, "the peer-store window was built for another cap_tokens");
   ep_comm_free_buffers(g);
   hipError_t e = hipMalloc(&g->ep_x_send, n * ep_row_elems(g) * g->es);
-  if (e == hipSuccess) e = hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es);
+  if (e == hipSuccess && !g->ep_x_recv) e = hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es);
   if (e == hipSuccess && !g->ep_x_y) e = hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es);
   if (e == hipSuccess) e = hipMalloc(&g->ep_x_ret, n * (size_t)g->H * g->es);
   if (e == hipSuccess) e = hipMemset(g->ep_x_y, 0, n * (size_t)g->H * g->es);  // padding rows travel as they are: keep them defined
@@ -2741,7 +2744,10 @@ extern "C" int moeinf_ep_peer_export(moeinf_engine* g, int cap_tokens, void* blo
   const int cap_rows = ep_min_cap(g, cap_tokens);
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
   if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
-  std::string err = g->ep_win.create(g->cfg.ep_size, cap_rows, ep_row_elems(g) * g->es, (int64_t)g->H * g->es);
+  std::string err = g->ep_win.create(g->cfg.ep_size, cap_rows, ep_row_elems(g) * g->es, (int64_t)g->H * g->es, g->E);
+  if (err.empty() && !g->ep_x_recv) {  // routed-form staging of the broadcast form's slow path (launch_ep_bcast_unpack)
+    if (hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es) != hipSuccess) { g->ep_x_recv = nullptr; err = "hipMalloc of the unpack staging buffer failed"; }
+  }
   if (err.empty() && !g->ep_x_y) {  // staging of the owner's outputs on the generic path (more rows than the self-indexing kernels take)
     if (hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es) != hipSuccess) { g->ep_x_y = nullptr; err = "hipMalloc of the output staging buffer failed"; }
   }
@@ -2827,11 +2833,113 @@ extern "C" int moeinf_ep_transport(const moeinf_engine* g, int32_t out[4]) {
   return MOEINF_OK;
 }
 
+// The caller's promise that EVERY rank passes the same token count to every moeinf_ep_moe_forward (decode loops do): with it,
+// a one-token forward over the peer-store transport takes the BROADCAST form (kernels.h: EpBcastArgs) — all ranks must then be
+// in that form together, which is why it cannot be inferred from this rank's own token count.
+extern "C" int moeinf_ep_set_uniform_tokens(moeinf_engine* g, int on) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  g->ep_uniform = on != 0;
+  return MOEINF_OK;
+}
+
+static bool ep_bcast_eligible(const moeinf_engine* g, int tokens) {
+  static const bool env = getenv("MOEINF_EP_BCAST") ? atoi(getenv("MOEINF_EP_BCAST")) != 0 : true;
+  const int et = g->cfg.expert_type;
+  // consumer kernels must poll for themselves (the broadcast rides in FFN stage 1: no room for a wait kernel in front of it)
+  return env && g->ep_uniform && tokens == 1 && g->ep_peer_poll && g->K <= 8 && g->E <= 64 && g->dt != DT_F32 &&
+         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
+         (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || can_hide_shared(g, 1));
+}
+
+// Batch-1 decode over the peer-store exchange, broadcast form: gate -> FFN stage 1 (block 0 broadcasts this rank's row +
+// logits and routes the home token; the other workgroups wait for every rank's broadcast, route all ep_size tokens and stream
+// the experts this rank owns) -> stage 2 (outputs stored into the home ranks' windows) -> combine.  FOUR launches.  If an
+// owned expert is not resident the host must see the routing: the broadcast becomes a launch of its own, an unpack kernel
+// turns the received (row, logits) pairs into the routed form locally and the generic owner path takes over.
+static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev, const void* gate_w_dev, void* out_dev, void* stream) {
+  if (!x_dev || !gate_w_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
+  if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  hipStream_t st = (hipStream_t)stream;
+  const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
+  const int64_t ld = ep_row_elems(g);
+  moeinf_engine::EpProfRec pr;
+  const bool prof = g->ep_profiling;
+  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
+  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
+  CHK(ep_alloc(g, cap));
+  g->ep_win.epoch += 1;
+  EpPeers pv;
+  ep_peer_view(g, &pv);
+  RouteArgs ra;
+  make_route_args(g, x_dev, gate_w_dev, 1, ra);
+  drop_stale_prefetches(g, layer);
+  MirrorPlan mp;
+  CHK(plan_mirror(g, layer, mp));
+  EpBcastArgs b;
+  memset(&b, 0, sizeof b);
+  b.x = x_dev; b.pair_pos = g->d_ep_pair_pos; b.peers = pv;
+  g->last_T = 1; g->last_layer = layer; g->last_stream = st; g->last_selfroute = false;
+  mark(0);
+  if (mp.fast) {
+    const bool hide = g->has_shared;  // (eligibility says it can be hidden)
+    FfnStage sh1, sh2;
+    if (hide) { hidden_shared_stages(g, layer, x_dev, sh1, sh2); HIPCHK(launch_gate_shared1(ra, sh1, st)); }
+    else HIPCHK(launch_gate_logits(ra, st));
+    g->last_hidden_shared = hide;
+    moeinf_engine::PendingMirror pm;
+    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = G; pm.prof = false; pm.local = false;
+    g->pend.push_back(pm);
+    for (int e = 0; e < g->E; ++e) {  // any of the layer's slots may be read by this forward
+      const Node& n = g->nodes[node_index(g, layer, e)];
+      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
+    }
+    CHK(flush_pokes(g, st));
+    FfnStage s1, s2;
+    fill_stage(g, layer, 1, s1, ld);
+    s1.in = g->ep_win.recv_region(); s1.row_map = nullptr;
+    fill_stage(g, layer, 2, s2);
+    s2.out = g->ep_x_y; s2.out_map = nullptr;
+    b.mirror = mp.target;
+    const int per_rank = (g->E + G - 1) / G;
+    const int max_active = std::max(1, std::min(std::max(1, g->owned_experts), G * std::min(g->K, per_rank)));
+    mark(1); mark(2);
+    HIPCHK(launch_ffn_epb_stage1(ra, s1, hide ? &sh2 : nullptr, b, g->d_ep_rec, max_active, 1, st));
+    EpOwnArgs o;
+    memset(&o, 0, sizeof o);
+    o.recv = g->ep_win.recv_region(); o.ld_recv = ld; o.H = g->H; o.nrows = std::min(64, G * cap); o.ep_size = G; o.ep_rank = g->cfg.ep_rank;
+    o.stage = 2; o.max_active = max_active; o.rec = g->d_ep_rec; o.peers = pv; o.tile_done = g->d_arrive;
+    HIPCHK(launch_ffn_ep_stage(s2, o, st));
+    g->st.forwards += 2;  // (home routing + owner FFN, as the routed form counts them)
+    g->seq += 1;
+    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+    mark(3);
+  } else {
+    // plan_mirror handed out the engine's own mirror (nothing pooled to give back); the generic owner path plans again
+    HIPCHK(launch_gate_logits(ra, st));
+    g->last_hidden_shared = false;  // the shared expert runs on the home rank inside the combine step
+    HIPCHK(launch_ep_bcast(ra, b, st));
+    g->st.forwards += 1;
+    mark(1); mark(2);
+    HIPCHK(launch_ep_bcast_unpack(ra, b, g->ep_x_recv, ld, g->dt, st));
+    EpPeers pvw = pv;  // (the unpack kernel has waited already; the generic path's wait kernel returns at once)
+    CHK(ep_expert_ffn_rows(g, layer, g->ep_x_recv, g->ep_x_y, G * cap, st, &pvw));
+    mark(3);
+  }
+  mark(4);
+  CHK(ep_combine_impl(g, x_dev, g->ep_win.ret_region(), out_dev, cap, stream, &pv));
+  mark(5);
+  if (prof) g->ep_prof_pending.push_back(pr);
+  return mp.fast ? pump_if_pending(g) : MOEINF_OK;
+}
+
 // One expert-parallel MoE layer over the peer-store exchange: router (+ pack into the destinations' windows) -> owner FFN
 // (polls the row flags; stage 2 stores its outputs into the home ranks' windows) -> combine (polls the output flags).
 // Five launches on `stream`, no collective, no copy.
 static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
   if (tokens > g->ep_win_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the exchange window", tokens, g->ep_win_cap_tokens);
+  if (ep_bcast_eligible(g, tokens)) return ep_peer_forward_bcast(g, layer, x_dev, gate_w_dev, out_dev, stream);
   hipStream_t st = (hipStream_t)stream;
   const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
   moeinf_engine::EpProfRec pr;

@@ -324,4 +324,212 @@ hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batch-1 decode over the peer-store exchange, BROADCAST form (kernels.h: EpBcastArgs).
+// ------------------------------------------------------------------------------------------------
+// Block 0's work (every thread of a workgroup of >= 64 threads): (a) this rank's token row and its E gate logits go to
+// EVERY rank (row 0 of this rank's segment of the destination's recv region; the logits into its broadcast region), drained,
+// then published in the destinations' recv flags; (b) the home token's routing — top-k ids, weights, combine order (the
+// generic router, as the meta block of ffn1_selfroute) and, for the combine, the ret row of every pair: the owner e % G puts
+// the output for the token's j-th chosen expert among those it owns (ascending id) at position j of its segment.
+template <typename T>
+__device__ __forceinline__ void epb_broadcast_and_route_home(const RouteArgs& r, const EpBcastArgs& b) {
+  const EpPeers& pv = b.peers;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int64_t row_bytes = pv.recv_row_bytes;
+  constexpr int EPV = DT<T>::EPV;
+  const int cpr = r.H / EPV;
+  for (int i = tid; i < pv.size * cpr; i += nthr) {
+    const int p = i / cpr, c = i - p * cpr;
+    const u32x4 v = ld16(reinterpret_cast<const T*>(b.x) + (size_t)c * EPV);
+    st16_system(ep_peer_recv_row(pv, p * pv.cap_rows, row_bytes) + (size_t)c * 16, v);
+  }
+  for (int i = tid; i < pv.size * r.E; i += nthr) {
+    const int p = i / r.E, e = i - p * r.E;
+    st_system(reinterpret_cast<float*>(pv.base[p] + pv.bcast_off + (int64_t)pv.rank * pv.bcast_stride) + e, r.logits[e]);
+  }
+  wait_stores_acked();
+  __syncthreads();
+  if (tid == 0) ep_publish(pv, 0);
+  if (tid < 64) {
+    Routed o;
+    route_core(r, 0, lane, o);
+    int my_sel, rank;
+    float my_w;
+    route_store(r, 0, lane, o, &my_sel, &my_w, &rank);
+    if (lane < r.K) {
+      int pos = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < r.K && o.sel[j] >= 0 && o.sel[j] < my_sel && (o.sel[j] % pv.size) == (my_sel % pv.size)) ++pos;
+      b.pair_pos[lane] = my_sel >= 0 ? (my_sel % pv.size) * pv.cap_rows + pos : -1;
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ep_bcast_kernel(RouteArgs r, EpBcastArgs b) { epb_broadcast_and_route_home<T>(r, b); }
+hipError_t launch_ep_bcast(const RouteArgs& r, const EpBcastArgs& b, hipStream_t st) {
+  if (r.x_dtype == DT_F16) hipLaunchKernelGGL(ep_bcast_kernel<half_t>, dim3(1), dim3(256), 0, st, r, b);
+  else hipLaunchKernelGGL(ep_bcast_kernel<uint16_t>, dim3(1), dim3(256), 0, st, r, b);
+  return hipGetLastError();
+}
+
+// One wave: wait for every rank's broadcast, then the chosen-expert SET of every rank's token restricted to the experts this
+// rank owns (bit e of own[s]); G <= EP_MAX_PEERS.  Every workgroup of every owner derives the same sets from the same logits
+// with the same instructions (route_set_lean: the arithmetic of the generic router on this path).
+__device__ __forceinline__ void epb_owned_sets(const RouteArgs& r, const EpPeers& pv, const int lane, const bool poll, uint64_t own[EP_MAX_PEERS]) {
+  if (poll) ep_poll(reinterpret_cast<const uint32_t*>(pv.base[pv.rank]), pv.size, pv.epoch, pv.timeout_ticks, pv.err);
+  uint64_t mine = 0;  // experts e with e % G == rank
+  for (int e = pv.rank; e < r.E; e += pv.size) mine |= 1ull << e;
+  for (int s = 0; s < EP_MAX_PEERS; ++s) {
+    own[s] = 0;
+    if (s < pv.size) {  // wave-uniform
+      const float* lg = reinterpret_cast<const float*>(pv.base[pv.rank] + pv.bcast_off + (int64_t)s * pv.bcast_stride);
+      own[s] = route_set_lean(lg, r.E, r.K, lane) & mine;
+    }
+  }
+}
+
+// FFN stage 1 of the broadcast form.  grid = 1 (block 0) + n_sh2 (the hidden shared expert's stage 2 for the home token, as in
+// ffn1_selfroute) + max_active * n_rg (+ 1 mirror block).  Workgroup (u, rg): the u-th smallest owned expert that any token
+// chose; its rows = the tokens (source ranks) that chose it; x rows are row 0 of the sources' segments of the recv region.
+template <typename T, int NW, int U>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(96))) void ffn_epb_kernel(RouteArgs r, FfnStage s, FfnStage sh2, EpBcastArgs b,
+                                                                                                EpOwnArgs::Rec* rec, int n_rg, int n_sh2, int max_active, int with_bcast) {
+  __shared__ float red[NW][2][256];
+  __shared__ int s_in[EP_MAX_PEERS], s_out[EP_MAX_PEERS];
+  __shared__ unsigned long long s_w;
+  __shared__ int s_cnt, s_off;
+  const EpPeers& pv = b.peers;
+  const int lane = threadIdx.x & 63;
+  int blk = (int)blockIdx.x - 1;
+  if (blk < 0) {  // block 0: dispatched first, waits for nothing
+    if (with_bcast) epb_broadcast_and_route_home<T>(r, b);
+    return;
+  }
+  if (blk < n_sh2) {  // shared expert, stage 2, home token (h_shared was written by the gate launch)
+    const char* Wsh = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
+    ffn_rows_item<T, 1, NW, U, 1>(sh2, blk, Wsh, true, 1, 0, reinterpret_cast<float (*)[1][256]>(&red[0][0][0]));
+    return;
+  }
+  blk -= n_sh2;
+  const bool mirror_blk = blk >= max_active * n_rg;
+  const int u = mirror_blk ? 0 : blk / n_rg, rg = mirror_blk ? 0 : blk - u * n_rg;
+  if (threadIdx.x < 64) {
+    uint64_t wp = 0;
+    if (lane < r.E) wp = s.wptr[lane];
+    uint64_t own[EP_MAX_PEERS];
+    epb_owned_sets(r, pv, lane, pv.poll != 0, own);
+    uint64_t present = 0;
+#pragma unroll
+    for (int q = 0; q < EP_MAX_PEERS; ++q) present |= own[q];
+    if (mirror_blk) {  // the routing mirror: {n_active, counts[E+1], active[E+1]} (the host zeroed the counts)
+      const int E1 = s.E + 1;
+      int na = 0;
+      for (uint64_t m = present; m; m &= m - 1, ++na) {
+        const int e = (int)__builtin_ctzll(m);
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < EP_MAX_PEERS; ++q) c += (int)((own[q] >> e) & 1ull);
+        if (lane == 0) { b.mirror[1 + e] = c; b.mirror[1 + E1 + na] = e; }
+      }
+      if (lane == 0) b.mirror[0] = na;
+    } else {
+      uint64_t m = present;
+      for (int i = 0; i < u; ++i) m &= m - 1;  // drop the u smallest ids
+      const int e = m ? (int)__builtin_ctzll(m) : -1;
+      int cnt = 0, off = 0;
+      if (e >= 0) {
+        const uint64_t below = (1ull << e) - 1ull;
+#pragma unroll
+        for (int q = 0; q < EP_MAX_PEERS; ++q) {
+          off += __popcll(own[q] & below & present);  // rows of the experts in front of this one (expert-sorted h rows)
+          if ((own[q] >> e) & 1ull) {
+            if (lane == 0) { s_in[cnt] = q * pv.cap_rows; s_out[cnt] = q * pv.cap_rows + __popcll(own[q] & below); }
+            ++cnt;
+          }
+        }
+      }
+      uint64_t wsel = 0;
+      if (e >= 0) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wp, e);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wp >> 32), e);
+        wsel = ((uint64_t)hi << 32) | lo;
+      }
+      if (lane == 0) {
+        s_w = wsel; s_cnt = cnt; s_off = off;
+        if (rg == 0) {  // one workgroup per expert slot leaves the record for stage 2 (ffn_ep_kernel, from_rec)
+          EpOwnArgs::Rec* rc = rec + u;
+          rc->w = wsel; rc->cnt = cnt; rc->off = off; rc->present = __popcll(present);
+          for (int i = 0; i < cnt; ++i) rc->rows[i] = s_out[i];
+        }
+      }
+    }
+  }
+  if (mirror_blk) return;
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt == 0) return;
+  const char* W = reinterpret_cast<const char*>(s_w);
+  if (W == nullptr) {  // never on the sync-free path
+    if (threadIdx.x == 0 && rg == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  ffn_rows_item<T, 2, NW, U, 1>(s, rg, W, false, cnt, s_off, red, -1, s_in, nullptr);
+}
+
+hipError_t launch_ffn_epb_stage1(const RouteArgs& r, const FfnStage& s1, const FfnStage* sh2, const EpBcastArgs& b, EpOwnArgs::Rec* rec,
+                                 int max_active, int with_bcast, hipStream_t st) {
+  const int n_rg = (s1.R + 15) / 16;
+  const int n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
+  const dim3 grid(1 + n_sh2 + max_active * n_rg + (b.mirror ? 1 : 0));
+  // as launch_ffn1_selfroute: multi-round grids (Mixtral) stream best with four workgroups per CU and four tiles per batch
+  const size_t dyn = grid.x > 4 * 256 ? 30 * 1024 : 0;
+#define EPB(TT, UU) hipLaunchKernelGGL((ffn_epb_kernel<TT, 4, UU>), grid, dim3(256), dyn, st, r, s1, sh2 ? *sh2 : s1, b, rec, n_rg, n_sh2, max_active, with_bcast)
+  if (s1.dtype == DT_F16) { if (grid.x > 4 * 256) EPB(half_t, 4); else EPB(half_t, 8); }
+  else { if (grid.x > 4 * 256) EPB(uint16_t, 4); else EPB(uint16_t, 8); }
+#undef EPB
+  return hipGetLastError();
+}
+
+// slow path of the owner (kernels.h: launch_ep_bcast_unpack): one workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void ep_bcast_unpack_kernel(RouteArgs r, EpBcastArgs b, void* recv_like, int64_t ld) {
+  __shared__ unsigned long long s_own[EP_MAX_PEERS];
+  const EpPeers& pv = b.peers;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    uint64_t own[EP_MAX_PEERS];
+    epb_owned_sets(r, pv, lane, true, own);  // (behind a wait kernel the poll succeeds at once)
+#pragma unroll
+    for (int q = 0; q < EP_MAX_PEERS; ++q)
+      if (lane == 0) s_own[q] = own[q];
+  }
+  __syncthreads();
+  constexpr int EPV = DT<T>::EPV;
+  const int cpr = r.H / EPV;
+  const int nrows = pv.size * pv.cap_rows;
+  T* out = reinterpret_cast<T*>(recv_like);
+  for (int row = tid; row < nrows; row += blockDim.x) {  // tails: expert id of the row, -1 = unused
+    const int q = row / pv.cap_rows, pos = row - q * pv.cap_rows;
+    uint64_t m = s_own[q];
+    for (int i = 0; i < pos && m; ++i) m &= m - 1;
+    reinterpret_cast<int32_t*>(out + (size_t)row * ld + r.H)[0] = m ? (int)__builtin_ctzll(m) : -1;
+  }
+  for (int i = tid; i < pv.size * pv.cap_rows * cpr; i += blockDim.x) {  // the token's row, once per owned chosen expert
+    const int row = i / cpr, c = i - row * cpr;
+    const int q = row / pv.cap_rows, pos = row - q * pv.cap_rows;
+    if (pos < __popcll(s_own[q])) {
+      const T* src = reinterpret_cast<const T*>(pv.base[pv.rank] + pv.recv_off + (int64_t)q * pv.cap_rows * pv.recv_row_bytes);
+      *reinterpret_cast<u32x4*>(out + (size_t)row * ld + (size_t)c * EPV) = ld16(src + (size_t)c * EPV);
+    }
+  }
+}
+hipError_t launch_ep_bcast_unpack(const RouteArgs& r, const EpBcastArgs& b, void* recv_like, int64_t ld, int dtype, hipStream_t st) {
+  if (dtype == DT_F16) hipLaunchKernelGGL(ep_bcast_unpack_kernel<half_t>, dim3(1), dim3(256), 0, st, r, b, recv_like, ld);
+  else hipLaunchKernelGGL(ep_bcast_unpack_kernel<uint16_t>, dim3(1), dim3(256), 0, st, r, b, recv_like, ld);
+  return hipGetLastError();
+}
+
 }  // namespace moeinf

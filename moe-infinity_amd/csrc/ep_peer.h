@@ -45,7 +45,8 @@ struct EpPeerWindow {
   void* base = nullptr;  // this rank's window
   size_t bytes = 0;
   int cap_rows = 0;
-  int64_t recv_off = 0, ret_off = 0, recv_row_bytes = 0, ret_row_bytes = 0;
+  int64_t recv_off = 0, ret_off = 0, bcast_off = 0, recv_row_bytes = 0, ret_row_bytes = 0;
+  int bcast_stride = 0;  // bytes per rank in the broadcast region (E gate logits, batch-1 broadcast form)
   const char* mem_kind = "";
   std::vector<void*> peer;       // window of every rank as mapped here
   std::vector<char> opened;      // 1: mapped with hipIpcOpenMemHandle (close it)
@@ -58,12 +59,14 @@ struct EpPeerWindow {
   static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
   // allocate + zero the window; "" or an error text
-  std::string create(int size, int cap, int64_t recv_row, int64_t ret_row) {
+  std::string create(int size, int cap, int64_t recv_row, int64_t ret_row, int num_experts) {
     if (size > EP_MAX_PEERS) return "peer-store exchange supports up to " + std::to_string(EP_MAX_PEERS) + " ranks";
     cap_rows = cap; recv_row_bytes = recv_row; ret_row_bytes = ret_row;
     recv_off = EP_WINDOW_HDR;
     ret_off = align_up(recv_off + (int64_t)size * cap * recv_row, 256);
-    bytes = (size_t)align_up(ret_off + (int64_t)size * cap * ret_row, 4096);
+    bcast_off = align_up(ret_off + (int64_t)size * cap * ret_row, 256);
+    bcast_stride = (int)align_up((int64_t)num_experts * 4, 256);
+    bytes = (size_t)align_up(bcast_off + (int64_t)size * bcast_stride, 4096);
     // uncached (MTYPE UC): no cache level of this GPU keeps a line of the window, so a consumer's plain loads see what a
     // peer's kernel stored a moment ago; measured alternatives: tools/ipc_probe.hip
     const char* want = getenv("MOEINF_EP_PEER_MEM");
@@ -130,6 +133,7 @@ struct EpPeerWindow {
     memset(v, 0, sizeof *v);
     for (int p = 0; p < size; ++p) v->base[p] = (uint64_t)peer[p];
     v->recv_off = recv_off; v->ret_off = ret_off; v->recv_row_bytes = recv_row_bytes; v->ret_row_bytes = ret_row_bytes;
+    v->bcast_off = bcast_off; v->bcast_stride = bcast_stride;
     v->timeout_ticks = timeout_ticks; v->done = done; v->err = err; v->epoch = epoch;
     v->rank = rank; v->size = size; v->cap_rows = cap_rows; v->on = 1; v->poll = poll ? 1 : 0;
   }

@@ -31,6 +31,8 @@ struct EpPeers {
   int32_t* done;                // arrival counter of many-workgroup producers (this device, zero between launches)
   int32_t* err;
   uint32_t epoch;               // number of this exchange (1, 2, ...)
+  int64_t bcast_off;            // broadcast region: [ep_size] x bcast_stride bytes (the E gate logits of rank p's token)
+  int bcast_stride;
   int rank, size, cap_rows;
   int on;                       // 0: the classic form (send buffer + a collective); the rest of the struct is unused
   int poll;                     // 1: consumer kernels poll their flags themselves; 0: a one-wave wait kernel runs in front
@@ -243,6 +245,31 @@ struct EpOwnArgs {
                         // every output row straight into its home rank's window and the last workgroup publishes
 };
 hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st);
+// ---- batch-1 decode over the peer-store exchange, BROADCAST form (every rank brings ONE token; round 4) -------------------
+// The routed form needs a router launch between the gate and the exchange (route_index + pack).  With one token per rank the
+// home rank instead BROADCASTS (its token's row, its E gate logits) to every rank, and every owner's FFN stage 1 routes for
+// itself — for all ep_size tokens — exactly as the local batch-1 path does for one (ffn1_selfroute, route_set_lean): the same
+// logits through the same instructions give the same top-k on every rank, so the owners agree with the home rank's combine
+// without a word of routing crossing the fabric.  Launches per layer: gate -> stage 1 (block 0: broadcast + home routing;
+// others: poll, route ep_size tokens, stream) -> stage 2 (from stage 1's records, outputs stored home) -> combine.
+struct EpBcastArgs {
+  const void* x;          // [1, H] this rank's token
+  int32_t* pair_pos;      // [K] -> ret row of every pair of the home token (owner * cap_rows + position)
+  int32_t* mirror;        // pinned routing mirror of the OWNER side (optional)
+  EpPeers peers;
+};
+// stage 1.  r / a: router arguments of the home token (r.logits = its gate logits, written by the gate launch); s1: routed
+// stage-1 descriptor (in = this rank's recv region, ld_in = exchange row elements); sh2: hidden shared expert's stage 2 or
+// nullptr; rec: stage-2 records.  with_bcast = 0: block 0's work was done by launch_ep_bcast (fallback paths).
+hipError_t launch_ffn_epb_stage1(const RouteArgs& r, const FfnStage& s1, const FfnStage* sh2, const EpBcastArgs& b, EpOwnArgs::Rec* rec,
+                                 int max_active, int with_bcast, hipStream_t st);
+// the broadcast + the home token's routing as a launch of its own
+hipError_t launch_ep_bcast(const RouteArgs& r, const EpBcastArgs& b, hipStream_t st);
+// owner side, slow path (an owned expert is not resident: the host must see the routing): wait for the broadcasts, route the
+// ep_size tokens and write what the ROUTED form would have delivered — rows with expert-id tails — into a local staging buffer
+// `recv_like` [ep_size*cap_rows, ld] so that the generic owner path can take over
+hipError_t launch_ep_bcast_unpack(const RouteArgs& r, const EpBcastArgs& b, void* recv_like, int64_t ld, int dtype, hipStream_t st);
+
 // peer-store exchange, owner side, generic path (more rows than the self-indexing kernel takes): copy the valid rows of
 // y [ep_size*cap_rows, H] (valid = the received row's tail >= 0) into their home ranks' windows and publish
 hipError_t launch_ep_push(const void* y, const void* recv, int64_t ld_recv, int H, int dtype, const EpPeers& peers, hipStream_t st);

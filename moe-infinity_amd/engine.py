@@ -392,6 +392,10 @@ class MoEEngine:
     def ep_select_transport(self, name: str):
         check(self.lib.moeinf_ep_select_transport(self._h, {"rccl": 1, "peer-store": 2}[name]))
 
+    def ep_set_uniform_tokens(self, on: bool = True):
+        """every rank passes the same token count to every ep_moe_forward: one-token forwards take the broadcast form"""
+        check(self.lib.moeinf_ep_set_uniform_tokens(self._h, 1 if on else 0))
+
     def ep_transport(self) -> dict:
         o = (C.c_int32 * 4)()
         check(self.lib.moeinf_ep_transport(self._h, o))

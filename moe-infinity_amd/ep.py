@@ -75,12 +75,14 @@ class ExpertParallelMoE:
 
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
                  group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None,
-                 native: Optional[bool] = False, transport: Optional[str] = None):
+                 native: Optional[bool] = False, transport: Optional[str] = None, uniform_tokens: bool = False):
         """transport (decode-sized, fixed-capacity exchanges; prefill-sized ones always go through torch.distributed):
         "peer-store" = rows stored straight into the peers' windows, no collective (csrc/ep_peer.h); "rccl" = RCCL called from
         inside the engine; both = ONE host call per layer; "torch" = all_to_all_single, five host calls per layer; "auto" =
         the first of those three that passes its self-test on EVERY rank.  ``native`` is the older switch: False = "torch",
-        None / True = "auto"."""
+        None / True = "auto".  ``uniform_tokens``: the caller's promise that every rank passes the same token count to every
+        forward (a decode loop does) — one-token forwards over the peer-store transport then take the broadcast form (four
+        launches per layer; include/moeinf.h: moeinf_ep_set_uniform_tokens)."""
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
@@ -126,6 +128,7 @@ class ExpertParallelMoE:
             self.native_note = "; ".join(notes)
         if self.native:
             self.ops.engine.ep_select_transport(self.transport)
+            self.ops.engine.ep_set_uniform_tokens(bool(uniform_tokens))
 
     @property
     def profile(self):

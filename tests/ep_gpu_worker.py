@@ -38,14 +38,17 @@ def main():
                     eng.register_expert(l, i, ex)
             if ws[l][2]:
                 eng.register_shared(l, ws[l][2])
-        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64, num_experts=e, transport=transport)
+        # uniform_tokens: one-token forwards (the same count on every rank below) take the broadcast form when the consumer
+        # kernels poll for themselves (MOEINF_EP_PEER_POLL=1); with wait kernels the routed form runs
+        ep = ExpertParallelMoE(HipEpOps(eng), h, k, tmax, torch.bfloat16, dev, var_threshold=64, num_experts=e, transport=transport,
+                               uniform_tokens=os.environ.get("EP_UNIFORM", "0") == "1")
         assert ep.transport == transport, f"rank {rank}: wanted {transport}, got {ep.transport}: {ep.native_note}"
         if transport == "peer-store":
             t = eng.ep_transport()  # the ranks share GPU 0: detected from the PCI bus ids in the blobs
             want_poll = os.environ.get("MOEINF_EP_PEER_POLL", "0") == "1"  # default for ranks that share a GPU: wait kernels
             assert t["transport"] == "peer-store" and t["shared_device"] and t["poll_in_kernels"] == want_poll, t
         dist.barrier()
-        for t in (1, 3 + rank, tmax - 3 * rank):  # batch 1, ragged small batches (fixed form), prefill-sized (variable split)
+        for t in (1, 1, 3 + rank, tmax - 3 * rank, 1):  # batch 1 (twice: decision path, then sync-free), ragged small batches (fixed form), prefill-sized (variable split), batch 1 again
             for l in range(L):
                 x = acts(t, h, torch.bfloat16, 3200 + 7 * t + l + 1000 * rank)
                 out = ep.forward(l, x.to(dev), ws[l][0].to(dev))

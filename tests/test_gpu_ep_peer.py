@@ -88,6 +88,47 @@ def test_peer_store_at_world_size_one_takes_every_owner_path():
                 os.environ.pop("MOEINF_EP_PEER_TIMEOUT_MS", None)
 
 
+@pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2), ("deepseek", 64, 6, 2)])
+def test_batch1_broadcast_form_at_world_size_one(family, e, k, n_shared):
+    """One token per rank with the caller's uniform-token promise: the home rank broadcasts (row, gate logits) and the owner's FFN
+    stage 1 routes for itself (four launches per layer).  First forward of a layer: its experts are not resident yet — the
+    slow path (broadcast launch + unpack into the routed form + generic owner kernels); from the second on: the fast path.
+    Both against the oracle block, bit-stable, and identical to what the routed form returns."""
+    os.environ["MOEINF_EP_PEER_TIMEOUT_MS"] = "2000"
+    try:
+        h, f, L = 512, 384, 2
+        ws, engs = _engines(family, 1, h, f, e, k, n_shared, L, max_tokens=16, seed=5400)
+        eng = engs[0]
+        eng.ep_peer_attach(eng.ep_peer_export(4))
+        assert eng.ep_peer_selftest()
+        for seed in range(3):
+            for l in range(L):
+                x = acts(1, h, torch.bfloat16, 5500 + 10 * seed + l)
+                ref = (R.block_mixtral(x[None], ws[l][0], ws[l][1], top_k=k) if family == "mixtral"
+                       else R.block_deepseek(x[None], ws[l][0], ws[l][1], k, shared=ws[l][2]))
+                eng.ep_set_uniform_tokens(False)
+                routed = torch.empty(1, h, dtype=torch.bfloat16, device=DEV)
+                eng.ep_moe_forward(l, x.to(DEV), ws[l][0].to(DEV), routed)
+                eng.ep_set_uniform_tokens(True)
+                outs = []
+                for _ in range(2):
+                    out = torch.empty(1, h, dtype=torch.bfloat16, device=DEV)
+                    eng.ep_moe_forward(l, x.to(DEV), ws[l][0].to(DEV), out)
+                    eng.sync()
+                    outs.append(out)
+                for out in outs + [routed]:
+                    assert_block_close(out.cpu(), ref, torch.bfloat16, f"broadcast form, {family} e={e}, layer {l}")
+                assert torch.equal(outs[0], outs[1]), "a repeated forward must be bit-identical"
+                if not n_shared:  # (a hidden shared expert's stage 2 splits its reduction over 4 waves here and 8 in the routed
+                    #               form's router launch: the same numbers in another fp32 summation order)
+                    assert torch.equal(outs[0], routed), "broadcast and routed forms must agree bit for bit"
+        st = eng.stats()
+        assert st["expert_misses"] <= L * e
+        eng.close()
+    finally:
+        os.environ.pop("MOEINF_EP_PEER_TIMEOUT_MS", None)
+
+
 def test_peer_store_bootstrap_errors_are_local_and_never_block():
     """every bootstrap step fails locally with a message (wrong blob size, blobs of another shape, attach before export);
     a self-test whose peer never shows up returns False after the timeout instead of hanging"""

@@ -24,9 +24,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,transport,poll", [(2, "peer-store", "0"), (3, "peer-store", "0"), (2, "peer-store", "1"), (2, "torch", "")],
-                         ids=["world2_peer_store_wait_kernels", "world3_peer_store_wait_kernels", "world2_peer_store_polls_inside_the_consumer_kernels", "world2_torch_host_staged"])
-def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport, poll):
+@pytest.mark.parametrize("world,transport,poll,uniform", [(2, "peer-store", "0", "0"), (3, "peer-store", "0", "0"), (2, "peer-store", "1", "0"),
+                                                          (2, "peer-store", "1", "1"), (3, "peer-store", "1", "1"), (2, "torch", "", "0")],
+                         ids=["world2_peer_store_wait_kernels", "world3_peer_store_wait_kernels", "world2_peer_store_polls_inside_the_consumer_kernels",
+                              "world2_batch1_broadcast_form", "world3_batch1_broadcast_form", "world2_torch_host_staged"])
+def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport, poll, uniform):
     """poll: MOEINF_EP_PEER_POLL — "0" = the mode ranks that share a GPU get by default (one-wave wait kernels), "1" = the mode
     of one rank per GPU (the consumer kernels poll their flag words themselves), forced here so that it, too, has run between
     real processes (the test shapes leave most of the GPU idle, so a polling kernel cannot starve the rank it waits for)."""
@@ -35,6 +37,7 @@ def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport, poll):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EP_TRANSPORT=transport)
     if poll:
         env["MOEINF_EP_PEER_POLL"] = poll
+    env["EP_UNIFORM"] = uniform  # "1": every rank promises equal token counts -> one-token forwards take the broadcast form
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     # the ranks share one stdout: their lines can run together
     assert r.returncode == 0 and r.stdout.count("EP_WORKER_OK") == world and r.stdout.count(f"transport {transport}") == world, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
