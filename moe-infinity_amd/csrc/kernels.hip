@@ -607,7 +607,8 @@ __global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
   ffn_rows_item<T, 1, NW, U, 1>(s, blockIdx.x, W, false, W ? 1 : 0, u, red);
   wait_stores_acked();  // this thread's (write-through) y stores have reached device-coherent memory
   __syncthreads();
-  if (tid == 0) is_last = (__hip_atomic_fetch_add(&s.tile_done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == K - 1);
+  // (top-1, Switch: this workgroup is the only one of its column tile — no counter to arrive at)
+  if (tid == 0) is_last = K == 1 ? 1 : (__hip_atomic_fetch_add(&s.tile_done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == K - 1);
   __syncthreads();
   if (is_last) {
     if (s.comb.kind == 2 /*SWITCH: out = Tr(router_prob * expert output), switch_transformers.py:99-109; K == 1*/) {
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
     } else if (tid < 4) {
       combine_apply<T, true>(s.comb, 0, r0 + tid * 4, m);
     }
-    if (tid == 0) s.tile_done[blockIdx.x] = 0;
+    if (tid == 0 && K > 1) s.tile_done[blockIdx.x] = 0;
   }
 }
 

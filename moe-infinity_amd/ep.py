@@ -159,7 +159,7 @@ class ExpertParallelMoE:
         this transport or none does.  Works with any process-group backend — the group only carries 192 bytes per rank — and
         between ranks that share one GPU."""
         eng = getattr(self.ops, "engine", None)
-        if eng is None or self.device.type != "cuda" or not hasattr(eng, "ep_peer_export"):
+        if eng is None or not hasattr(eng, "ep_peer_export"):  # (an engine with this method IS the HIP engine: it only exists on a GPU)
             self.native_note = "ops are not the HIP engine"
             return False
         blob, ok = bytes(eng.PEER_BLOB_BYTES), True

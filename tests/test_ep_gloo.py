@@ -104,3 +104,89 @@ def test_ep_gloo_capacity_of_one_slot_per_token_with_one_expert_per_rank():
         assert p.exitcode == 0
     for rank, worst in res:
         assert worst == 0.0, f"rank {rank}: EP result differs from the oracle block by {worst}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Bootstrap of the engine-side transports (ExpertParallelMoE._try_peer_store): every step is local, its outcome is all-reduced,
+# and ONE rank failing at ANY step must leave EVERY rank on the torch.distributed transport — never some ranks inside a
+# transport the others did not enter.  A stand-in engine plays the C ABI (the real one is tests/test_gpu_ep_*.py).
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeEngine:
+    PEER_BLOB_BYTES = 192
+
+    def __init__(self, rank, world, fail_rank, fail_step):
+        self.rank, self.world, self.fail_rank, self.fail_step = rank, world, fail_rank, fail_step
+        self.attached_with, self.selected, self.uniform, self.forwards = None, None, None, 0
+
+    def _maybe_fail(self, step):
+        if self.rank == self.fail_rank and step == self.fail_step:
+            raise RuntimeError(f"injected failure at {step}")
+
+    def ep_peer_export(self, cap_tokens):
+        self._maybe_fail("export")
+        return bytes([self.rank]) * self.PEER_BLOB_BYTES
+
+    def ep_peer_attach(self, blobs):
+        self._maybe_fail("attach")
+        assert len(blobs) == self.world * self.PEER_BLOB_BYTES
+        assert all(blobs[p * self.PEER_BLOB_BYTES] == p for p in range(self.world)), "blobs must arrive in rank order"
+        self.attached_with = blobs
+
+    def ep_peer_selftest(self):
+        self._maybe_fail("selftest")
+        return not (self.rank == self.fail_rank and self.fail_step == "selftest_false")
+
+    def ep_transport(self):
+        return {"transport": "peer-store", "shared_device": False, "poll_in_kernels": True, "exchanges": 1}
+
+    def ep_select_transport(self, name):
+        self.selected = name
+
+    def ep_set_uniform_tokens(self, on):
+        self.uniform = on
+
+    def ep_moe_forward(self, layer, x2, gate_w, out, batch_rows=1):
+        self.forwards += 1
+
+
+def _bootstrap_worker(rank, world, port, q, fail_rank, fail_step):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ep_cpu_ops import OracleEpOps
+        from moe_infinity_amd.ep import ExpertParallelMoE
+        from oracle.synth import acts, make_weights
+
+        h, f, e, k = 64, 64, 4, 2
+        ws = make_weights("mixtral", h, f, e, 90, torch.bfloat16)
+        ops = OracleEpOps([ws[1]], rank, world, k, e, h)
+        ops.engine = _FakeEngine(rank, world, fail_rank, fail_step)
+        ep = ExpertParallelMoE(ops, h, k, 4, torch.bfloat16, "cpu", num_experts=e, transport="peer-store", uniform_tokens=True)
+        ep.forward(0, acts(2, h, torch.bfloat16, 91 + rank), ws[0])  # collective either way: native (fake) or torch transport (oracle ops)
+        q.put((rank, ep.transport, ep.native, ep.native_note, ops.engine.selected, ops.engine.uniform, ops.engine.forwards))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fail_rank,fail_step", [(2, -1, ""), (3, 1, "export"), (3, 2, "attach"), (2, 0, "selftest"), (3, 1, "selftest_false")])
+def test_transport_bootstrap_is_all_or_nothing(world, fail_rank, fail_step):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, world, port, q, fail_rank, fail_step)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = "peer-store" if fail_rank < 0 else "torch"
+    for rank, transport, native, note, selected, uniform, forwards in res:
+        assert transport == want and native == (want != "torch"), (rank, transport, note)
+        if want == "peer-store":
+            assert selected == "peer-store" and uniform is True and forwards == 1 and "self-test passed on every rank" in note
+        else:  # every rank — the one that failed AND the ones that did not — stayed on torch.distributed and says why
+            assert forwards == 0 and selected is None, (rank, note)
+            assert ("failed" in note) or ("another rank" in note) or ("self-test" in note), note
