@@ -1363,10 +1363,11 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
-    if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
+    if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
+    else if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
-    if (sr && fuse) HIPCHK(launch_ffn2_decode1(s2, st));
+    if (sr && fuse && T == 1) HIPCHK(launch_ffn2_decode1(s2, st));
     else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[4], st));
   } else {
@@ -1492,7 +1493,16 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // (round 4) Switch: top-1, plain ReLU experts, bf16 or fp32; a single token can never exceed the per-row capacity
   const bool sr_switch = g->cfg.router_kind == MOEINF_ROUTER_SWITCH && et_ == MOEINF_EXPERT_SWITCH && K == 1 && !g->has_shared &&
                          (flags & MOEINF_FWD_NO_COMBINE) == 0 && ia.capacity != 0 && fuse_mode() != 0;
-  const bool selfroute = selfroute_env && !route_only && mp.fast && T == 1 && K <= 8 && E <= 64 && !g->ovr_out && (sr_gated || sr_switch);
+  // (round 4) decode batches of 2..8 tokens of the gated families: the same idea, every workgroup routes every token
+  // Measured (profiles/r04_small_batch_selfroute.txt): DeepSeek-V2-Lite batch 2 / 4: 1.530 -> 1.373 / 2.163 -> 2.056 ms per step;
+  // batch 8 (48 pairs over 64 experts): 3.17 -> 3.61 — every workgroup of the worst-case grid (48 expert slots) pays eight
+  // routings before it knows that its slot is empty.  Hence at most 24 (token, expert) pairs; Mixtral (8 experts, all of them
+  // active from batch 4 on) gains 2.3 / 0.9 / 0.6 % at batch 2 / 4 / 8.
+  static const int sr_multi_env = getenv("MOEINF_SELFROUTE_MULTI") ? atoi(getenv("MOEINF_SELFROUTE_MULTI")) : 8;
+  static const int sr_multi_pairs = getenv("MOEINF_SELFROUTE_MULTI_PAIRS") ? atoi(getenv("MOEINF_SELFROUTE_MULTI_PAIRS")) : 24;
+  const bool sr_multi = T >= 2 && T <= std::min(8, sr_multi_env) && T * K <= std::min(64, sr_multi_pairs) && sr_gated;
+  const bool selfroute = selfroute_env && !route_only && mp.fast && K <= 8 && E <= 64 && !g->ovr_out &&
+                         ((T == 1 && (sr_gated || sr_switch)) || sr_multi);
   g->last_selfroute = selfroute;
   FfnStage sh1, sh2;
   if (hide_shared) {

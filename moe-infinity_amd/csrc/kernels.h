@@ -169,6 +169,10 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
 // routes for itself from the gate logits (no top-k/index launch).  r/a as for launch_route_index (a.shared must be 0),
 // s1 = the routed stage-1 descriptor, sh2 = the hidden shared expert's stage-2 descriptor or nullptr.
 hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st);
+// The same for decode batches of 2..8 tokens (bf16 / fp16 gated families, T*K <= 64): the meta block routes every token and
+// builds the index, every other workgroup routes the tokens for itself; stage 2 is the generic launch_ffn_stage (combine fused).
+// max_active = min(E, T*K).
+hipError_t launch_ffn1_selfroute_multi(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, int max_active, hipStream_t st);
 // ... and its stage 2 (s2.fuse_combine set, K = s2.comb.K active experts, one token): blob pointers and combine weights
 // come from the records the self-routing launch left in s2.dec_w / s2.dec_cw
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st);

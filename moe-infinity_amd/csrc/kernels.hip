@@ -588,6 +588,99 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same for SMALL decode batches (2..SR_MAX_T tokens; round 4): FFN stage 1 routes for itself for EVERY token.  The meta
+// block (block 0) runs the generic router per token and the one-wave dispatch index — everything stage 2, the combine and the
+// host read.  Every other workgroup repeats the tokens' top-k sets with route_set_lean (one call per token), takes the u-th
+// smallest expert ANY token chose, and streams it over the rows of the tokens that chose it; its expert-sorted row offset is
+// the number of (token, expert) pairs with smaller expert ids — the very order index_small produces (stable counting sort by
+// expert, pairs in token order), so stage 2 (the generic kernel, combine fused) finds the rows where the index says they are.
+// grid = 1 + n_sh2 + max_active * n_rg.  Saves the top-k/index launch of decode batches the batcher produces (serving).
+constexpr int SR_MAX_T = 8;
+template <typename T, int NW, int U>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(96))) void ffn1_selfroute_multi_kernel(RouteArgs r, IndexArgs a, FfnStage s, FfnStage sh2, int n_rg, int n_sh2) {
+  __shared__ float red[NW][2][256];
+  __shared__ int s_in[SR_MAX_T];
+  __shared__ unsigned long long s_w;
+  __shared__ int s_cnt, s_off;
+  static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
+  const int lane = threadIdx.x & 63;
+  const int Tn = r.T;
+  int blk = (int)blockIdx.x - 1;
+  if (blk < 0) {  // meta block: dispatched first
+    for (int t = threadIdx.x >> 6; t < Tn; t += NW) route_token(r, t, lane);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      int* scratch = reinterpret_cast<int*>(&red[0][0][0]);
+      index_small(a, scratch, scratch + IDX_MAXE);
+    }
+    return;
+  }
+  if (blk < n_sh2) {  // hidden shared expert, stage 2, all tokens (h_shared was written by the gate launch)
+    const char* Wsh = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
+    ffn_rows_item<T, 1, NW, U, 1>(sh2, blk, Wsh, true, Tn, 0, reinterpret_cast<float (*)[1][256]>(&red[0][0][0]));
+    return;
+  }
+  blk -= n_sh2;
+  const int u = blk / n_rg, rg = blk - u * n_rg;
+  if (threadIdx.x < 64) {
+    uint64_t wp = 0;
+    if (lane < r.E) wp = s.wptr[lane];
+    uint64_t chosen[SR_MAX_T];
+    uint64_t present = 0;
+#pragma unroll
+    for (int t = 0; t < SR_MAX_T; ++t) {
+      chosen[t] = 0;
+      if (t < Tn) chosen[t] = route_set_lean(r.logits + (size_t)t * r.E, r.E, r.K, lane);  // wave-uniform branch
+      present |= chosen[t];
+    }
+    uint64_t m = present;
+    for (int i = 0; i < u; ++i) m &= m - 1;  // drop the u smallest ids
+    const int e = m ? (int)__builtin_ctzll(m) : -1;
+    int cnt = 0, off = 0;
+    if (e >= 0) {
+      const uint64_t below = (1ull << e) - 1ull;
+#pragma unroll
+      for (int t = 0; t < SR_MAX_T; ++t) {
+        off += __popcll(chosen[t] & below);
+        if ((chosen[t] >> e) & 1ull) {
+          if (lane == 0) s_in[cnt] = t;
+          ++cnt;
+        }
+      }
+    }
+    uint64_t wsel = 0;
+    if (e >= 0) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wp, e);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wp >> 32), e);
+      wsel = ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) { s_w = wsel; s_cnt = cnt; s_off = off; }
+  }
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt == 0) return;  // fewer than u+1 distinct experts chosen (block-uniform)
+  const char* W = reinterpret_cast<const char*>(s_w);
+  if (W == nullptr) {  // never on the sync-free path
+    if (threadIdx.x == 0 && rg == 0) atomicExch(s.miss_flag, 1);
+    return;
+  }
+  ffn_rows_item<T, 2, NW, U, 1>(s, rg, W, false, cnt, s_off, red, -1, s_in, nullptr);
+}
+
+hipError_t launch_ffn1_selfroute_multi(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, int max_active, hipStream_t st) {
+  const int n_rg = (s1.R + 15) / 16;
+  const int n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
+  const dim3 grid(1 + n_sh2 + max_active * n_rg);
+  const size_t dyn = grid.x > 4 * 256 ? 30 * 1024 : 0;  // as launch_ffn1_selfroute
+#define SRM(TT, UU) hipLaunchKernelGGL((ffn1_selfroute_multi_kernel<TT, 4, UU>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2)
+  if (s1.dtype == DT_F16) { if (grid.x > 4 * 256) SRM(half_t, 4); else SRM(half_t, 8); }
+  else { if (grid.x > 4 * 256) SRM(uint16_t, 4); else SRM(uint16_t, 8); }
+#undef SRM
+  return hipGetLastError();
+}
+
 // Stage 2 of a batch-1 self-routed forward, with the combine in its tail.  Differences from ffn_rows_kernel's fused
 // form: one scalar round in the prologue (blob pointer dec_w[u] instead of active[u] -> {wptr, counts, offsets}); the
 // combine weights (dec_cw, ascending expert id = rows 0..K-1 of y) are fetched at kernel START, so the last-arriving

@@ -699,6 +699,43 @@ def test_batch1_decode_selfrouting_stage1(family, e, k, n_shared):
     eng.close()
 
 
+@pytest.mark.parametrize("t", [2, 3, 5, 8])
+@pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 64, 6, 2), ("deepseek", 16, 4, 0)],
+                         ids=["mixtral_e8k2", "deepseek_e64k6_shared", "deepseek_e16k4"])
+def test_small_decode_batches_selfrouting_stage1(family, e, k, n_shared, t):
+    """Decode batches of 2..8 tokens on the sync-free path (round 4): FFN stage 1 routes EVERY token for itself
+    (ffn1_selfroute_multi_kernel: no top-k/index launch); its meta block writes the routing outputs and the dispatch index, the
+    generic stage 2 (combine fused) finds the expert-sorted rows where that index says they are.  Against the oracle: routing,
+    dispatch index, expert rows, block output; repeated forwards bit-identical; MOEINF_SELFROUTE_MULTI is on by default."""
+    h, f = 512, 384
+    gate, experts, shared = make_weights(family, h, f, e, 4300 + e + t, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=8)
+    register_all(eng, experts, shared)
+    g = gate.to(DEV)
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    for seed in range(4):
+        x = acts(t, h, torch.bfloat16, 4400 + seed)
+        if seed == 3:
+            x[1] = x[0]  # two identical tokens: the same experts, two rows each
+        if family == "mixtral":
+            ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+        else:
+            ref = R.block_deepseek(x[None], gate, experts, k, shared=shared)
+        outs = []
+        for rep in range(2):
+            out = eng.forward(0, x.to(DEV), g)
+            r = _check_routing_exact(eng, ref, k_sorted=(family == "mixtral"))
+            _check_dispatch_index(r, ref)
+            rows = oracle_expert_rows(ref, e)
+            assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+            assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block output")
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1])
+    assert eng.stats()["expert_misses"] == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("family,e,k", [("mixtral", 8, 2), ("deepseek", 16, 6)])
 def test_batch1_selfrouting_ties_lowest_index(family, e, k):
     """Exact ties in front of the self-routing kernel's own top-k (route_set_lean): identical gate rows -> identical
