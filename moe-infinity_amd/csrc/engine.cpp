@@ -1290,7 +1290,7 @@ static int wait_late(moeinf_engine* g, int layer, hipStream_t st, std::vector<in
 // chunk may recycle its slots once its kernels have drained.
 static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_t st, hipEvent_t ev_before,
                        hipEvent_t ev_mid, hipEvent_t ev_after, int64_t ld_x = 0, const CombineArgs* fuse = nullptr,
-                       bool* fused = nullptr) {
+                       bool* fused = nullptr, int rows_hint = 0) {
   const int E = g->E, E1 = E + 1;
   const int na = g->h_mirror[0];
   const int32_t* active = g->h_mirror + 1 + E1;
@@ -1314,7 +1314,9 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
       s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse;
       if (fused) *fused = true;
     }
-    int max_rows = 0;
+    // the exact maximum, but never below the estimate the sync-free path passes for the same forward (rows_hint): both paths
+    // then pick the same kernel form unless the routing is skewed beyond 1.5 x the mean
+    int max_rows = rows_hint;
     for (int i = a; i < b; ++i) max_rows = std::max(max_rows, (int)g->h_mirror[1 + active[i]]);
     HIPCHK(launch_ffn_stage(s1, b - a, max_rows, st));
     if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
@@ -1384,7 +1386,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     // the host holds this layer's routing right now: predict and request the next layers' experts BEFORE serving this
     // layer's misses, so the speculative queue is ordered and the copies start as soon as the link is free
     if (g->pred_tracer && !g->ovr_out) CHK(predictor_observe(g, layer, g->h_mirror, /*prefetch=*/true));
-    CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused));
+    CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused, exp_rows));
   }
   return MOEINF_OK;
 }

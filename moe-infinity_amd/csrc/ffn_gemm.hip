@@ -1,6 +1,6 @@
 // ffn_gemm.hip — the grouped-GEMM forms of the expert FFN stage for experts with MANY rows (prefill, large batches):
 // ffn_gemm (register-tiled), ffn_gemm_lds (both operands through LDS), ffn_gemm_hyb (activations through LDS, weights
-// straight to registers), ffn_gemm_ring (gated stage, register ring).  Selected by launch_ffn_gemm, which
+// straight to registers), ffn_gemm_ring2 (register ring of weight tiles, software-pipelined; long reductions).  Selected by launch_ffn_gemm, which
 // launch_ffn_stage (kernels.hip) calls for more than 16 rows per expert.
 #include "kdev.h"
 
@@ -504,63 +504,93 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// ffn_gemm_ring: the GATED stage (x -> silu(x W1^T) * (x W3^T)) for experts with ~64..1000 tokens (prefill), bf16,
-// long reductions (K >= 4096).
-// What bounds ffn_gemm_lds / ffn_gemm_hyb at ~128 tokens per expert is WEIGHT BYTES IN FLIGHT: one stage ahead,
-// drained by `vmcnt(0)` + `__syncthreads()` every k-step, leaves 16-32 KiB of weights outstanding per CU against a
-// ~2 us HBM round trip = ~4 TB/s chip-wide (measured 3.4-3.9).  Here
-//   * block = 8 waves, ONE block per CU; wave w owns the same 16 rows of BOTH matrices against NTB token groups
-//     (128 or 256 tokens): 16 / 32 accumulator tiles, SiLU*mul in registers;
-//   * weights go HBM -> VGPRs directly (the tiled layout IS the MFMA A fragment) through a ring of D register stages
-//     (a stage = 2 k-tiles = 4 one-KiB tiles per wave); D = 4: 12 KiB per wave = 96 KiB per CU in flight (D = 3 for
-//     the 256-token variant, which needs the registers for accumulators).  The loads are inline asm so that the
-//     compiler's vmcnt bookkeeping cannot drain the ring;
-//   * activations go L2 -> LDS by global_load_lds in full 128-byte lines (source-side XOR swizzle, as ffn_gemm_lds
-//     XL) through a ring of 3 LDS stages;
-//   * ONE raw s_barrier per stage and a COUNTED s_waitcnt: every wave issues the same VM ops in the same order
-//     (... W(k) X(k) W(k+1) X(k+1) ..., 4 weight loads and XPW activation DMAs per stage; pieces of absent token
-//     groups are still issued, clamped, so the count never varies).
-// Mixtral stage 1 at 512 tokens (128 rows per expert): 565 -> 420-450 us per layer (3.4 -> 4.4 TB/s); at 2048 tokens
-// 1490 -> 1250-1420 us.  The same structure for the PLAIN stage (two row groups per wave, or one row group with the
-// k-tiles of a 4-tile stage split over two partial accumulators) was built and measured too: Mixtral's down
-// projection 250 -> 300-380 us at 512 tokens, 805 -> 840-1180 us at 2048 — slower than ffn_gemm_lds there (a matrix
-// with H = 4096 rows gives 128-256 eight-wave blocks for 256 CUs), so the plain stage stays on ffn_gemm_lds.
-// Requires K % 64 == 0.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ring_load(u32x4& dst, const char* p) {
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void ring_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-  // the counted wait carries the stage's registers as in/out operands: no MFMA that reads them can be scheduled above it
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void ring_wait8(u32x4 (&w)[8]) {
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : "n"(N) : "memory");
+
+// ------------------------------------------------------------------------------------------------
+// ffn_gemm_ring2 (round 4): BOTH stages (NMAT = 2: gated, NMAT = 1: plain with the bias / ReLU epilogues) for experts with
+// ~33..340 rows and long reductions (K >= 4096, K % 64 == 0), 2-byte types.  Weight-streaming GEMM at ~128 rows per expert:
+// 128 flop per weight byte, i.e. bound by the HBM stream as long as the multiply phase hides behind it.
+//   * block = 8 waves, ONE block per CU; wave w owns the same 16 rows of the stage's matrix (gated: of BOTH matrices) against
+//     NTB token groups (128 / 192 / 256 tokens per pass): the accumulators never leave the registers;
+//   * weights go HBM -> VGPRs directly (the tiled layout IS the MFMA A fragment) through a ring of D register stages (a stage =
+//     2 k-tiles = 2 or 4 one-KiB tiles per wave); inline-asm loads, so the compiler's vmcnt bookkeeping cannot drain the ring;
+//   * activations go L2 -> LDS by global_load_lds in full 128-byte lines (8 rows x 128 B per instruction, source-side XOR
+//     swizzle, conflict-free ds_read_b128) through a ring of 3 LDS stages;
+//   * ONE raw s_barrier per stage and a COUNTED s_waitcnt: every wave issues the same VM ops in the same order.
+// It replaces round 2's ffn_gemm_ring (gated stage; same data path) and, for these shapes, ffn_gemm_lds (plain stage).  What
+// the counters said about those two at 512 Mixtral tokens (profiles/r04_pmc_prefill512_ring_lds_before_ring2.json): fabric
+// traffic 1.05x / 1.25x the algorithmic bytes, no LDS bank conflicts, MFMA pipe 31 % / 22 % busy, streams at 4.1 / 3.6 TB/s.
+// The ISA showed why.  ffn_gemm_ring at 254 registers had eight left for activation fragments: a wave ran
+// `2 x ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs` twelve times per k-tile — an exposed LDS round trip in front of every
+// 64 cycles of matrix work — and all eight VMEM instructions of a stage went out back to back right behind the barrier, from
+// all eight waves at once.  ffn_gemm_lds has ONE stage in flight per block (two buffers, `vmcnt(0)` + __syncthreads per
+// k-step): 224 stages x one memory latency = the 262 us it took.  Here, per stage:
+//   wait (counted vmcnt) -> s_barrier -> fragments of chunk 0 -> for every chunk: [fragments of the NEXT chunk ->
+//   one or two of the stage's VMEM instructions -> the chunk's 8 MFMAs];
+//   * two fragment sets (2 x CW x 4 registers): an LDS read is always one chunk of MFMAs ahead of its use.  The reads are
+//     inline asm with counted lgkmcnt waits of their own — with compiler-scheduled reads every LDS-DMA between a read and its
+//     use turned the wait into lgkmcnt(0), i.e. the prefetched chunk was waited for as well;
+//   * the stage's VMEM instructions (activation DMA pieces of stage S+2, weight tiles of stage S+D-1) are spread over the
+//     chunks — same order in every wave, so the counted wait still holds — and overlap the partner wave's MFMAs;
+//   * the number of token-group PAIRS present is a compile-time constant of the pass (switch over instantiations of the whole
+//     k-loop): no branch inside a stage, absent pairs are neither fetched nor multiplied (a 140-row expert: 10 groups of 16,
+//     not 12 or 16);
+//   * registers: accumulators 16 x pairs (gated) / 8 x pairs (plain) + ring D x WL x 4 + fragments 32 / 64.
+// The plain stage: a wave owns 16 rows of ONE matrix, a stage is still two k-tiles (2 KiB per wave); 128 rows per workgroup
+// = 256 workgroups for Mixtral's down projection, one per CU.
+// Mixtral-8x7B, 512 tokens, us per layer: gate/up 441 -> 374 (4.3 -> 5.1 TB/s), down 261 -> 202 (3.7 -> 4.8 TB/s).
+// ------------------------------------------------------------------------------------------------
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void dispatch_np(int np, F&& f) {
+  if constexpr (LO >= HI) {
+    f(std::integral_constant<int, HI>{});
+  } else {
+    if (np <= LO) f(std::integral_constant<int, LO>{});
+    else dispatch_np<LO + 1, HI>(np, f);
+  }
 }
 
-// KT = k-tiles (32 k each) per stage: 2 (a stage = 4 one-KiB weight tiles per wave) or 4 (8 tiles: twice the weight
-// bytes in flight per wave — the 512-token Mixtral prefill is bound by exactly that: 64 KiB in flight per CU against a
-// ~2.5 us HBM round trip under load = 4.1 TB/s; with KT = 4 the activation stage doubles too, so it goes with NTB = 12
-// (192 tokens per pass, 3 x 48 KiB of LDS) and D = 3).
-// NWV = waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (ONE per SIMD: the whole 512-entry register file,
-// room for a 4-stage ring of 8-tile stages next to 96-128 accumulator registers; 14336 rows / 64 = 224 workgroups per
-// expert x 8 experts = 1792 = exactly seven rounds on 256 CUs, where 896 eight-wave workgroups are three and a half).
-template <int NTB, int D, int KT, int NWV>
-__global__ __launch_bounds__(NWV * 64) void ffn_gemm_ring_kernel(FfnStage s) {
-  static_assert(D == 3 || D == 4, "register ring of 3 or 4 stages");
-  static_assert(KT == 2 || KT == 4, "2 or 4 k-tiles per stage");
-  static_assert(NTB % 4 == 0, "token groups are multiplied in chunks of 4");
-  typedef uint16_t T;
-  constexpr int EPT = 32, EPV = 8;
-  constexpr int WL = KT * 2;                // weight tiles (1 KiB) per wave and stage: KT k-tiles x 2 matrices
-  constexpr int NLINE = KT / 2;             // full 128-byte activation lines per row and stage
-  constexpr int XPW = NLINE * 2 * NTB / NWV;  // activation DMA pieces (8 rows x 128 B) per wave and stage
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16(u32x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+// s_waitcnt lgkmcnt(N) that carries the first W fragment registers: no MFMA reading them can be scheduled above it
+template <int W, int N, int CW>
+__device__ __forceinline__ void frag_wait(u32x4 (&f)[CW]) {
+  static_assert(W == 2 || W == 4 || W == 6 || W == 8, "chunk widths are whole pairs");
+  if constexpr (W == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N) : "memory");
+  else if constexpr (W == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N) : "memory");
+  else if constexpr (W == 6) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N) : "memory");
+  else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N) : "memory");
+}
+
+template <int WL, int N>
+__device__ __forceinline__ void ring2_wait(u32x4 (&w)[WL]) {
+  static_assert(WL == 2 || WL == 4, "2 or 4 weight tiles per stage");
+  if constexpr (WL == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N) : "memory");
+}
+
+template <typename T, int NMAT, int NTB, int D>
+__global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
+  static_assert(sizeof(T) == 2, "bf16 / fp16");
+  static_assert(D >= 3 && D <= 6, "register ring of 3..6 stages");
+  static_assert(NTB % 4 == 0, "whole activation DMA pieces per wave");
+  constexpr int NWV = 8, KT = 2, EPT = 32, EPV = 8;
+  constexpr int WL = KT * NMAT;             // weight tiles (1 KiB) per wave and stage
+  constexpr int XPW = 2 * NTB / NWV;        // activation DMA pieces (8 rows x 128 B) per wave and stage
   constexpr int XSTAGE = KT * NTB * 1024;   // activation bytes per stage
   constexpr int NX = 3;                     // LDS ring
-  static_assert((NLINE * 2 * NTB) % NWV == 0, "pieces must divide over the waves");
+  constexpr int CW = 8 / NMAT;              // token groups per chunk: 8 MFMAs between two fragment batches
   __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
 
   const int u = blockIdx.y;
@@ -584,126 +614,150 @@ __global__ __launch_bounds__(NWV * 64) void ffn_gemm_ring_kernel(FfnStage s) {
   const int KB = K / EPT;
   const int KS = KB / KT;
   const size_t rg_stride = (size_t)KB * 1024;
-  // this wave's two weight-tile streams (a row group past the end re-reads the last one; its results are dropped)
+  // this wave's weight-tile stream(s) (a row group past the end re-reads the last one; its results are dropped)
   const int rg = min((int)blockIdx.x * NWV + wave, nrg_total - 1);
   const bool rg_live = (int)blockIdx.x * NWV + wave < nrg_total;
-  const char* ap[2];
+  const char* ap[NMAT];
   ap[0] = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg * rg_stride + lane * 16;
-  ap[1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg * rg_stride + lane * 16;
+  if (NMAT == 2) ap[NMAT - 1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg * rg_stride + lane * 16;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // fragment read of (token n of group g, k-tile kk): piece 2g + n/8, byte (n%8)*128 + (((kk*4 + q) ^ (n%8)) << 4)
+  const int rr = n & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  uint32_t frag_off[KT];
+#pragma unroll
+  for (int kk = 0; kk < KT; ++kk) frag_off[kk] = (n >> 3) * 1024 + rr * 128 + ((((kk & 1) * 4 + q) ^ rr) << 4);
 
   for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
     const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);  // token groups present in this pass (block-uniform)
-    // activation DMA pieces of this wave: piece id pid = wave + NWV*i -> (line li = pid / (2*NTB), 8-row group pg = pid % (2*NTB))
     const T* xrp[XPW];
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
-      const int pid = wave + NWV * i;
-      const int li = pid / (2 * NTB), pg = pid - li * (2 * NTB);
+      const int pg = wave + NWV * i;  // 8-row piece of the pass
       const int trow = tile0 * 16 + pg * 8 + (lane >> 3);
       const int srow = off + min(trow, cnt - 1);
       const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + li * 2 * EPT + (((lane & 7) ^ (lane >> 3)) * EPV);
+      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (((lane & 7) ^ (lane >> 3)) * EPV);
     }
-    f32x4 acc[NTB][2];
+    auto pass = [&](auto npc) {
+      constexpr int NG = decltype(npc)::value * 2;  // token groups multiplied in this pass
+      constexpr int NCH = (NG + CW - 1) / CW;       // chunks per k-tile
+      constexpr int NSLOT = KT * NCH;
+      constexpr int XPWP = (2 * NG + NWV - 1) / NWV;  // activation DMA pieces per wave and stage that hold rows of this pass
+      constexpr int OPS = XPWP + WL;                  // VMEM instructions per wave and stage
+      constexpr int NWAIT = (D == 3 ? WL : 2 * WL) + XPWP;  // what may stay in flight when stage S is consumed (see below)
+      f32x4 acc[NG][NMAT];
 #pragma unroll
-    for (int b = 0; b < NTB; ++b) { acc[b][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    u32x4 wr[D][WL];  // [ring stage][k-tile * 2 + matrix]
-    auto issue_w = [&](int ks, u32x4 (&dst)[WL]) {
-      const int kb = min(ks, KS - 1) * KT;  // past the end: re-read the last stage (never multiplied), the count stays fixed
+      for (int b = 0; b < NG; ++b)
 #pragma unroll
-      for (int kk = 0; kk < KT; ++kk) {
-        ring_load(dst[kk * 2 + 0], ap[0] + (size_t)(kb + kk) * 1024);
-        ring_load(dst[kk * 2 + 1], ap[1] + (size_t)(kb + kk) * 1024);
+        for (int m = 0; m < NMAT; ++m) acc[b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 wr[D][WL];  // [ring stage][k-tile * NMAT + matrix]
+      auto issue_w1 = [&](int ks, u32x4 (&dst)[WL], int t) {  // past the end: re-read the last stage (never multiplied)
+        const int kk = t / NMAT, m = t % NMAT;
+        ring_load(dst[t], ap[m] + (size_t)(min(ks, KS - 1) * KT + kk) * 1024);
+      };
+      auto issue_x1 = [&](int ks, int i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)min(ks, KS - 1) * KT * EPT),
+                                         (lptr_t)(smem + (ks % NX) * XSTAGE + (wave + NWV * i) * 1024), 16, 0, 0);
+      };
+      // Issue order of every wave: prologue W0 X0 W1 X1 W2 .. W(D-2); step S issues X(S+2) then W(S+D-1), spread over its
+      // chunks.  When stage S is consumed, what was issued after X(S) (D > 3; after W(S) for D == 3) may still be in flight:
+      // D > 3: W(S+D-3) X(S+1) W(S+D-2) = 2 WL + XPWP;  D == 3: X(S+1) W(S+1) = WL + XPWP.
+#pragma unroll
+      for (int t = 0; t < WL; ++t) issue_w1(0, wr[0], t);
+#pragma unroll
+      for (int i = 0; i < XPWP; ++i) issue_x1(0, i);
+#pragma unroll
+      for (int t = 0; t < WL; ++t) issue_w1(1, wr[1], t);
+#pragma unroll
+      for (int i = 0; i < XPWP; ++i) issue_x1(1, i);
+#pragma unroll
+      for (int d = 2; d <= D - 2; ++d)
+#pragma unroll
+        for (int t = 0; t < WL; ++t) issue_w1(d, wr[d], t);
+      auto step = [&](int S, u32x4 (&wc)[WL], u32x4 (&wn)[WL]) {
+        ring2_wait<WL, NWAIT>(wc);      // this wave's W(S), X(S) landed
+        __builtin_amdgcn_s_barrier();   // everybody's X(S) landed; LDS buffer (S+2)%3 and ring slot (S-1)%D are free
+        const uint32_t sbase = lds0 + (S % NX) * XSTAGE;
+        uint32_t fa[KT];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) fa[kk] = sbase + frag_off[kk];
+        u32x4 fb[2][CW];
+        // the fragment reads are inline asm with counted lgkmcnt waits of their own: with compiler-scheduled reads every
+        // LDS-DMA between a read and its use turns the compiler's wait into lgkmcnt(0) — the prefetched chunk would be waited for
+        auto read_slot = [&](auto jc, u32x4 (&f)[CW]) {
+          constexpr int j = decltype(jc)::value, kk = j / NCH, c = j % NCH;
+          static_for<CW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (c * CW + i < NG) lds_read16<(c * CW + i) * 2048>(f[i], fa[kk]);
+          });
+        };
+        read_slot(std::integral_constant<int, 0>{}, fb[0]);
+        static_for<NSLOT>([&](auto jc) {
+          constexpr int j = decltype(jc)::value, kk = j / NCH, c = j % NCH;
+          constexpr int width = (NG - c * CW) < CW ? (NG - c * CW) : CW;
+          constexpr int cn = (j + 1) % NCH;
+          constexpr int width_next = j + 1 < NSLOT ? ((NG - cn * CW) < CW ? (NG - cn * CW) : CW) : 0;
+          if constexpr (j + 1 < NSLOT) read_slot(std::integral_constant<int, j + 1>{}, fb[(j + 1) & 1]);
+          static_for<(j + 1) * OPS / NSLOT - j * OPS / NSLOT>([&](auto oc) {
+            constexpr int o = j * OPS / NSLOT + decltype(oc)::value;
+            if constexpr (o < XPWP) issue_x1(S + 2, o);
+            else issue_w1(S + D - 1, wn, o - XPWP);
+          });
+          frag_wait<width, width_next>(fb[j & 1]);  // this chunk's fragments landed; the next chunk's stay in flight
+          __builtin_amdgcn_sched_barrier(0);          // the reads and loads above stay above the MFMAs below
+          static_for<width>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) mma16<T>(acc[c * CW + i][m], wc[kk * NMAT + m], fb[j & 1][i]);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      // unrolled by D: the register ring is indexed statically; past the end the issues are clamped re-reads
+      for (int ks = 0; ks < KS; ks += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          if (ks + d < KS) step(ks + d, wr[d], wr[(d + D - 1) % D]);
       }
-    };
-    auto issue_x = [&](int ks) {
-      char* base = smem + (ks % NX) * XSTAGE;
-      const int kc = min(ks, KS - 1);
+      // the clamped tail issues: the drain names every ring register, so none of them can be handed to another value while a
+      // load that nobody reads is still on its way into it
 #pragma unroll
-      for (int i = 0; i < XPW; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)kc * KT * EPT), (lptr_t)(base + (wave + NWV * i) * 1024), 16, 0, 0);
-    };
-    // token groups are multiplied in chunks of 4 (absent groups of a partly filled chunk hold clamped copies of the last
-    // row and are dropped by the epilogue): one wave-uniform branch per chunk instead of one per group, so the LDS
-    // fragment reads of a chunk are issued together and its 8 MFMAs run back to back (a branch per group serialised
-    // ds_read -> wait -> 2 MFMAs)
-    auto compute = [&](int ks, const u32x4 (&w)[WL]) {
-      const char* base = smem + (ks % NX) * XSTAGE;
-      const int r = n & 7;
+      for (int d = 0; d < D; ++d) ring2_wait<WL, 0>(wr[d]);
+      // epilogue straight from the accumulators: lane holds 4 consecutive rows of one token
+      epi_switch<NMAT>(s.epi, [&](auto epic) {
+        constexpr int EPI = decltype(epic)::value;
+        const T* bias = reinterpret_cast<const T*>(W + s.off_bias);
+        const bool aligned = (s.ld_out & 3) == 0;
 #pragma unroll
-      for (int kk = 0; kk < KT; ++kk) {
-        const int ch = (kk & 1) * 4 + q;
-        const char* lbase = base + (kk >> 1) * (2 * NTB * 1024);  // the 128-byte line this k-tile lives in
-#pragma unroll
-        for (int c = 0; c < NTB / 4; ++c) {
-          if (c * 4 < ntl) {
-            u32x4 bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const u32x4*>(lbase + ((c * 4 + i) * 2 + (n >> 3)) * 1024 + r * 128 + ((ch ^ r) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int b = c * 4 + i;
-              acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kk * 2 + 0]), __builtin_bit_cast(bf16x8, bf[i]), acc[b][0], 0, 0, 0);
-              acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kk * 2 + 1]), __builtin_bit_cast(bf16x8, bf[i]), acc[b][1], 0, 0, 0);
-            }
+        for (int b = 0; b < NG; ++b) {
+          const int tok = (tile0 + b) * 16 + n;
+          if (tok < cnt && rg_live) {
+            const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
+            epi_quad<T, EPI>(acc[b][0], acc[b][NMAT - 1], bias, rg * 16 + q * 4, R, aligned, reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out);
           }
         }
-      }
+      });
     };
-    auto wait_stage = [&](u32x4 (&w)[WL]) {  // this wave's W(S), X(S) landed; what may stay in flight: see below
-      constexpr int N = (D - 2) * WL + XPW;
-      if constexpr (WL == 4) ring_wait<N>(w[0], w[1], w[2], w[3]);
-      else ring_wait8<N>(w);
-    };
-    // Issue order of every wave: ... W(k) X(k) W(k+1) X(k+1) ...
-    //   D == 4: prologue W0 X0 W1 X1 W2, step S issues X(S+2) W(S+3); before stage S is consumed W(S+1) X(S+1) W(S+2) may
-    //           be outstanding: vmcnt(2*WL + XPW);
-    //   D == 3: prologue W0 X0 W1 X1,    step S issues W(S+2) X(S+2); outstanding W(S+1) X(S+1): vmcnt(WL + XPW).
-    // Unrolled by D so that the register ring is indexed statically.  Past the end the issues are clamped re-reads
-    // (count-preserving); the final wait below drains them.
-    issue_w(0, wr[0]); issue_x(0);
-    issue_w(1, wr[1]); issue_x(1);
-    if (D == 4) issue_w(2, wr[2]);
-#define RING_STEP(S, CUR, NXT)                                                                   \
-    if ((S) < KS) {                                                                              \
-      wait_stage(wr[CUR]);                       /* this wave's W(S), X(S) landed */               \
-      __builtin_amdgcn_s_barrier();              /* everybody's X(S) landed; LDS buffer (S+2)%3 is free */        \
-      if (D == 4) { issue_x((S) + 2); issue_w((S) + 3, wr[NXT]); }                                \
-      else { issue_w((S) + 2, wr[NXT]); issue_x((S) + 2); }                                      \
-      compute((S), wr[CUR]);                                                                     \
-    }
-    if (D == 4) {
-      for (int ks = 0; ks < KS; ks += 4) {
-        RING_STEP(ks, 0, 3)
-        RING_STEP(ks + 1, 1, 0)
-        RING_STEP(ks + 2, 2, 1)
-        RING_STEP(ks + 3, 3, 2)
-      }
-    } else {
-      for (int ks = 0; ks < KS; ks += 3) {
-        RING_STEP(ks, 0, 2)
-        RING_STEP(ks + 1, 1, 0)
-        RING_STEP(ks + 2, 2, 1)
-      }
-    }
-#undef RING_STEP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail issues
-    // epilogue straight from the accumulators: lane holds 4 consecutive rows of one token
-    {
-      const bool aligned = (s.ld_out & 3) == 0;
-#pragma unroll
-      for (int b = 0; b < NTB; ++b) {
-        const int tok = (tile0 + b) * 16 + n;
-        if (tok < cnt && rg_live) {
-          const int srow = s.out_map ? s.out_map[off + tok] : off + tok;
-          epi_quad<T, EPI_GATED_SILU>(acc[b][0], acc[b][1], nullptr, rg * 16 + q * 4, R, aligned, reinterpret_cast<T*>(s.out) + (size_t)srow * s.ld_out);
-        }
-      }
-    }
+    // the pass body is instantiated per number of token-group pairs present (block-uniform switch)
+    dispatch_np<2, NTB / 2>((ntl + 1) >> 1, pass);
     __syncthreads();  // the next pass re-uses the LDS ring from stage 0
+  }
+}
+
+// the ring2 tile forms by rows per expert (<= 128: 128 tokens per pass, <= 208: 192, else 256)
+template <typename T, int NMAT>
+static void launch_ring2(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
+  const dim3 g2((grid.x + 7) / 8, grid.y);
+  if constexpr (NMAT == 2) {
+    if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
+    else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);
+  } else {
+    if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
+    else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 16, 4>), g2, dim3(512), 0, st, s);
   }
 }
 
@@ -719,13 +773,6 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   // both stages switch at the same row count now; below it (512 tokens: 436 vs 450 gate/up but 324 vs 265 down) ring / lds stay
   static const int big_env = env_int("MOEINF_GEMM_BIG", 1);
   static const int big_rows = env_int("MOEINF_GEMM_BIG_ROWS", 256);
-  static const int big_rows_ring = env_int("MOEINF_GEMM_BIG_ROWS_RING", 256);
-  bool ring_stage = false;
-  if constexpr (sizeof(T) == 2 && NMAT == 2) {
-    static const int ring_min_k0 = env_int("MOEINF_RING_MIN_K", 4096);
-    ring_stage = env_int("MOEINF_GEMM_RING", 1) && (s.K % 64) == 0 && s.K >= ring_min_k0 && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring_min_k0));
-  }
-  if (use_gemm == 2 && big_env && sizeof(T) == 2 && max_rows > (ring_stage ? big_rows_ring : big_rows) && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return true;
   const int ept = sizeof(T) == 2 ? 32 : 16;
   const bool k_ok = (s.K % ept) == 0 && (s.K_sh % ept) == 0;
   // 17-64 rows per expert (e.g. NLLB's 128 experts at a 2048-token batch): too many for the decode kernel, too few to
@@ -735,30 +782,30 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   // NLLB's 128 experts at 4096 tokens the same switch costs +11 %)
   static const int hyb_rows_env = env_int("MOEINF_GEMM_HYB_ROWS", 0);
   const int hyb_rows = hyb_rows_env ? hyb_rows_env : ((int)grid.y <= 16 ? 128 : 64);
-  static const int ring_env = env_int("MOEINF_GEMM_RING", 1);
-  if constexpr (sizeof(T) == 2 && NMAT == 2) {
-    // bf16 gated stage, more than hyb_rows rows per expert, long reduction: the register-ring kernel.  With a short K
-    // (DeepSeek: 32 stages) filling and draining the ring costs more than it hides (297 vs 287 us at 512 tokens).
-    static const int ring_min_k = env_int("MOEINF_RING_MIN_K", 4096);
-    const bool ring_ok = (s.K % 64) == 0 && (s.K_sh % 64) == 0 && s.K >= ring_min_k && (s.K_sh == 0 || s.K_sh >= ring_min_k);
-    if ((use_gemm == 4 || (use_gemm == 2 && ring_env && max_rows > hyb_rows)) && ring_ok) {
-      static const int ring_wide = env_int("MOEINF_RING_WIDE", -1);
-      const bool wide = ring_wide >= 0 ? ring_wide != 0 : max_rows > 128;
-      const dim3 g2((grid.x + 7) / 8, grid.y);
-      // 129-200 rows per expert (a 512-token Mixtral prefill): 192 tokens per pass with FOUR k-tiles per stage and four waves
-      // per workgroup (one per SIMD, 344-378 registers) — twice the weight bytes in flight per wave.  Measured SLOWER
-      // (profiles/r03_ffn_sweep_prefill_ring_k4.txt: 585 / 589 us vs 470 at 512 tokens): with one wave per SIMD nothing
-      // covers a wave's wait -> barrier -> issue -> multiply sequence.  Opt-in only (1: D = 4, 3: D = 3).
-      static const int k4_env = env_int("MOEINF_RING_K4", 0);
-      const bool k4 = k4_env && wide && max_rows <= 200 && (s.K % 128) == 0 && (s.K_sh % 128) == 0;
-      const dim3 g4((grid.x + 3) / 4, grid.y);
-      if (k4 && k4_env == 3) hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 3, 4, 4>), g4, dim3(256), 0, st, s);
-      else if (k4) hipLaunchKernelGGL((ffn_gemm_ring_kernel<12, 4, 4, 4>), g4, dim3(256), 0, st, s);
-      else if (wide) hipLaunchKernelGGL((ffn_gemm_ring_kernel<16, 3, 2, 8>), g2, dim3(512), 0, st, s);
-      else hipLaunchKernelGGL((ffn_gemm_ring_kernel<8, 4, 2, 8>), g2, dim3(512), 0, st, s);
+  if constexpr (sizeof(T) == 2) {
+    // long reductions (K >= 4096: Mixtral's two stages, NLLB's second), 17 (plain) / hyb_rows+1 (gated) .. 340 rows per expert:
+    // the software-pipelined register ring.  Measured against what ran there before (profiles/r04_ffn_sweep_ring2_*.txt,
+    // Mixtral-8x7B, us per layer, gate-up / down):
+    //   tokens   96       224       336       384       512       640       768       896
+    //   before   320/162  337/196   365/233   404/252   441/261   494/274   492/342   510/347   (hybrid | ring + lds | big)
+    //   ring2    (hyb)/147 (hyb)/157 (hyb)/173 347/178   374/202   401/233   438/256   487/287
+    // gated stage below 129 rows: the hybrid kernel is 1-2 % ahead and stays.  Above ~256 rows per expert (the row estimate of
+    // the sync-free path is 1.5 x the mean + 1 = 337 at 896 tokens, 385 at 1 024) a second pass over the weights begins and the
+    // big-tile kernel takes over.  An expert with more rows than a pass holds takes another pass; correctness never depends on
+    // the estimate.
+    static const int ring2_env = env_int("MOEINF_GEMM_RING2", 3);  // bit 0: gated stage, bit 1: plain stage
+    static const int ring2_min_k = env_int("MOEINF_RING_MIN_K", 4096);
+    static const int ring2_max_rows = env_int("MOEINF_RING2_MAX_ROWS", 340);
+    static const int ring2_min_gated = env_int("MOEINF_RING2_MIN_ROWS_GATED", 0);  // 0: where the hybrid kernel stops
+    static const int ring2_min_plain = env_int("MOEINF_RING2_MIN_ROWS_PLAIN", 16);  // (48 tokens, 19 rows: 146 vs 158 us)
+    const int ring2_min = NMAT == 2 ? (ring2_min_gated ? ring2_min_gated : hyb_rows) : ring2_min_plain;
+    const bool ring2_ok = (s.K % 64) == 0 && s.K >= ring2_min_k && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring2_min_k));
+    if (use_gemm == 2 && (ring2_env & (NMAT == 2 ? 1 : 2)) && ring2_ok && max_rows > ring2_min && max_rows <= ring2_max_rows) {
+      launch_ring2<T, NMAT>(s, grid, max_rows, st);
       return true;
     }
   }
+  if (use_gemm == 2 && big_env && sizeof(T) == 2 && max_rows > big_rows && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return true;
   if ((use_gemm == 3 || (use_gemm == 2 && max_rows <= hyb_rows)) && k_ok) {  // weights -> registers, activations -> LDS
     static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
     static const int hxl_env = env_int("MOEINF_GEMM_XL", 1);
@@ -805,6 +852,19 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   } else {
     return false;
   }
+  return true;
+}
+// fp16 experts: of the mid-sized GEMM kernels only ring2 is built for the f16 matrix instruction (the hybrid / LDS kernels are
+// bf16 and fp32); same conditions as above, from 65 rows per expert on (gated) / 17 (plain).  false: not handled
+bool launch_ffn_gemm_ring2_f16(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st) {
+  static const int ring2_env = env_int("MOEINF_GEMM_RING2", 3);
+  static const int ring2_min_k = env_int("MOEINF_RING_MIN_K", 4096);
+  static const int ring2_max_rows = env_int("MOEINF_RING2_MAX_ROWS", 340);
+  const bool ok = (s.K % 64) == 0 && s.K >= ring2_min_k && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring2_min_k));
+  if (!ok || !(ring2_env & (nmat == 2 ? 1 : 2)) || max_rows > ring2_max_rows || max_rows <= (nmat == 2 ? 64 : 16)) return false;
+  if ((nmat == 2) != (s.epi == EPI_GATED_SILU)) return false;
+  if (nmat == 2) launch_ring2<half_t, 2>(s, grid, max_rows, st);
+  else launch_ring2<half_t, 1>(s, grid, max_rows, st);
   return true;
 }
 template bool launch_ffn_gemm<uint16_t, 1>(const FfnStage&, dim3, int, hipStream_t);

@@ -98,14 +98,17 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnStage s) {
 template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st);
 bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st);  // ffn_gemm_big.hip (bf16, fp16)
+bool launch_ffn_gemm_ring2_f16(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st);  // ffn_gemm.hip
 
 template <typename T, int NMAT>
 static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, int max_rows, hipStream_t st) {
 #define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
   if (many_tokens) {  // grouped GEMM kernels (ffn_gemm.hip); MOEINF_FFN_GEMM=0: the decode kernel looping 4 token tiles
     if constexpr (sizeof(T) == 2 && !std::is_same<T, uint16_t>::value) {
-      // fp16 experts: of the GEMM kernels only the 256 x 256 one is built for the f16 matrix instruction; it takes over from
-      // 65 rows per expert (below that the decode kernel looping token tiles re-streams the weights at most 4 times)
+      // fp16 experts: of the GEMM kernels the register ring (long reductions, up to 340 rows per expert) and the 256 x 256 one
+      // are built for the f16 matrix instruction; the latter takes over from 65 rows per expert elsewhere (below that the
+      // decode kernel looping token tiles re-streams the weights at most 4 times)
+      if (launch_ffn_gemm_ring2_f16(s, NMAT, grid, max_rows, st)) return;
       if (max_rows > 64 && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return;
     } else {
       if (launch_ffn_gemm<T, NMAT>(s, grid, max_rows, st)) return;

@@ -48,7 +48,8 @@ def _check_index(eng, ref):
     return r
 
 
-@pytest.mark.parametrize("t", [1, 512, 2048], ids=["decode_b1", "prefill_t512", "prefill_t2048_compute_bound_gemm"])
+@pytest.mark.parametrize("t", [1, 352, 512, 640, 2048],
+                         ids=["decode_b1", "prefill_t352_ring2_partly_filled_pass", "prefill_t512", "prefill_t640_ring2_256_token_pass", "prefill_t2048_compute_bound_gemm"])
 def test_mixtral_8x7b_layer(t):
     eng, cfg = _engine("mixtral_8x7b", t)
     experts, _ = fill_layer_on_gpu(eng, "mixtral", 0, 1234)
@@ -148,7 +149,7 @@ def test_switch_base_8_layer_fp32(b, s):
 
 def test_mixtral_8x7b_layer_fp16_decode_and_prefill():
     """fp16 experts (dtype id 2) at Mixtral-8x7B's full shape: batch 1 (the self-routing kernels on the f16 matrix
-    instruction) and a 512-token prefill (ffn_gemm_big for fp16).  north_star's "within 1e-3 fp16" applies literally here:
+    instruction) and a 512-token prefill (ffn_gemm_ring2 on the f16 matrix instruction).  north_star's "within 1e-3 fp16" applies literally here:
     fp16 ulp 2^-10 in every bar, mean relative error <= 1e-3, and the fp32-exact arm."""
     from moe_infinity_amd import config as Cf
 
@@ -170,3 +171,52 @@ def test_mixtral_8x7b_layer_fp16_decode_and_prefill():
         print(f"mixtral fp16 t={t}: mean rel err {rep['mean_rel']:.2e}, max rel err {rep['max_rel_err']:.2e}; |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f}")
         assert rep["mean_rel"] <= 1e-3
         eng.close()
+
+
+def test_many_experts_long_reduction_prefill_takes_the_128_token_ring():
+    """32 experts x ~64 rows with H = F = 4096: more than 16 active experts keep the hybrid kernel to <= 64 rows, so both FFN
+    stages run the software-pipelined register ring in its 128-token form (ffn_gemm_ring2<*, 8, 4>; the Mixtral shapes above
+    cover the 192- and 256-token forms)."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    t, e, k, h, f = 1024, 32, 2, 4096, 4096
+    cfg = Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_MIXTRAL, hidden=h, inter=f, top_k=k,
+                          router_kind=Cf.ROUTER_MIXTRAL, dtype=Cf.DTYPE_BF16, max_tokens=t)
+    eng = MoEEngine(cfg)
+    experts, _ = fill_layer_on_gpu(eng, "mixtral", 0, 4242)
+    gate = _gate(e, h, torch.bfloat16, 77, 0.02)
+    x = acts(t, h, torch.bfloat16, 2025)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k)
+    r = _check_index(eng, ref)
+    assert np.array_equal(r["topk_idx"], ref.topk_idx.numpy().astype(np.int32))
+    assert 64 < int(r["counts"].max()) <= 128 and int((r["counts"] > 0).sum()) > 16, r["counts"]
+    rows = oracle_expert_rows(ref, e)
+    got_rows = eng.expert_outputs(rows.shape[0])
+    assert_model_close(got_rows, rows, torch.bfloat16, "expert FFN outputs")
+    assert_block_close(out, ref, torch.bfloat16, "32 experts, 1024 tokens")
+    assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.bfloat16, "32 experts, 1024 tokens", rows=got_rows)
+    eng.close()
+
+
+def test_nllb_moe_54b_layer_prefill_t2048():
+    """A 2048-token NLLB prefill: ~32 rows per expert over 128 experts.  The second stage (K = 8192, bias epilogue) runs the
+    software-pipelined register ring in its plain form with EPI_BIAS; the first (K = 2048) the hybrid kernel."""
+    t = 2048
+    eng, cfg = _engine("nllb_moe_54b", t)
+    experts, _ = fill_layer_on_gpu(eng, "nllb", 0, 3234)
+    gate = _gate(cfg.num_experts, cfg.hidden, torch.bfloat16, 4323, 0.5)
+    x = acts(t, cfg.hidden, torch.bfloat16, 2027)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_nllb(x[None], gate, experts)
+    r = _check_index(eng, ref)
+    assert np.array_equal(_mask_from_idx(r["topk_idx"], cfg.num_experts), ref.router_mask.numpy()), "routing sets must be bit-exact"
+    rows = oracle_expert_rows(ref, cfg.num_experts)
+    got_rows = eng.expert_outputs(rows.shape[0])
+    assert_model_close(got_rows, rows, torch.bfloat16, "expert FFN outputs", ulps=2.0)  # (two rounding points: see the batch-32 test)
+    assert_block_close(out, ref, torch.bfloat16, "NLLB-MoE-54B layer, 2048 tokens")
+    assert_as_accurate_as_the_oracle(out, ref, "nllb", x[None], experts, torch.bfloat16, "NLLB-MoE-54B layer, 2048 tokens", rows=got_rows)
+    eng.close()
