@@ -580,32 +580,38 @@ __device__ __forceinline__ void ring2_wait(u32x4 (&w)[WL]) {
   else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N) : "memory");
 }
 
-template <typename T, int NMAT, int NTB, int D>
+template <typename T, int NMAT, int NTB, int D, bool TAIL = false>
 __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   static_assert(sizeof(T) == 2, "bf16 / fp16");
   static_assert(D >= 3 && D <= 6, "register ring of 3..6 stages");
   static_assert(NTB % 4 == 0, "whole activation DMA pieces per wave");
   constexpr int NWV = 8, KT = 2, EPT = 32, EPV = 8;
   constexpr int WL = KT * NMAT;             // weight tiles (1 KiB) per wave and stage
-  constexpr int XPW = 2 * NTB / NWV;        // activation DMA pieces (8 rows x 128 B) per wave and stage
   constexpr int XSTAGE = KT * NTB * 1024;   // activation bytes per stage
   constexpr int NX = 3;                     // LDS ring
   constexpr int CW = 8 / NMAT;              // token groups per chunk: 8 MFMAs between two fragment batches
   __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
 
-  const int u = blockIdx.y;
+  // TAIL: 1-D grid over units (expert slot, row block); units from ring2_split on are shared by two workgroups (half 0 / 1)
+  int u = blockIdx.y, bx = blockIdx.x, half = -1;
+  if constexpr (TAIL) {
+    const int lin = blockIdx.x;
+    int unit = lin;
+    if (lin >= s.ring2_split) { const int h = lin - s.ring2_split; unit = s.ring2_split + (h >> 1); half = h & 1; }
+    u = unit / s.ring2_nblk; bx = unit - u * s.ring2_nblk;
+  }
   if (u >= (s.n_active_host >= 0 ? s.n_active_host : *s.n_active)) return;
   const int e = s.active[u];
   const bool sh = (e == s.E);
   const int K = sh ? s.K_sh : s.K;
   const int R = sh ? s.R_sh : s.R;
   const int nrg_total = (R + 15) / 16;
-  if ((int)blockIdx.x * NWV >= nrg_total) return;
+  if (bx * NWV >= nrg_total) return;
   const int cnt = s.counts[e];
   const int off = s.offsets[e];
   const char* W = reinterpret_cast<const char*>(s.wptr[e]);
   if (W == nullptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
+    if (threadIdx.x == 0 && bx == 0) atomicExch(s.miss_flag, 1);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -615,8 +621,10 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   const int KS = KB / KT;
   const size_t rg_stride = (size_t)KB * 1024;
   // this wave's weight-tile stream(s) (a row group past the end re-reads the last one; its results are dropped)
-  const int rg = min((int)blockIdx.x * NWV + wave, nrg_total - 1);
-  const bool rg_live = (int)blockIdx.x * NWV + wave < nrg_total;
+  // (a half workgroup: waves 0-3 own row groups half*4 .. half*4+3 of the block, waves 4-7 only keep the barriers company)
+  const int rg_want = bx * NWV + (half > 0 ? 4 : 0) + wave;
+  const int rg = min(rg_want, nrg_total - 1);
+  const bool rg_live = rg_want < nrg_total;
   const char* ap[NMAT];
   ap[0] = W + (sh ? s.off_a_sh : s.off_a) + (size_t)rg * rg_stride + lane * 16;
   if (NMAT == 2) ap[NMAT - 1] = W + (sh ? s.off_b_sh : s.off_b) + (size_t)rg * rg_stride + lane * 16;
@@ -631,20 +639,28 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
 
   for (int tile0 = 0; tile0 * 16 < cnt; tile0 += NTB) {
     const int ntl = min(NTB, (cnt - tile0 * 16 + 15) / 16);  // token groups present in this pass (block-uniform)
-    const T* xrp[XPW];
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-      const int pg = wave + NWV * i;  // 8-row piece of the pass
-      const int trow = tile0 * 16 + pg * 8 + (lane >> 3);
-      const int srow = off + min(trow, cnt - 1);
-      const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
-      xrp[i] = reinterpret_cast<const T*>(s.in) + xrow * s.ld_in + (((lane & 7) ^ (lane >> 3)) * EPV);
-    }
-    auto pass = [&](auto npc) {
+    auto pass = [&](auto npc, auto nwc) {
       constexpr int NG = decltype(npc)::value * 2;  // token groups multiplied in this pass
+      constexpr int NWVE = decltype(nwc)::value;     // waves that work (4 in a half workgroup)
+      if constexpr (NWVE < NWV) {
+        if (wave >= NWVE) {  // same barriers as the working waves, nothing else
+          for (int ks = 0; ks < KS; ++ks) __builtin_amdgcn_s_barrier();
+          return;
+        }
+      }
       constexpr int NCH = (NG + CW - 1) / CW;       // chunks per k-tile
       constexpr int NSLOT = KT * NCH;
-      constexpr int XPWP = (2 * NG + NWV - 1) / NWV;  // activation DMA pieces per wave and stage that hold rows of this pass
+      constexpr int XPWP = (2 * NG + NWVE - 1) / NWVE;  // activation DMA pieces per wave and stage that hold rows of this pass
+      // element offset of this lane's 16 bytes in each of its pieces (8 rows x 128 B; piece id = wave + NWVE * i)
+      uint32_t xoff[XPWP];
+#pragma unroll
+      for (int i = 0; i < XPWP; ++i) {
+        const int pg = wave + NWVE * i;
+        const int trow = tile0 * 16 + pg * 8 + (lane >> 3);
+        const int srow = off + min(trow, cnt - 1);
+        const int64_t xrow = s.row_map ? (int64_t)s.row_map[srow] : (int64_t)srow;
+        xoff[i] = (uint32_t)(xrow * s.ld_in + (((lane & 7) ^ (lane >> 3)) * EPV));
+      }
       constexpr int OPS = XPWP + WL;                  // VMEM instructions per wave and stage
       constexpr int NWAIT = (D == 3 ? WL : 2 * WL) + XPWP;  // what may stay in flight when stage S is consumed (see below)
       f32x4 acc[NG][NMAT];
@@ -658,8 +674,8 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
         ring_load(dst[t], ap[m] + (size_t)(min(ks, KS - 1) * KT + kk) * 1024);
       };
       auto issue_x1 = [&](int ks, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)min(ks, KS - 1) * KT * EPT),
-                                         (lptr_t)(smem + (ks % NX) * XSTAGE + (wave + NWV * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const T*>(s.in) + ((size_t)xoff[i] + (size_t)min(ks, KS - 1) * KT * EPT)),
+                                         (lptr_t)(smem + (ks % NX) * XSTAGE + (wave + NWVE * i) * 1024), 16, 0, 0);
       };
       // Issue order of every wave: prologue W0 X0 W1 X1 W2 .. W(D-2); step S issues X(S+2) then W(S+D-1), spread over its
       // chunks.  When stage S is consumed, what was issued after X(S) (D > 3; after W(S) for D == 3) may still be in flight:
@@ -741,16 +757,31 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
       });
     };
     // the pass body is instantiated per number of token-group pairs present (block-uniform switch)
-    dispatch_np<2, NTB / 2>((ntl + 1) >> 1, pass);
+    if (TAIL && half >= 0) dispatch_np<2, NTB / 2>((ntl + 1) >> 1, [&](auto npc) { pass(npc, std::integral_constant<int, 4>{}); });
+    else dispatch_np<2, NTB / 2>((ntl + 1) >> 1, [&](auto npc) { pass(npc, std::integral_constant<int, NWV>{}); });
     __syncthreads();  // the next pass re-uses the LDS ring from stage 0
   }
 }
 
 // the ring2 tile forms by rows per expert (<= 128: 128 tokens per pass, <= 208: 192, else 256)
 template <typename T, int NMAT>
-static void launch_ring2(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
+static void launch_ring2(const FfnStage& s0, dim3 grid, int max_rows, hipStream_t st) {
   const dim3 g2((grid.x + 7) / 8, grid.y);
+  // A last round that fills at most half of the CUs (Mixtral's gate-up: 112 row blocks x 8 experts = 896 workgroups = 3.5 rounds
+  // on 256 CUs) is dealt out as twice as many half workgroups (four working waves, 64 rows): all CUs stay busy to the end.
+  static const int tail_env = env_int("MOEINF_RING2_TAIL", 1);
+  static const int ncu = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+  const int units = (int)(g2.x * g2.y), rem = units % ncu;
+  FfnStage s = s0;
   if constexpr (NMAT == 2) {
+    if (tail_env && units > ncu && rem > 0 && rem <= ncu / 2) {
+      s.ring2_nblk = (int)g2.x; s.ring2_split = units - rem;
+      const dim3 g1(units + rem);
+      if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
+      else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
+      else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3, true>), g1, dim3(512), 0, st, s);
+      return;
+    }
     if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
     else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
     else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);

@@ -104,6 +104,10 @@ struct FfnStage {
   // batch-1 decode records (self-routing path): written by the meta block of ffn1_selfroute, read by ffn2_decode1
   uint64_t* dec_w;         // [8] blob pointer of the u-th active expert (ascending expert id)
   float* dec_cw;           // [8] the token's combine weight of that expert
+  // ffn_gemm_ring2 with a split tail (set by its launcher): 1-D grid over units = (expert slot, 128-row block); units from
+  // ring2_split on are dealt to TWO workgroups of four working waves each (64 rows), so a half-empty last round fills the chip
+  int ring2_nblk;          // row blocks per expert (0: the plain 2-D grid)
+  int ring2_split;
 };
 // max_rows_per_expert: upper bound of rows any one expert receives (selects the multi-token-tile variant)
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
