@@ -264,7 +264,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
     log(f"{label}: cache warm ({warm['slots_used']} experts resident) in {time.time() - t0:.1f}s, h2d {warm['h2d_bytes'] / 2**30:.1f} GiB, link-busy {warm['h2d_busy_ms']:.0f} ms")
     # prefill of the prompt (B sequences x --prompt tokens) through every layer: exercises the large-T
     # path; timed separately, NOT part of `value`
-    prefill_ms, prefill_passes = None, None
+    prefill_ms, prefill_passes, prefill_kernels = None, None, None
     if prompt > 0 and not use_ep:
         xp = acts(B * prompt, H, dt, 777).to(dev)
         outp = torch.empty_like(xp)
@@ -280,6 +280,35 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             passes.append((time.perf_counter() - tp) * 1e3)
         prefill_ms = statistics.median(passes)
         prefill_passes = [round(v, 2) for v in passes]
+        # one more pass with per-kernel HIP events on the launch stream: the two grouped-GEMM stages against the HBM roof
+        # (algorithmic bytes of the stage / event interval; at ~128 rows per expert the stage is still a weight-streaming kernel)
+        try:
+            eng.set_profiling(True)
+            for l in range(L):
+                eng.forward(l, xp, gates[l], batch_rows=batch_rows, out=outp)
+            torch.cuda.synchronize(dev)
+            pp = eng.profile()
+            eng.set_profiling(False)
+
+            def pstat(ms, launches, nbytes):
+                if launches == 0 or ms <= 0:
+                    return None
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                return {"avg_launch_us": round(ms * 1e3 / launches, 1), "algorithmic_bytes_per_launch": int(nbytes // launches),
+                        "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+            prefill_kernels = {"ffn_stage1": pstat(pp["ffn1_ms"], pp["ffn1_launches"], pp["ffn1_bytes"]),
+                               "ffn_stage2": pstat(pp["ffn2_ms"], pp["ffn2_launches"], pp["ffn2_bytes"]),
+                               "route_us_per_layer": round(pp["route_ms"] * 1e3 / max(1, pp["forwards"]), 1),
+                               "combine_us_per_layer": round(pp["combine_ms"] * 1e3 / max(1, pp["forwards"]), 1),
+                               "how": "HIP events around each launch on the launch stream, one extra pass over all layers"}
+        except Exception as ex:  # an extra leg: the line survives without it
+            log(f"prefill kernel leg failed: {ex!r}")
+            try:
+                eng.set_profiling(False)
+                eng.profile()
+            except Exception:
+                pass
         del xp, outp
     run_steps(0, warmup)
     eng.sync_copies()
@@ -583,7 +612,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
 
     res = {"label": label, "family": family, "cfg": cfg, "L": L, "E": E, "K": K, "H": H, "B": B, "dt": dt,
            "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
-           "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
+           "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prefill_kernels": prefill_kernels, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
            "warm": warm, "st": st, "ep_phases": ep_phases,
            "ep_transport": None if ep is None else {
                "chosen": ep.transport,
@@ -694,7 +723,8 @@ def main():
             "windows_ms": r["windows_ms"], "value_is": f"median of {len(r['windows_ms'])} windows of {args.steps} steps (first = the contract's window)",
             "prefill": None if r["prefill_ms"] is None else {"tokens": B * r["prompt"], "ms_all_layers": round(r["prefill_ms"], 2),
                                                              "passes_ms": r["prefill_passes"], "value_is": "median of 5 passes",
-                                                             "tokens_per_s": round(B * r["prompt"] / r["prefill_ms"] * 1e3, 1)},
+                                                             "tokens_per_s": round(B * r["prompt"] / r["prefill_ms"] * 1e3, 1),
+                                                             "kernels": r.get("prefill_kernels")},
             "roofline": r["roof"],
             "cpu_baseline": r["cpu"],
             "kernels": r["kernels"],
