@@ -220,3 +220,33 @@ def test_nllb_moe_54b_layer_prefill_t2048():
     assert_block_close(out, ref, torch.bfloat16, "NLLB-MoE-54B layer, 2048 tokens")
     assert_as_accurate_as_the_oracle(out, ref, "nllb", x[None], experts, torch.bfloat16, "NLLB-MoE-54B layer, 2048 tokens", rows=got_rows)
     eng.close()
+
+
+def test_mixtral_8x7b_layer_skewed_routing_takes_several_passes():
+    """Routing far from uniform: (nearly) every one of 512 tokens picks expert 0, so that expert has ~2.7 x the rows the
+    sync-free path's estimate (1.5 x the mean + 1 = 193) sized the GEMM tile for.  The estimate only picks the kernel FORM: the
+    register-ring kernel walks such an expert in several 192-token passes over its weights (accumulators, LDS ring and register
+    ring restart per pass; the split-tail half workgroups take the same passes).  First forward = decision path (exact row
+    counts: the big-tile kernel), second = sync-free path (the passes); both must agree with the oracle."""
+    t = 512
+    eng, cfg = _engine("mixtral_8x7b", t)
+    experts, _ = fill_layer_on_gpu(eng, "mixtral", 0, 1234)
+    gate = _gate(cfg.num_experts, cfg.hidden, torch.bfloat16, 4321, 0.02)
+    x = acts(t, cfg.hidden, torch.bfloat16, 2031)
+    x[:, 0] = 4.0  # a coordinate only expert 0's gate row looks at
+    gate[:, 0] = 0.0
+    gate[0, 0] = 1.0
+    ref = R.block_mixtral(x[None], gate, experts, top_k=cfg.top_k)
+    counts = ref.router_mask.sum(0).tolist()
+    assert counts[0] >= 480 and max(counts[1:]) <= 192, counts
+    rows = oracle_expert_rows(ref, cfg.num_experts)
+    for it in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        r = _check_index(eng, ref)
+        assert np.array_equal(r["topk_idx"], ref.topk_idx.numpy().astype(np.int32)), "routing indices must be bit-exact"
+        got_rows = eng.expert_outputs(rows.shape[0])
+        what = f"Mixtral-8x7B layer, skewed routing, {'decision' if it == 0 else 'sync-free'} path"
+        assert_model_close(got_rows, rows, torch.bfloat16, f"expert FFN outputs ({what})")
+        assert_block_close(out, ref, torch.bfloat16, what)
+    assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.bfloat16, "Mixtral-8x7B layer, skewed routing", rows=got_rows)
+    eng.close()
