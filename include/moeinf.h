@@ -130,6 +130,15 @@ typedef struct moeinf_stats {
 const char* moeinf_last_error(void);
 int moeinf_abi_version(void);
 
+/* ---- introspection for tests (no reference counterpart, no GPU needed): which form of the register-ring GEMM
+ * (csrc/ffn_gemm.hip: ffn_gemm_ring2) the launcher picks for an FFN stage.  dtype: MOEINF_DTYPE_*; nmat: 2 = gated stage,
+ * 1 = plain; K / K_sh: reduction length of the routed / shared experts (0: no shared expert); R: output rows; active: experts
+ * with rows (the grid's upper bound); max_rows: rows of the busiest expert as the engine passes it (1.5 x the mean + 1 on the
+ * sync-free path); num_cus: compute units.  out[0] = token groups of 16 per pass (0: another kernel runs), out[1] = 1 when the
+ * last round of workgroups is split into half workgroups, out[2] = row blocks per expert, out[3] = first split unit,
+ * out[4] = workgroups launched.  Environment knobs are honoured as in the launcher. */
+int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5);
+
 /* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------
  * (core/prefetch/archer_prefetch_handle.cpp:18-64,73-81) */
 int moeinf_create(const moeinf_config* cfg, moeinf_engine** out);

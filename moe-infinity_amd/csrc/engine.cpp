@@ -362,6 +362,14 @@ static hipEvent_t get_event(moeinf_engine* g) {
 // ---- lifecycle -----------------------------------------------------------------------------
 extern "C" const char* moeinf_last_error(void) { return g_err.c_str(); }
 extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
+extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5) {
+  if (!out5 || (nmat != 1 && nmat != 2) || K <= 0 || R <= 0 || active <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_ffn_ring2_form: bad arguments");
+  const bool two_bytes = dtype == MOEINF_DTYPE_BF16 || dtype == MOEINF_DTYPE_F16;
+  const moeinf::Ring2Form f = moeinf::ring2_form(two_bytes ? 2 : 4, dtype == MOEINF_DTYPE_F16, nmat, K, K_sh, (R + 15) / 16, active, max_rows, num_cus,
+                                                 moeinf::Ring2Knobs::from_env());
+  out5[0] = f.ntb; out5[1] = f.tail; out5[2] = f.nblk; out5[3] = f.split; out5[4] = f.blocks;
+  return MOEINF_OK;
+}
 
 static int validate(const moeinf_config* c) {
   if (!c) return fail(MOEINF_ERR_INVALID, "cfg is NULL");

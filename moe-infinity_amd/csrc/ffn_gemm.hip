@@ -763,31 +763,32 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   }
 }
 
-// the ring2 tile forms by rows per expert (<= 128: 128 tokens per pass, <= 208: 192, else 256)
-template <typename T, int NMAT>
-static void launch_ring2(const FfnStage& s0, dim3 grid, int max_rows, hipStream_t st) {
-  const dim3 g2((grid.x + 7) / 8, grid.y);
-  // A last round that fills at most half of the CUs (Mixtral's gate-up: 112 row blocks x 8 experts = 896 workgroups = 3.5 rounds
-  // on 256 CUs) is dealt out as twice as many half workgroups (four working waves, 64 rows): all CUs stay busy to the end.
-  static const int tail_env = env_int("MOEINF_RING2_TAIL", 1);
+// launch the form ring2_form (kernels.h) chose: 128 / 192 / 256 tokens per pass; the gated stage with a split tail when the last
+// round of workgroups would fill at most half of the CUs (Mixtral's gate-up: 112 row blocks x 8 experts = 896 workgroups = 3.5
+// rounds on 256 CUs -> the last 128 units go out as 256 half workgroups of four working waves, 64 rows each)
+static int ring2_num_cus() {
   static const int ncu = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
-  const int units = (int)(g2.x * g2.y), rem = units % ncu;
+  return ncu;
+}
+template <typename T, int NMAT>
+static void launch_ring2(const FfnStage& s0, dim3 grid, const Ring2Form& f, hipStream_t st) {
+  const dim3 g2((unsigned)f.nblk, grid.y);
   FfnStage s = s0;
   if constexpr (NMAT == 2) {
-    if (tail_env && units > ncu && rem > 0 && rem <= ncu / 2) {
-      s.ring2_nblk = (int)g2.x; s.ring2_split = units - rem;
-      const dim3 g1(units + rem);
-      if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
-      else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
+    if (f.tail) {
+      s.ring2_nblk = f.nblk; s.ring2_split = f.split;
+      const dim3 g1((unsigned)f.blocks);
+      if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
+      else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
       else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3, true>), g1, dim3(512), 0, st, s);
       return;
     }
-    if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
-    else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
+    if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
     else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);
   } else {
-    if (max_rows <= 128) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
-    else if (max_rows <= 208) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
+    if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
     else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 16, 4>), g2, dim3(512), 0, st, s);
   }
 }
@@ -811,8 +812,8 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   // hybrid kernel (weights -> registers) up to 64 rows per expert; up to 128 when few experts are active (<= 16: big
   // matrices, few workgroups — Mixtral at 192 / 256 / 320 tokens: down projection 213 -> 174, 227 -> 208, 232 -> 226 us; with
   // NLLB's 128 experts at 4096 tokens the same switch costs +11 %)
-  static const int hyb_rows_env = env_int("MOEINF_GEMM_HYB_ROWS", 0);
-  const int hyb_rows = hyb_rows_env ? hyb_rows_env : ((int)grid.y <= 16 ? 128 : 64);
+  static const Ring2Knobs knobs0 = Ring2Knobs::from_env();
+  const int hyb_rows = hyb_rows_for((int)grid.y, knobs0);
   if constexpr (sizeof(T) == 2) {
     // long reductions (K >= 4096: Mixtral's two stages, NLLB's second), 17 (plain) / hyb_rows+1 (gated) .. 340 rows per expert:
     // the software-pipelined register ring.  Measured against what ran there before (profiles/r04_ffn_sweep_ring2_*.txt,
@@ -824,15 +825,10 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
     // the sync-free path is 1.5 x the mean + 1 = 337 at 896 tokens, 385 at 1 024) a second pass over the weights begins and the
     // big-tile kernel takes over.  An expert with more rows than a pass holds takes another pass; correctness never depends on
     // the estimate.
-    static const int ring2_env = env_int("MOEINF_GEMM_RING2", 3);  // bit 0: gated stage, bit 1: plain stage
-    static const int ring2_min_k = env_int("MOEINF_RING_MIN_K", 4096);
-    static const int ring2_max_rows = env_int("MOEINF_RING2_MAX_ROWS", 340);
-    static const int ring2_min_gated = env_int("MOEINF_RING2_MIN_ROWS_GATED", 0);  // 0: where the hybrid kernel stops
-    static const int ring2_min_plain = env_int("MOEINF_RING2_MIN_ROWS_PLAIN", 16);  // (48 tokens, 19 rows: 146 vs 158 us)
-    const int ring2_min = NMAT == 2 ? (ring2_min_gated ? ring2_min_gated : hyb_rows) : ring2_min_plain;
-    const bool ring2_ok = (s.K % 64) == 0 && s.K >= ring2_min_k && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring2_min_k));
-    if (use_gemm == 2 && (ring2_env & (NMAT == 2 ? 1 : 2)) && ring2_ok && max_rows > ring2_min && max_rows <= ring2_max_rows) {
-      launch_ring2<T, NMAT>(s, grid, max_rows, st);
+    static const Ring2Knobs ring2_knobs = Ring2Knobs::from_env();
+    const Ring2Form f2 = ring2_form((int)sizeof(T), false, NMAT, s.K, s.K_sh, (int)grid.x, (int)grid.y, max_rows, ring2_num_cus(), ring2_knobs);
+    if (use_gemm == 2 && f2.ntb) {
+      launch_ring2<T, NMAT>(s, grid, f2, st);
       return true;
     }
   }
@@ -888,14 +884,12 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
 // fp16 experts: of the mid-sized GEMM kernels only ring2 is built for the f16 matrix instruction (the hybrid / LDS kernels are
 // bf16 and fp32); same conditions as above, from 65 rows per expert on (gated) / 17 (plain).  false: not handled
 bool launch_ffn_gemm_ring2_f16(const FfnStage& s, int nmat, dim3 grid, int max_rows, hipStream_t st) {
-  static const int ring2_env = env_int("MOEINF_GEMM_RING2", 3);
-  static const int ring2_min_k = env_int("MOEINF_RING_MIN_K", 4096);
-  static const int ring2_max_rows = env_int("MOEINF_RING2_MAX_ROWS", 340);
-  const bool ok = (s.K % 64) == 0 && s.K >= ring2_min_k && (s.K_sh == 0 || ((s.K_sh % 64) == 0 && s.K_sh >= ring2_min_k));
-  if (!ok || !(ring2_env & (nmat == 2 ? 1 : 2)) || max_rows > ring2_max_rows || max_rows <= (nmat == 2 ? 64 : 16)) return false;
+  static const Ring2Knobs knobs = Ring2Knobs::from_env();
   if ((nmat == 2) != (s.epi == EPI_GATED_SILU)) return false;
-  if (nmat == 2) launch_ring2<half_t, 2>(s, grid, max_rows, st);
-  else launch_ring2<half_t, 1>(s, grid, max_rows, st);
+  const Ring2Form f = ring2_form(2, true, nmat, s.K, s.K_sh, (int)grid.x, (int)grid.y, max_rows, ring2_num_cus(), knobs);
+  if (!f.ntb) return false;
+  if (nmat == 2) launch_ring2<half_t, 2>(s, grid, f, st);
+  else launch_ring2<half_t, 1>(s, grid, f, st);
   return true;
 }
 template bool launch_ffn_gemm<uint16_t, 1>(const FfnStage&, dim3, int, hipStream_t);

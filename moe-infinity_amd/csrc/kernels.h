@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace moeinf {
 
@@ -109,6 +110,56 @@ struct FfnStage {
   int ring2_nblk;          // row blocks per expert (0: the plain 2-D grid)
   int ring2_split;
 };
+// ---- which form of ffn_gemm_ring2 a stage takes: pure host logic, shared by the launchers (ffn_gemm.hip) and the introspection
+// export moeinf_ffn_ring2_form (engine.cpp), which tests/test_kernel_selection_cpu.py pins against DESIGN.md section 4.3.
+// (Round 4: the launcher once asked for max_rows <= 192 where the sync-free path's estimate is 193 — the kernel silently never
+// ran and six experiments measured its predecessor.)
+struct Ring2Knobs {
+  int enable_bits = 3;   // MOEINF_GEMM_RING2: bit 0 gated stage, bit 1 plain stage
+  int min_k = 4096;      // MOEINF_RING_MIN_K
+  int max_rows = 340;    // MOEINF_RING2_MAX_ROWS: above, a second pass over the weights begins -> the big-tile kernel
+  int min_gated = 0;     // MOEINF_RING2_MIN_ROWS_GATED (0: where the hybrid kernel stops)
+  int min_plain = 16;    // MOEINF_RING2_MIN_ROWS_PLAIN
+  int tail = 1;          // MOEINF_RING2_TAIL: split a half-empty last round of the gated stage into half workgroups
+  int hyb_rows = 0;      // MOEINF_GEMM_HYB_ROWS (0: 128 with <= 16 active experts, else 64)
+  static int env_or(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
+  static Ring2Knobs from_env() {
+    Ring2Knobs k;
+    k.enable_bits = env_or("MOEINF_GEMM_RING2", k.enable_bits); k.min_k = env_or("MOEINF_RING_MIN_K", k.min_k);
+    k.max_rows = env_or("MOEINF_RING2_MAX_ROWS", k.max_rows); k.min_gated = env_or("MOEINF_RING2_MIN_ROWS_GATED", k.min_gated);
+    k.min_plain = env_or("MOEINF_RING2_MIN_ROWS_PLAIN", k.min_plain); k.tail = env_or("MOEINF_RING2_TAIL", k.tail);
+    k.hyb_rows = env_or("MOEINF_GEMM_HYB_ROWS", k.hyb_rows);
+    return k;
+  }
+};
+// rows per expert up to which the hybrid kernel runs (17 ..): 128 when at most 16 experts are active, else 64
+inline int hyb_rows_for(int active, const Ring2Knobs& k) { return k.hyb_rows ? k.hyb_rows : (active <= 16 ? 128 : 64); }
+struct Ring2Form {
+  int ntb = 0;    // 0: not ring2; else token groups per pass: 8 / 12 / 16 (128 / 192 / 256 tokens)
+  int tail = 0;   // 1: 1-D grid with a split tail (gated stage only)
+  int nblk = 0;   // row blocks (128 rows) per expert
+  int split = 0;  // first unit that is dealt to two half workgroups
+  int blocks = 0; // workgroups launched
+};
+// elem_bytes: 2 (bf16 / fp16); f16: the hybrid kernel does not exist for fp16, the gated stage starts at 65 rows there;
+// row_groups = ceil(max(R, R_sh) / 16); active = grid.y (upper bound of experts with rows); max_rows: see launch_ffn_stage
+inline Ring2Form ring2_form(int elem_bytes, bool f16, int nmat, int K, int K_sh, int row_groups, int active, int max_rows, int num_cus,
+                            const Ring2Knobs& k) {
+  Ring2Form f;
+  if (elem_bytes != 2 || !(k.enable_bits & (nmat == 2 ? 1 : 2))) return f;
+  const bool k_ok = (K % 64) == 0 && K >= k.min_k && (K_sh == 0 || ((K_sh % 64) == 0 && K_sh >= k.min_k));
+  const int min_rows = nmat == 2 ? (k.min_gated ? k.min_gated : (f16 ? 64 : hyb_rows_for(active, k))) : k.min_plain;
+  if (!k_ok || max_rows <= min_rows || max_rows > k.max_rows) return f;
+  f.ntb = max_rows <= 128 ? 8 : (max_rows <= 208 ? 12 : 16);
+  f.nblk = (row_groups + 7) / 8;
+  const int units = f.nblk * active, rem = num_cus > 0 ? units % num_cus : 0;
+  f.blocks = units;
+  if (nmat == 2 && k.tail && units > num_cus && rem > 0 && rem <= num_cus / 2) {
+    f.tail = 1; f.split = units - rem; f.blocks = units + rem;
+  }
+  return f;
+}
+
 // max_rows_per_expert: upper bound of rows any one expert receives (selects the multi-token-tile variant)
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
 // row-major [R,K] -> MFMA A-operand tiles (see kernels.hip); dst needs tiled_bytes(R,K) bytes
