@@ -137,6 +137,8 @@ int moeinf_abi_version(void);
  * sync-free path); num_cus: compute units.  out[0] = token groups of 16 per pass (0: another kernel runs), out[1] = 1 when the
  * last round of workgroups is split into half workgroups, out[2] = row blocks per expert, out[3] = first split unit,
  * out[4] = workgroups launched.  Environment knobs are honoured as in the launcher. */
+/* the row estimate moeinf_moe_forward passes to the FFN launchers when every expert of the layer is resident (sync-free path) */
+int moeinf_rows_estimate(int tokens, int top_k, int num_experts);
 int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5);
 
 /* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "moeinf_last_error": (C.c_char_p, []),
     "moeinf_abi_version": (C.c_int, []),
     "moeinf_ffn_ring2_form": (C.c_int, [C.c_int] * 8 + [_I32P]),
+    "moeinf_rows_estimate": (C.c_int, [C.c_int] * 3),
     "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "moeinf_destroy": (C.c_int, [_P]),
     "moeinf_expert_layout": (C.c_int, [_P, C.c_int, _I64P, _I64P, _I32P, _I64P]),

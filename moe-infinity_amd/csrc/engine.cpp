@@ -362,6 +362,10 @@ static hipEvent_t get_event(moeinf_engine* g) {
 // ---- lifecycle -----------------------------------------------------------------------------
 extern "C" const char* moeinf_last_error(void) { return g_err.c_str(); }
 extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
+// rows of the busiest expert as the sync-free path assumes them (the host does not know the routing there): 1.5 x the mean + 1,
+// at most T.  Picks the FORM of the FFN kernels only; an expert with more rows takes more passes.
+static inline int rows_estimate(int T, int K, int E) { return (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1); }
+extern "C" int moeinf_rows_estimate(int tokens, int top_k, int num_experts) { return rows_estimate(tokens, top_k, num_experts); }
 extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5) {
   if (!out5 || (nmat != 1 && nmat != 2) || K <= 0 || R <= 0 || active <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_ffn_ring2_form: bad arguments");
   const bool two_bytes = dtype == MOEINF_DTYPE_BF16 || dtype == MOEINF_DTYPE_F16;
@@ -1562,7 +1566,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   bool fused = false;
   SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
-                       (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1), st, prof, prof ? &pr : nullptr,
+                       rows_estimate(T, K, E), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));
   strace.mark("dispatch_experts");
   if (want_combine && !fused) HIPCHK(launch_combine(ca, st));

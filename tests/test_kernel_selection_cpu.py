@@ -20,8 +20,11 @@ def form(dtype, nmat, K, R, active, max_rows, K_sh=0, cus=256):
 
 
 def engine_row_estimate(T, K, E):
-    """what moeinf_moe_forward passes on the sync-free path (csrc/engine.cpp: min(T, 1.5 T K / E + 1))"""
-    return min(T, (T * K * 3) // (2 * max(1, E)) + 1)
+    """what moeinf_moe_forward passes on the sync-free path (csrc/engine.cpp rows_estimate: min(T, 1.5 T K / E + 1)) — the
+    engine's own function, through the C ABI"""
+    est = load_library().moeinf_rows_estimate(T, K, E)
+    assert est == min(T, (T * K * 3) // (2 * max(1, E)) + 1)
+    return est
 
 
 def test_the_benchmarked_prefill_takes_the_192_token_form_with_a_split_tail():
