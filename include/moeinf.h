@@ -131,7 +131,7 @@ const char* moeinf_last_error(void);
 int moeinf_abi_version(void);
 
 /* ---- introspection for tests (no reference counterpart, no GPU needed): which form of the register-ring GEMM
- * (csrc/ffn_gemm.hip: ffn_gemm_ring2) the launcher picks for an FFN stage.  dtype: MOEINF_DTYPE_*; nmat: 2 = gated stage,
+ * (csrc/ffn_ring2_kernel.h: ffn_gemm_ring2) the launcher picks for an FFN stage.  dtype: MOEINF_DTYPE_*; nmat: 2 = gated stage,
  * 1 = plain; K / K_sh: reduction length of the routed / shared experts (0: no shared expert); R: output rows; active: experts
  * with rows (the grid's upper bound); max_rows: rows of the busiest expert as the engine passes it (1.5 x the mean + 1 on the
  * sync-free path); num_cus: compute units.  out[0] = token groups of 16 per pass (0: another kernel runs), out[1] = 1 when the

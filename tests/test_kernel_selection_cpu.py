@@ -1,4 +1,4 @@
-"""Which form of the register-ring GEMM (csrc/ffn_gemm.hip: ffn_gemm_ring2) an FFN stage takes — the table of DESIGN.md section
+"""Which form of the register-ring GEMM (csrc/ffn_ring2_kernel.h: ffn_gemm_ring2) an FFN stage takes — the table of DESIGN.md section
 4.3, pinned through the introspection export moeinf_ffn_ring2_form (include/moeinf.h; pure host logic, the function the
 launchers themselves call: csrc/kernels.h ring2_form).  Why this exists: in round 4 the launcher asked for max_rows <= 192 where
 the engine's sync-free path passes 1.5 x the mean + 1 = 193 for a 512-token Mixtral prefill; the new kernel silently never ran
