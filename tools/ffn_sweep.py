@@ -68,7 +68,7 @@ if __name__ == "__main__":
     for spec in wls:
         wl, B, L = spec.split(":")
         # default sweep: the shipped choice vs the main alternatives (see DESIGN.md section 4.3 for every knob)
-        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_RING": 0}, {"MOEINF_RING_WIDE": 0}, {"MOEINF_RING_WIDE": 1}]
+        envs = [{}] if int(B) <= 16 else [{}, {"MOEINF_GEMM_RING2": 0}, {"MOEINF_RING2_TAIL": 0}, {"MOEINF_GEMM_BIG": 0}]
         if os.environ.get("SWEEP_ENVS"):
             envs = [dict(kv.split("=") for kv in e.split(",") if kv) for e in os.environ["SWEEP_ENVS"].split(";")]
         for env in envs:

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 3 study; MOEINF_RING_K4 and the ffn_gemm_ring kernel it selected were removed in round 4 — kept as the record of what
+#  profiles/r03_ffn_sweep_prefill_ring_k4.txt ran)
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-r3j}; mkdir -p "$OUT"
