@@ -82,12 +82,10 @@ __device__ __forceinline__ void ring2_wait(u32x4 (&w)[WL]) {
   else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N) : "memory");
 }
 
-// EARLY (built in round 4, NOT yet measured — off unless MOEINF_RING2_EARLY=1): a four-deep LDS ring with the stage barrier one
-// stage early.  Barrier S then certifies everybody's X(S+1), so the first fragments of stage S+1 are read at the END of step S and
-// a step starts its MFMAs right behind its barrier instead of behind an LDS round trip.  Issue order of every wave: prologue
-// W0 X0 X1 W1 X2 W2 .. W(D-2); step S issues X(S+3) then W(S+D-1); before step S: own W(S) and X(S+1) landed — the same
-// in-flight counts as the plain form, one stage later for X.
-template <typename T, int NMAT, int NTB, int D, bool TAIL = false, bool EARLY = false>
+// (Round 4 built an EARLY form — four-deep LDS ring, stage barrier one stage early, the first fragments of stage S+1 read at the
+// end of step S.  Measured in round 5 (profiles/r05_ffn_sweep_ring2_early_vs_shipped.txt): parity green, 512 tokens 363.5-386.8 us
+// vs 359.8-384.4 us for this form, 384 / 768 tokens within 1 % — no gain for 24 KiB more LDS, so it was removed.)
+template <typename T, int NMAT, int NTB, int D, bool TAIL = false>
 __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   static_assert(sizeof(T) == 2, "bf16 / fp16");
   static_assert(D >= 3 && D <= 6, "register ring of 3..6 stages");
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   constexpr int NWV = 8, KT = 2, EPT = 32, EPV = 8;
   constexpr int WL = KT * NMAT;             // weight tiles (1 KiB) per wave and stage
   constexpr int XSTAGE = KT * NTB * 1024;   // activation bytes per stage
-  constexpr int NX = EARLY ? 4 : 3;         // LDS ring
+  constexpr int NX = 3;                       // LDS ring
   constexpr int CW = 8 / NMAT;              // token groups per chunk: 8 MFMAs between two fragment batches
   __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
 
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
       constexpr int NWVE = decltype(nwc)::value;     // waves that work (4 in a half workgroup)
       if constexpr (NWVE < NWV) {
         if (wave >= NWVE) {  // same barriers as the working waves, nothing else
-          for (int ks = 0; ks < KS + (EARLY ? 1 : 0); ++ks) __builtin_amdgcn_s_barrier();
+          for (int ks = 0; ks < KS; ++ks) __builtin_amdgcn_s_barrier();
           return;
         }
       }
@@ -191,34 +189,17 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
       for (int t = 0; t < WL; ++t) issue_w1(0, wr[0], t);
 #pragma unroll
       for (int i = 0; i < XPWP; ++i) issue_x1(0, i);
-      if constexpr (EARLY) {
-#pragma unroll
-        for (int i = 0; i < XPWP; ++i) issue_x1(1, i);
-      }
 #pragma unroll
       for (int t = 0; t < WL; ++t) issue_w1(1, wr[1], t);
 #pragma unroll
-      for (int i = 0; i < XPWP; ++i) issue_x1(EARLY ? 2 : 1, i);
+      for (int i = 0; i < XPWP; ++i) issue_x1(1, i);
 #pragma unroll
       for (int d = 2; d <= D - 2; ++d)
 #pragma unroll
         for (int t = 0; t < WL; ++t) issue_w1(d, wr[d], t);
-      u32x4 fb0[CW];  // EARLY only: the first chunk of the next stage, read before that stage's barrier (a third fragment set)
-      auto read_first_chunk_of = [&](uint32_t stage_base) {
-        static_for<CW>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i < NG) lds_read16<i * 2048>(fb0[i], stage_base + frag_off[0]);
-        });
-      };
-      if constexpr (EARLY) {
-        // own X(0) landed (behind it in the prologue: X1 W1 X2 W2 .. W(D-2)) -> barrier: everybody's -> first fragments of stage 0
-        ring2_wait<WL, 2 * XPWP + (D - 2) * WL>(wr[0]);
-        __builtin_amdgcn_s_barrier();
-        read_first_chunk_of(lds0);
-      }
       auto step = [&](int S, u32x4 (&wc)[WL], u32x4 (&wn)[WL]) {
-        ring2_wait<WL, NWAIT>(wc);      // this wave's W(S) and X(S) (EARLY: X(S+1)) landed
-        __builtin_amdgcn_s_barrier();   // everybody's X(S) (EARLY: X(S+1)) landed; the LDS buffer the step refills and ring slot (S-1)%D are free
+        ring2_wait<WL, NWAIT>(wc);      // this wave's W(S) and X(S) landed
+        __builtin_amdgcn_s_barrier();   // everybody's X(S) landed; the LDS buffer the step refills and ring slot (S-1)%D are free
         const uint32_t sbase = lds0 + (S % NX) * XSTAGE;
         uint32_t fa[KT];
 #pragma unroll
@@ -233,30 +214,18 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
             if constexpr (c * CW + i < NG) lds_read16<(c * CW + i) * 2048>(f[i], fa[kk]);
           });
         };
-        if constexpr (!EARLY) read_slot(std::integral_constant<int, 0>{}, fb[0]);  // (EARLY: chunk 0 sits in fb0, read before the barrier)
+        read_slot(std::integral_constant<int, 0>{}, fb[0]);
         static_for<NSLOT>([&](auto jc) {
           constexpr int j = decltype(jc)::value, kk = j / NCH, c = j % NCH;
           constexpr int width = (NG - c * CW) < CW ? (NG - c * CW) : CW;
           constexpr int cn = (j + 1) % NCH;
-          constexpr bool cross = EARLY && j + 1 == NSLOT;  // the next stage's first chunk, before that stage's barrier
-          constexpr int width_next = (j + 1 < NSLOT || cross) ? ((NG - cn * CW) < CW ? (NG - cn * CW) : CW) : 0;
+          constexpr int width_next = (j + 1 < NSLOT) ? ((NG - cn * CW) < CW ? (NG - cn * CW) : CW) : 0;
           if constexpr (j + 1 < NSLOT) read_slot(std::integral_constant<int, j + 1>{}, fb[(j + 1) & 1]);
-          else if constexpr (cross) read_first_chunk_of(lds0 + ((S + 1) % NX) * XSTAGE);  // (past the last stage: stale bytes, never multiplied)
           static_for<(j + 1) * OPS / NSLOT - j * OPS / NSLOT>([&](auto oc) {
             constexpr int o = j * OPS / NSLOT + decltype(oc)::value;
-            if constexpr (o < XPWP) issue_x1(S + (EARLY ? 3 : 2), o);
+            if constexpr (o < XPWP) issue_x1(S + 2, o);
             else issue_w1(S + D - 1, wn, o - XPWP);
           });
-          if constexpr (EARLY && j == 0) {
-            frag_wait<width, width_next>(fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<width>([&](auto ic) {
-              constexpr int i = decltype(ic)::value;
-#pragma unroll
-              for (int m = 0; m < NMAT; ++m) mma16<T>(acc[c * CW + i][m], wc[kk * NMAT + m], fb0[i]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
           frag_wait<width, width_next>(fb[j & 1]);  // this chunk's fragments landed; the next chunk's stay in flight
           __builtin_amdgcn_sched_barrier(0);          // the reads and loads above stay above the MFMAs below
           static_for<width>([&](auto ic) {
@@ -265,7 +234,6 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
             for (int m = 0; m < NMAT; ++m) mma16<T>(acc[c * CW + i][m], wc[kk * NMAT + m], fb[j & 1][i]);
           });
           __builtin_amdgcn_sched_barrier(0);
-          }
         });
       };
       // unrolled by D: the register ring is indexed statically; past the end the issues are clamped re-reads
@@ -278,7 +246,6 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
       // load that nobody reads is still on its way into it
 #pragma unroll
       for (int d = 0; d < D; ++d) ring2_wait<WL, 0>(wr[d]);
-      if constexpr (EARLY) frag_wait<(NG < CW ? NG : CW), 0>(fb0);  // the stale cross-stage reads of the last step
       // epilogue straight from the accumulators: lane holds 4 consecutive rows of one token
       epi_switch<NMAT>(s.epi, [&](auto epic) {
         constexpr int EPI = decltype(epic)::value;
@@ -311,16 +278,12 @@ static int ring2_num_cus() {
 template <typename T, int NMAT>
 static void launch_ring2(const FfnStage& s0, dim3 grid, const Ring2Form& f, hipStream_t st) {
   const dim3 g2((unsigned)f.nblk, grid.y);
-  // (unmeasured; bf16, 192-token forms only: the gated stage with a split tail, the plain stage)
-  static const bool early_env = env_int("MOEINF_RING2_EARLY", 0) != 0;
-  const bool early = early_env && std::is_same<T, uint16_t>::value;
   FfnStage s = s0;
   if constexpr (NMAT == 2) {
     if (f.tail) {
       s.ring2_nblk = f.nblk; s.ring2_split = f.split;
       const dim3 g1((unsigned)f.blocks);
       if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
-      else if (f.ntb == 12 && early) { if constexpr (std::is_same<T, uint16_t>::value) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true, true>), g1, dim3(512), 0, st, s); }
       else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
       else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3, true>), g1, dim3(512), 0, st, s);
       return;
@@ -330,7 +293,6 @@ static void launch_ring2(const FfnStage& s0, dim3 grid, const Ring2Form& f, hipS
     else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);
   } else {
     if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
-    else if (f.ntb == 12 && early) { if constexpr (std::is_same<T, uint16_t>::value) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4, false, true>), g2, dim3(512), 0, st, s); }
     else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
     else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 16, 4>), g2, dim3(512), 0, st, s);
   }

@@ -6,8 +6,6 @@ dispatch index, per-expert rows within 1 ulp, block output within the combine ba
 (oracle/parity.py): block output and expert rows must be as close to the fp32 computation as the reference's CPU path
 (the oracle in the model dtype) is, mean |gpu - exact| <= 1.15 x mean |oracle - exact|.  Needs an MI355X: -m gpu."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -254,12 +252,3 @@ def test_mixtral_8x7b_layer_skewed_routing_takes_several_passes():
         assert_block_close(out, ref, torch.bfloat16, what)
     assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.bfloat16, "Mixtral-8x7B layer, skewed routing", rows=got_rows)
     eng.close()
-
-
-@pytest.mark.skipif(os.environ.get("MOEINF_TEST_EXPERIMENTAL") != "1", reason="kernel variants that are built but not yet measured (DESIGN.md section 11): MOEINF_TEST_EXPERIMENTAL=1")
-def test_experimental_early_barrier_form_of_the_register_ring():
-    """MOEINF_RING2_EARLY=1 (four-deep LDS ring, barrier one stage early; off by default): the 512-token and the skewed-routing
-    cases in a child process with the knob set (the launchers read their knobs once per process)."""
-    env = dict(os.environ, MOEINF_RING2_EARLY="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "prefill_t512 or skewed or prefill_t352"], env=env, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:]
