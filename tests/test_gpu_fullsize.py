@@ -5,7 +5,6 @@ Switch-base-8 (fp32).  Same assertions as the toy-shape tests (tests/helpers.py 
 dispatch index, per-expert rows within 1 ulp, block output within the combine bar — and the fp32-exact arm
 (oracle/parity.py): block output and expert rows must be as close to the fp32 computation as the reference's CPU path
 (the oracle in the model dtype) is, mean |gpu - exact| <= 1.15 x mean |oracle - exact|.  Needs an MI355X: -m gpu."""
-import os
 
 import numpy as np
 import pytest
