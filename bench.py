@@ -207,32 +207,49 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 break
             if ep_plain is None:
                 ep_plain = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport="torch")
-            same = True
-            try:
-                for _ in range(2):  # the first pass takes the decision path, the second the sync-free one
-                    for l in range(min(2, L)):
+            # Every rank runs the SAME sequence of collectives whatever happens to it locally: a candidate forward that raises
+            # (or whose poll gives up) only sets this rank's verdict; the torch-transport forward and the all-reduce of the
+            # verdicts follow on every rank, after EVERY probation forward — so one failing rank ends the probation of this
+            # candidate for everybody at the next all-reduce instead of leaving the others in a collective it never enters.
+            t_prob = time.time()
+            if cand == "peer-store":  # on probation a peer that never publishes costs seconds per poll, not MOEINF_EP_PEER_TIMEOUT_MS
+                eng.ep_peer_set_timeout_ms(3000)
+            passed, why = True, ""
+            for it in range(2):  # the first pass takes the decision path, the second the sync-free one
+                for l in range(min(2, L)):
+                    same, got = True, None
+                    try:
                         ep.forward(l, xs[0][l], gates[l], out=out)
+                        eng.sync()  # raises if a kernel of the exchange gave up waiting (flag 2) or met a rank out of step (flag 3)
                         got = out.clone()
-                        ep_plain.forward(l, xs[0][l], gates[l], out=out)
-                        if cfg.shared_inter and not torch.equal(got, out):
-                            # a hidden shared expert's stage 2 splits its reduction over another number of waves in the batch-1
-                            # broadcast form than in the router launch of the routed form: the same numbers in another fp32
-                            # summation order, i.e. at most a last-bit difference after the rounding to the model dtype
-                            a, b_ = got.float(), out.float()
-                            same &= bool(((a - b_).abs() <= 2.0 ** -7 * torch.maximum(torch.maximum(a.abs(), b_.abs()), b_.abs().mean())).all())
-                        else:
-                            same &= bool(torch.equal(got, out))
-                eng.sync()  # raises if a kernel of the exchange gave up waiting
-            except Exception as ex:  # noqa: BLE001
-                same = False
-                ep_notes.append(f"{cand}: {ex}")
-            v = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
-            if world > 1:
-                dist.all_reduce(v, op=dist.ReduceOp.MIN)
-            if bool(v.item()):
-                ep_notes.append(f"{cand}: self-test passed and probation passed on every rank (bit-identical to the torch.distributed transport" + ("; shared expert: to the last bit of the model dtype" if cfg.shared_inter else "") + ")")
+                    except Exception as ex:  # noqa: BLE001
+                        same, why = False, f"{ex}"
+                    ep_plain.forward(l, xs[0][l], gates[l], out=out)
+                    if got is not None and cfg.shared_inter and not torch.equal(got, out):
+                        # a hidden shared expert's stage 2 splits its reduction over another number of waves in the batch-1
+                        # broadcast form than in the router launch of the routed form: the same numbers in another fp32
+                        # summation order, i.e. at most a last-bit difference after the rounding to the model dtype
+                        a, b_ = got.float(), out.float()
+                        same &= bool(((a - b_).abs() <= 2.0 ** -7 * torch.maximum(torch.maximum(a.abs(), b_.abs()), b_.abs().mean())).all())
+                    elif got is not None:
+                        same &= bool(torch.equal(got, out))
+                    if same is False and not why:
+                        why = "outputs differ from the torch.distributed transport"
+                    v = torch.tensor([1 if same else 0], dtype=torch.int32, device=comm_dev(dist, dev))
+                    if world > 1:
+                        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                    passed = bool(v.item())
+                    if not passed:
+                        break
+                if not passed:
+                    break
+            if cand == "peer-store":
+                eng.ep_peer_set_timeout_ms(int(os.environ.get("MOEINF_EP_PEER_TIMEOUT_MS", "10000")))
+            if passed:
+                ep_notes.append(f"{cand}: self-test passed and probation passed on every rank (bit-identical to the torch.distributed transport" + ("; shared expert: to the last bit of the model dtype" if cfg.shared_inter else "") + f") in {time.time() - t_prob:.1f}s")
                 break
-            ep_notes.append(f"{cand}: FAILED probation (outputs differ from the torch.distributed transport on some rank)")
+            ep_notes.append(f"{cand}: FAILED probation after {time.time() - t_prob:.1f}s (" + (why or "on another rank") + ")")
+            ep.drop_native()  # collective: every rank gives the candidate's windows / buffers back
         log("expert-parallel transport: " + ep.transport + " | " + " | ".join(ep_notes))
 
         def layer_fwd(l, x):
@@ -325,7 +342,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev(dist, dev))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         windows.append(elapsed)
@@ -544,7 +561,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         n_pairs = max(1, len(refs))
         acc_ratio = acc_gpu / (acc_ref + 1e-30)
         if world > 1:  # one verdict for the job: every rank must be inside the bar
-            v = torch.tensor([1.0 if (ok and exact and acc_ok) else 0.0, -worst, -max_abs, -max_rel, -mean_rel, -acc_worst, -acc_ratio], dtype=torch.float64, device=dev)
+            v = torch.tensor([1.0 if (ok and exact and acc_ok) else 0.0, -worst, -max_abs, -max_rel, -mean_rel, -acc_worst, -acc_ratio], dtype=torch.float64, device=comm_dev(dist, dev))
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             ranks_ok = int(v[0].item())
             worst, max_abs, max_rel, mean_rel, acc_worst, acc_ratio = -v[1].item(), -v[2].item(), -v[3].item(), -v[4].item(), -v[5].item(), -v[6].item()
@@ -624,6 +641,28 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
     return res
 
 
+def comm_dev(dist, dev):
+    """where the small verdict / timing tensors of a collective live: RCCL moves device tensors, gloo host tensors"""
+    return dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def spawn_ranks(n, argv):
+    """Re-run this script under torch.distributed.run with n ranks on this node; returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port (the hostname may not resolve: 127.0.0.1 only)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / hipIpc between the ranks
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("spawning:", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     # Native libraries (RCCL prints a version banner, HIP/driver warnings) write to the C stdout; keep the
     # process's real stdout for the ONE JSON line only.
@@ -657,11 +696,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("MOEINF_BENCH_SHARE_GPU0"):  # testing only: every rank on GPU 0 (multi-rank RCCL on a 1-GPU box, if RCCL allows it)
-        local_rank = 0
+    share_gpu0 = bool(os.environ.get("MOEINF_BENCH_SHARE_GPU0"))
+    if share_gpu0:  # testing only (tests/test_gpu_bench_ranks.py): every rank on GPU 0 of a one-GPU box.  RCCL refuses several
+        local_rank = 0  # ranks per GPU, so the process group is gloo (bootstrap blobs, verdicts); the rows travel over the peer-store transport
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves, exactly as the driver's launcher would
+        # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...);
+        # rank 0 of the children writes the ONE JSON line to the stdout it inherits from this process.
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N` and let it spawn them)")
     import torch.distributed as dist
 
     torch.cuda.set_device(local_rank)
@@ -670,7 +716,10 @@ def main():
     if use_ep:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share_gpu0 and world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
 

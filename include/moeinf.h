@@ -470,7 +470,12 @@ int moeinf_ep_all_to_all(moeinf_engine* eng, const void* send_dev, void* recv_de
  * ranks map it (hipIpcOpenMemHandle between processes, the plain pointer inside one process).  The router's pack step and the
  * owner's FFN stage 2 store rows STRAIGHT into the destination rank's window over xGMI and publish an exchange number in its
  * flag words; the consumer kernels poll their own flags (bounded: MOEINF_EP_PEER_TIMEOUT_MS, default 10 000; on expiry the
- * device error flag reads 2 at the next sync point).  Unlike RCCL it also runs between processes that SHARE a GPU.
+ * device error flag reads 2; a flag AHEAD of the awaited exchange — a rank out of step after a failed call — reads 3).  The
+ * flag is reported by moeinf_sync AND, without any sync, by a later moeinf_ep_moe_forward: the stream copies it to a pinned
+ * word every MOEINF_EP_ERR_CHECK_EVERY (16) exchanges and every forward looks at that word first (MOEINF_ERR_STATE).
+ * Unlike RCCL it also runs between processes that SHARE a GPU.  Which exchange form a forward takes (routed / batch-1
+ * broadcast, polls inside the consumers / a wait kernel in front) is decided from ALL ranks' blobs, so MOEINF_EP_PEER_POLL and
+ * MOEINF_EP_BCAST set on one rank only cannot split the group.
  * Bootstrap — every call is local and fails without blocking anyone; agree on the outcome between the steps:
  *   1. every rank: moeinf_ep_peer_export(eng, cap_tokens, blob)        allocates the window, writes a 192-byte blob
  *   2. exchange the blobs over any channel (torch.distributed all_gather, a file, MPI), concatenate them in rank order
@@ -482,6 +487,15 @@ int moeinf_ep_all_to_all(moeinf_engine* eng, const void* send_dev, void* recv_de
 int moeinf_ep_peer_export(moeinf_engine* eng, int cap_tokens, void* blob_out, int nbytes /* 192 */);
 int moeinf_ep_peer_attach(moeinf_engine* eng, const void* blobs, int nbytes /* ep_size * 192 */);
 int moeinf_ep_peer_selftest(moeinf_engine* eng, void* stream, int32_t* ok);
+/* Undo steps 1-3 (local): unmap the peers, free the window and its staging buffers (kept if an RCCL communicator uses them).
+ * For a group that agreed NOT to use this transport after a failed attach / self-test; every rank calls it or none (a peer
+ * may store into a window until it is released).  The reference has no counterpart: its peer access is process-wide
+ * (core/prefetch/archer_prefetch_handle.cpp:37-61). */
+int moeinf_ep_peer_release(moeinf_engine* eng);
+/* How long a consumer waits for a peer's flag before it gives up (error flag 2).  Set from MOEINF_EP_PEER_TIMEOUT_MS (10 000)
+ * by moeinf_ep_peer_export; a host layer shortens it while a transport is on probation (bench.py: 3 000) so that a peer that
+ * never publishes costs seconds, and restores it afterwards.  Takes effect with the next exchange; ms > 0. */
+int moeinf_ep_peer_set_timeout_ms(moeinf_engine* eng, int ms);
 /* out[0] = transport moeinf_ep_moe_forward will take (MOEINF_EP_TRANSPORT_*); out[1] = 1 if another rank shares this GPU
  * (then a one-wave wait kernel runs in front of the consumers instead of polls inside them); out[2] = 1: polls inside the
  * consumer kernels; out[3] = exchanges so far */

@@ -161,6 +161,8 @@ PROTOTYPES = {
     "moeinf_ep_peer_export": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "moeinf_ep_peer_attach": (C.c_int, [_P, _P, C.c_int]),
     "moeinf_ep_peer_selftest": (C.c_int, [_P, _P, _I32P]),
+    "moeinf_ep_peer_release": (C.c_int, [_P]),
+    "moeinf_ep_peer_set_timeout_ms": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_transport": (C.c_int, [_P, _I32P]),
     "moeinf_ep_select_transport": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_set_uniform_tokens": (C.c_int, [_P, C.c_int]),

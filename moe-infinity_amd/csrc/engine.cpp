@@ -276,7 +276,10 @@ struct moeinf_engine {
   bool ep_uniform = false;         // the caller guarantees equal token counts on every rank (moeinf_ep_set_uniform_tokens): batch 1 = broadcast form
   std::vector<int32_t> ep_peer_pids;
   std::vector<uint64_t> ep_peer_ptrs;
-  bool ep_peer_poll = true;        // consumer kernels poll their flags themselves (false: a one-wave wait kernel in front)
+  bool ep_peer_poll = true;        // consumer kernels poll their flags themselves (false: a one-wave wait kernel in front); agreed by all ranks (ep_peer.h: poll_agreed)
+  bool ep_bcast_ok = true;         // the broadcast form may be taken: agreed by all ranks (ep_peer.h: bcast_agreed)
+  int32_t* ep_err_host = nullptr;  // pinned copy of the device error flag, refreshed by the exchange itself (see ep_peer_forward)
+  uint32_t ep_err_every = 16;      // ... every so many exchanges (MOEINF_EP_ERR_CHECK_EVERY)
   int64_t ep_peer_timeout_ticks = 0;
   struct EpProfRec { hipEvent_t ev[6]; };
   std::vector<EpProfRec> ep_prof_pending;
@@ -452,6 +455,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (g->ep_comm) { std::string e; if (const RcclApi* api = RcclApi::get(&e)) api->CommDestroy(g->ep_comm); g->ep_comm = nullptr; }
   for (void* b : {g->ep_x_send, g->ep_x_recv, g->ep_x_y, g->ep_x_ret}) if (b) hipFree(b);
   g->ep_x_y = nullptr;
+  if (g->ep_err_host) { hipHostFree(g->ep_err_host); g->ep_err_host = nullptr; }
   g->ep_win.destroy();  // (the caller's ranks have agreed to stop before any of them gets here: a peer may still store into the window)
   for (auto& s : g->slots) if (s.dev) hipFree(s.dev);
   for (auto p : g->shared_dev) if (p) hipFree(p);
@@ -1699,6 +1703,8 @@ static int check_device_flag(moeinf_engine* g) {
   HIPCHK(hipMemcpy(&f, g->d_miss, sizeof f, hipMemcpyDeviceToHost));
   if (f == 0) return MOEINF_OK;
   HIPCHK(hipMemset(g->d_miss, 0, sizeof f));
+  if (g->ep_err_host) *g->ep_err_host = 0;
+  if (f == 3) return fail(MOEINF_ERR_STATE, "device error flag 3: a kernel of the peer-store exchange found another rank AHEAD of this one (an earlier call failed on one side), results of the last forwards are invalid");
   if (f == 2) return fail(MOEINF_ERR_STATE, "device error flag 2: a kernel of the peer-store exchange gave up waiting for another rank's rows (MOEINF_EP_PEER_TIMEOUT_MS), results of the last forwards are invalid");
   return fail(MOEINF_ERR_STATE, "device error flag %d: an FFN workgroup found no resident blob for an active expert, results of the last forwards are invalid", f);
 }
@@ -2768,6 +2774,13 @@ extern "C" int moeinf_ep_peer_export(moeinf_engine* g, int cap_tokens, void* blo
   const int cap_rows = ep_min_cap(g, cap_tokens);
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
   if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
+  if (g->ep_x_send && g->ep_x_cap_rows != cap_rows)  // staging buffers of a communicator prepared for another capacity would be re-used below
+    return fail(MOEINF_ERR_STATE, "the RCCL exchange buffers were built for another cap_tokens (cap_rows %d, wanted %d)", g->ep_x_cap_rows, cap_rows);
+  if (!g->ep_err_host) {
+    if (hipHostMalloc((void**)&g->ep_err_host, 64, hipHostMallocDefault) != hipSuccess) { g->ep_err_host = nullptr; (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "pinned error word"); }
+    *g->ep_err_host = 0;
+    if (const char* ev = getenv("MOEINF_EP_ERR_CHECK_EVERY")) g->ep_err_every = (uint32_t)std::max(1, atoi(ev));
+  }
   std::string err = g->ep_win.create(g->cfg.ep_size, cap_rows, ep_row_elems(g) * g->es, (int64_t)g->H * g->es, g->E);
   if (err.empty() && !g->ep_x_recv) {  // routed-form staging of the broadcast form's slow path (launch_ep_bcast_unpack)
     if (hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es) != hipSuccess) { g->ep_x_recv = nullptr; err = "hipMalloc of the unpack staging buffer failed"; }
@@ -2802,13 +2815,34 @@ extern "C" int moeinf_ep_peer_attach(moeinf_engine* g, const void* blobs, int nb
   }
   const std::string err = g->ep_win.attach(bs.data(), g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id);
   if (!err.empty()) { (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "%s", err.c_str()); }
-  // ranks that share this GPU (tests on a one-GPU box) must not spin inside wide kernels — the rank they wait for needs CUs
-  // to run on; MOEINF_EP_PEER_POLL=0/1 overrides
-  g->ep_peer_poll = !g->ep_win.shared_device;
-  if (const char* e = getenv("MOEINF_EP_PEER_POLL")) g->ep_peer_poll = atoi(e) != 0;
+  // ranks that share a GPU (tests on a one-GPU box) must not spin inside wide kernels — the rank they wait for needs CUs
+  // to run on; MOEINF_EP_PEER_POLL=0/1 overrides.  Both, and MOEINF_EP_BCAST, are GROUP decisions: every rank derives them
+  // from all ranks' blobs (ep_peer.h: attach), so that no two ranks can end up in different exchange forms.
+  g->ep_peer_poll = g->ep_win.poll_agreed;
+  g->ep_bcast_ok = g->ep_win.bcast_agreed;
   g->ep_peer_pids.clear(); g->ep_peer_ptrs.clear();
   for (auto& b : bs) { g->ep_peer_pids.push_back(b.pid); g->ep_peer_ptrs.push_back(b.ptr); }
   g->ep_use_peer = true;
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_peer_set_timeout_ms(moeinf_engine* g, int ms) {
+  if (!g || ms <= 0) return fail(MOEINF_ERR_INVALID, "engine is NULL or ms <= 0");
+  g->ep_peer_timeout_ticks = (int64_t)ms * 100000;  // wall_clock64: 100 MHz
+  return MOEINF_OK;
+}
+
+extern "C" int moeinf_ep_peer_release(moeinf_engine* g) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  HIPCHK(hipSetDevice(g->cfg.device_id));
+  HIPCHK(hipDeviceSynchronize());  // no kernel of this rank still reads or writes a window
+  g->ep_win.destroy();
+  g->ep_win_cap_tokens = 0;
+  g->ep_use_peer = false;
+  g->ep_peer_pids.clear(); g->ep_peer_ptrs.clear();
+  if (!g->ep_x_send) {  // the staging buffers belong to this transport alone (no communicator prepared)
+    for (void** b : {&g->ep_x_recv, &g->ep_x_y}) if (*b) { (void)hipFree(*b); *b = nullptr; }
+  }
   return MOEINF_OK;
 }
 
@@ -2838,7 +2872,10 @@ extern "C" int moeinf_ep_peer_selftest(moeinf_engine* g, void* stream, int32_t* 
   const int words = (int)std::min<int64_t>(1024, std::min(pv.recv_row_bytes, pv.ret_row_bytes) * pv.cap_rows / 4);
   int32_t* ok_dev = g->ep_win.done + 8;  // a spare word of the counter allocation
   HIPCHK(hipMemsetAsync(ok_dev, 0, 4, st));
-  HIPCHK(launch_ep_selftest_send(pv, words, st));
+  // fault injection for the liveness tests (tests/test_gpu_bench_ranks.py): this rank never publishes — what a rank behind a
+  // dead link looks like to its peers; they must come out of their self-test with ok = 0 after the bounded wait
+  const char* silent = getenv("MOEINF_EP_TEST_SILENT_RANK");
+  if (!silent || atoi(silent) != g->cfg.ep_rank) HIPCHK(launch_ep_selftest_send(pv, words, st));
   HIPCHK(launch_ep_selftest_check(pv, words, ok_dev, st));
   HIPCHK(hipMemcpyAsync(ok, ok_dev, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -2867,7 +2904,7 @@ extern "C" int moeinf_ep_set_uniform_tokens(moeinf_engine* g, int on) {
 }
 
 static bool ep_bcast_eligible(const moeinf_engine* g, int tokens) {
-  static const bool env = getenv("MOEINF_EP_BCAST") ? atoi(getenv("MOEINF_EP_BCAST")) != 0 : true;
+  const bool env = g->ep_bcast_ok;  // (MOEINF_EP_BCAST of EVERY rank, see moeinf_ep_peer_attach)
   const int et = g->cfg.expert_type;
   // consumer kernels must poll for themselves (the broadcast rides in FFN stage 1: no room for a wait kernel in front of it)
   return env && g->ep_uniform && tokens == 1 && g->ep_peer_poll && g->K <= 8 && g->E <= 64 && g->dt != DT_F32 &&
@@ -2893,8 +2930,7 @@ static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev,
   auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
   if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
   CHK(ep_alloc(g, cap));
-  g->ep_win.epoch += 1;
-  EpPeers pv;
+  EpPeers pv;  // (the exchange number was taken by ep_peer_forward)
   ep_peer_view(g, &pv);
   RouteArgs ra;
   make_route_args(g, x_dev, gate_w_dev, 1, ra);
@@ -2961,7 +2997,31 @@ static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev,
 // One expert-parallel MoE layer over the peer-store exchange: router (+ pack into the destinations' windows) -> owner FFN
 // (polls the row flags; stage 2 stores its outputs into the home ranks' windows) -> combine (polls the output flags).
 // Five launches on `stream`, no collective, no copy.
+static int ep_peer_forward_body(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream);
+
+// Exchange numbers are failure-atomic: EVERY entry takes the next number before anything can fail, so a rank whose call
+// returns an error (bad arguments, an allocation) is not one exchange behind its peers for good — its peers' kernels give
+// up on the exchange it never published (flag 2 after MOEINF_EP_PEER_TIMEOUT_MS), and a rank that IS out of step is
+// caught by the consumers themselves (a flag AHEAD of the exchange they wait for: flag 3, kdev.h ep_poll).  The device flag
+// is copied to a pinned word by the stream every ep_err_every exchanges and looked at on entry: a caller that never
+// calls moeinf_sync() still gets the error from one of its next forwards instead of silent garbage.
 static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
+  g->ep_win.epoch += 1;  // collective discipline: every rank runs the same sequence of exchanges
+  if (g->ep_err_host) {
+    const int32_t f = *(volatile int32_t*)g->ep_err_host;
+    if (f == 2 || f == 3) {
+      *g->ep_err_host = 0;
+      return fail(MOEINF_ERR_STATE, f == 2 ? "peer-store exchange: a kernel gave up waiting for another rank's rows (MOEINF_EP_PEER_TIMEOUT_MS); the results of the last forwards are invalid"
+                                           : "peer-store exchange: another rank is AHEAD of this one (an earlier call failed here or there); the results of the last forwards are invalid");
+    }
+  }
+  const int rc = ep_peer_forward_body(g, layer, x_dev, tokens, batch_rows, gate_w_dev, out_dev, stream);
+  if (rc == MOEINF_OK && g->ep_err_host && g->ep_win.epoch % g->ep_err_every == 0)
+    HIPCHK(hipMemcpyAsync(g->ep_err_host, g->d_miss, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return rc;
+}
+
+static int ep_peer_forward_body(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
   if (tokens > g->ep_win_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the exchange window", tokens, g->ep_win_cap_tokens);
   if (ep_bcast_eligible(g, tokens)) return ep_peer_forward_bcast(g, layer, x_dev, gate_w_dev, out_dev, stream);
   hipStream_t st = (hipStream_t)stream;
@@ -2970,7 +3030,6 @@ static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int t
   const bool prof = g->ep_profiling;
   auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
   if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-  g->ep_win.epoch += 1;  // collective discipline: every rank runs the same sequence of exchanges
   EpPeers pv;
   ep_peer_view(g, &pv);
   mark(0);

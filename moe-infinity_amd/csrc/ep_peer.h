@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -35,7 +36,9 @@ struct EpPeerBlob {
   char bus_id[32];          // PCI bus id of that device: equal ids + different pids = ranks sharing one GPU
   uint64_t ptr;             // window address in the exporting process
   uint64_t window_bytes;
-  int32_t cap_rows, reserved;
+  int32_t cap_rows;
+  int32_t wishes;           // this rank's environment overrides, so the decisions below are taken from the SAME data on every rank:
+                            // bits 0-1: MOEINF_EP_PEER_POLL (0 unset, 1 "0", 2 "1"); bit 2: broadcast form allowed (MOEINF_EP_BCAST != 0)
   int64_t recv_row_bytes, ret_row_bytes;
   hipIpcMemHandle_t handle;  // 64 bytes
 };
@@ -52,6 +55,11 @@ struct EpPeerWindow {
   std::vector<char> opened;      // 1: mapped with hipIpcOpenMemHandle (close it)
   bool attached = false;
   bool shared_device = false;    // some other rank runs on THIS GPU (another process): consumers must not spin in wide kernels
+  // decided in attach() from ALL ranks' blobs — identical on every rank, because the exchange FORM must be (a rank in the
+  // broadcast form and a rank in the routed form read regions of each other's windows that nobody wrote):
+  bool shared_anywhere = false;  // ANY two ranks of the group share a GPU
+  bool poll_agreed = true;       // consumer kernels poll for themselves (false: a one-wave wait kernel in front) — on every rank
+  bool bcast_agreed = true;      // the batch-1 broadcast form may be taken — on every rank
   uint32_t epoch = 0;
   int32_t* done = nullptr;       // arrival counter (ordinary device memory)
   std::string bus_id;
@@ -80,8 +88,17 @@ struct EpPeerWindow {
     return "";
   }
 
+  static int32_t env_wishes() {
+    int32_t w = 0;
+    if (const char* e = getenv("MOEINF_EP_PEER_POLL")) w |= atoi(e) != 0 ? 2 : 1;
+    const char* b = getenv("MOEINF_EP_BCAST");
+    if (!b || atoi(b) != 0) w |= 4;
+    return w;
+  }
+
   std::string export_blob(int rank, int size, int device, EpPeerBlob* b) const {
     memset(b, 0, sizeof *b);
+    b->wishes = env_wishes();
     b->magic = kEpPeerMagic; b->bytes_of_blob = sizeof *b;
     b->rank = rank; b->size = size; b->pid = (int32_t)getpid(); b->device = device;
     hipError_t e = hipDeviceGetPCIBusId(b->bus_id, sizeof b->bus_id, device);
@@ -111,22 +128,44 @@ struct EpPeerWindow {
     (void)hipGetLastError();
     for (int p = 0; p < size; ++p) {
       const EpPeerBlob& b = blobs[p];
-      if (b.magic != kEpPeerMagic || b.rank != p || b.size != size) return "blob " + std::to_string(p) + " is not rank " + std::to_string(p) + "'s export";
-      if (b.window_bytes != bytes || b.cap_rows != cap_rows || b.recv_row_bytes != recv_row_bytes || b.ret_row_bytes != ret_row_bytes)
+      if (b.magic != kEpPeerMagic || b.rank != p || b.size != size) { detach(); return "blob " + std::to_string(p) + " is not rank " + std::to_string(p) + "'s export"; }
+      if (b.window_bytes != bytes || b.cap_rows != cap_rows || b.recv_row_bytes != recv_row_bytes || b.ret_row_bytes != ret_row_bytes) {
+        detach();
         return "rank " + std::to_string(p) + " built a different window (cap_tokens / model shape must be the same on every rank)";
+      }
       if (p == rank) { peer[p] = base; continue; }
       if (b.pid == (int32_t)getpid()) {
         peer[p] = (void*)b.ptr;  // same process (several engines in one process): the address is valid here
       } else {
         void* q = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&q, b.handle, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return "hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(e);
+        if (e != hipSuccess) { detach(); return "hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(e); }
         peer[p] = q; opened[p] = 1;
         if (!strncmp(b.bus_id, mine, sizeof mine)) shared_device = true;
       }
     }
+    // group-wide decisions, from data every rank holds identically (the blobs): who shares a GPU with whom, and every
+    // rank's environment overrides
+    shared_anywhere = false;
+    for (int p = 0; p < size; ++p)
+      for (int q = p + 1; q < size; ++q)
+        if (blobs[p].pid != blobs[q].pid && !strncmp(blobs[p].bus_id, blobs[q].bus_id, sizeof blobs[p].bus_id)) shared_anywhere = true;
+    poll_agreed = true; bcast_agreed = true;
+    for (int p = 0; p < size; ++p) {
+      const int pw = blobs[p].wishes & 3;
+      const bool vote = pw ? pw == 2 : !shared_anywhere;  // a rank's wish, else the default: never spin where a peer needs the CUs
+      poll_agreed = poll_agreed && vote;
+      bcast_agreed = bcast_agreed && (blobs[p].wishes & 4) != 0;
+    }
     attached = true;
     return "";
+  }
+
+  // unmap the peers (the window itself stays: it can be exported and attached again)
+  void detach() {
+    for (size_t p = 0; p < peer.size(); ++p) if (opened[p] && peer[p]) (void)hipIpcCloseMemHandle(peer[p]);
+    peer.clear(); opened.clear();
+    attached = false; shared_device = false;
   }
 
   void view(EpPeers* v, int rank, int size, int32_t* err, int64_t timeout_ticks, bool poll) const {
@@ -143,8 +182,7 @@ struct EpPeerWindow {
   const uint32_t* ret_flags() const { return (const uint32_t*)((const char*)base + EP_RET_FLAGS_OFF); }
 
   void destroy() {
-    for (size_t p = 0; p < peer.size(); ++p) if (opened[p] && peer[p]) (void)hipIpcCloseMemHandle(peer[p]);
-    peer.clear(); opened.clear();
+    detach();
     if (base) (void)hipFree(base);
     if (done) (void)hipFree(done);
     base = nullptr; done = nullptr; attached = false; bytes = 0;

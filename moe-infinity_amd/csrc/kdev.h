@@ -126,7 +126,12 @@ __device__ __forceinline__ void ep_poll(const uint32_t* flags, const int n, cons
   for (;;) {
     uint32_t v = epoch;
     if (lane < n) v = __hip_atomic_load(flags + lane * EP_FLAG_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (__all((int32_t)(v - epoch) >= 0)) break;
+    if (__all((int32_t)(v - epoch) >= 0)) {
+      // a producer AHEAD of this exchange: one of the two ranks lost a call (a failed moeinf_ep_moe_forward); the rows read
+      // next belong to another exchange.  Not waited for — reported (3), like a timeout (2).
+      if (__any((int32_t)(v - epoch) > 0) && lane == 0) atomicExch(err, 3);
+      break;
+    }
     if (wall_clock64() - t0 > timeout_ticks) {
       if (lane == 0) atomicExch(err, 2);
       break;

@@ -382,6 +382,13 @@ class MoEEngine:
         buf = (C.c_uint8 * len(blobs)).from_buffer_copy(blobs)
         check(self.lib.moeinf_ep_peer_attach(self._h, buf, len(blobs)))
 
+    def ep_peer_set_timeout_ms(self, ms: int):
+        check(self.lib.moeinf_ep_peer_set_timeout_ms(self._h, int(ms)))
+
+    def ep_peer_release(self):
+        """moeinf_ep_peer_release: unmap the peers and free the window (the group agreed not to use this transport)"""
+        check(self.lib.moeinf_ep_peer_release(self._h))
+
     def ep_peer_selftest(self) -> bool:
         """tagged rows + flags to and from every peer (every rank must call it); False on a mismatch or a timeout"""
         ok = C.c_int32()

@@ -20,6 +20,7 @@ number of collectives is what matters.
 gloo backend (tests/test_ep_gloo.py supplies oracle-backed ops); the product ops are
 ``HipEpOps`` (HIP kernels through the C ABI).
 """
+import os
 from typing import Optional
 
 import torch
@@ -72,6 +73,7 @@ class ExpertParallelMoE:
     PHASES = ("route_pack", "a2a_dispatch", "owner_ffn", "a2a_combine", "combine")
 
     TRANSPORTS = ("auto", "peer-store", "rccl", "torch")
+    BOOT_TIMEOUT_MS = 3000  # per poll of the bootstrap self-test (MOEINF_EP_PEER_TIMEOUT_MS governs the exchanges after it)
 
     def __init__(self, ops, hidden: int, top_k: int, max_tokens: int, dtype: torch.dtype, device,
                  group: Optional[dist.ProcessGroup] = None, var_threshold: int = 64, num_experts: Optional[int] = None,
@@ -128,7 +130,9 @@ class ExpertParallelMoE:
             self.native_note = "; ".join(notes)
         if self.native:
             self.ops.engine.ep_select_transport(self.transport)
-            self.ops.engine.ep_set_uniform_tokens(bool(uniform_tokens))
+            # the promise selects the exchange FORM of one-token forwards, and the form must be the same on every rank:
+            # it holds only if EVERY rank made it
+            self.ops.engine.ep_set_uniform_tokens(self._agree(bool(uniform_tokens)))
 
     @property
     def profile(self):
@@ -171,6 +175,7 @@ class ExpertParallelMoE:
         if not self._agree(ok):
             if ok:
                 self.native_note = "window export failed on another rank"
+            self._release_peer_store(eng)
             return False
         dev = self._comm_device()
         mine = torch.tensor(list(blob), dtype=torch.uint8, device=dev)
@@ -185,22 +190,47 @@ class ExpertParallelMoE:
         if not self._agree(ok):
             if ok:
                 self.native_note = "mapping the peers' windows failed on another rank"
+            self._release_peer_store(eng)
             return False
         try:
+            # bounded bootstrap: a peer that never publishes costs BOOT_TIMEOUT_MS per poll of the self-test, not the
+            # exchange's own (long) timeout; the caller's setting comes back below
+            if hasattr(eng, "ep_peer_set_timeout_ms"):
+                eng.ep_peer_set_timeout_ms(self.BOOT_TIMEOUT_MS)
             ok = eng.ep_peer_selftest()
             if not ok:
                 self.native_note = "self-test: wrong rows or a peer never published (timeout)"
         except Exception as ex:  # noqa: BLE001
             ok = False
             self.native_note = f"self-test failed: {ex}"
+        finally:
+            if hasattr(eng, "ep_peer_set_timeout_ms"):
+                eng.ep_peer_set_timeout_ms(int(os.environ.get("MOEINF_EP_PEER_TIMEOUT_MS", "10000")))
         if not self._agree(ok):
             if ok:
                 self.native_note = "self-test failed on another rank"
+            self._release_peer_store(eng)
             return False
         t = eng.ep_transport()
         self.native_note = ("rows stored straight into the peers' windows, no collective (self-test passed on every rank; "
                             + ("ranks share a GPU: one-wave wait kernels" if not t["poll_in_kernels"] else "consumer kernels poll their flags") + ")")
         return True
+
+    def _release_peer_store(self, eng):
+        """every rank took the same 'not this transport' branch (the verdicts are all-reduced): unmap the peers and free the
+        window and its staging buffers — once nobody can still be storing into anybody's window"""
+        try:
+            dist.barrier(group=self.group)
+            eng.ep_peer_release()
+        except Exception as ex:  # noqa: BLE001
+            self.native_note += f" (release: {ex})"
+
+    def drop_native(self):
+        """Collective: the group decided (outside: bench.py's probation) not to use the native transport this object
+        bootstrapped — back to torch.distributed; a peer-store window is unmapped and freed on every rank."""
+        if self.native and self.transport == "peer-store":
+            self._release_peer_store(self.ops.engine)
+        self.native, self.transport = False, "torch"
 
     def _try_native(self, cap_tokens: int) -> bool:
         """Bootstrap the engine's own RCCL communicator through the existing process group, then PROVE it: a tagged

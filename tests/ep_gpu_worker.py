@@ -25,6 +25,14 @@ def main():
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    # EP_POLL_ONLY_RANK=r: MOEINF_EP_PEER_POLL=1 in the environment of rank r ALONE.  The exchange form is a group decision
+    # (every rank derives it from all ranks' blobs, csrc/ep_peer.h): rank r's wish is out-voted by the ranks that share the GPU
+    # with it and did not ask, so ALL ranks run wait kernels + the routed form — not rank r the broadcast form on its own.
+    only = os.environ.get("EP_POLL_ONLY_RANK", "")
+    if only != "":
+        os.environ.pop("MOEINF_EP_PEER_POLL", None)
+        if int(only) == rank:
+            os.environ["MOEINF_EP_PEER_POLL"] = "1"
     for family, e, k, n_shared in (("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2)):
         h, f, L, tmax = 256, 512, 2, 40
         ws = [make_weights(family, h, f, e, 3100 + 10 * l, torch.bfloat16, n_shared=n_shared) for l in range(L)]
@@ -45,7 +53,7 @@ def main():
         assert ep.transport == transport, f"rank {rank}: wanted {transport}, got {ep.transport}: {ep.native_note}"
         if transport == "peer-store":
             t = eng.ep_transport()  # the ranks share GPU 0: detected from the PCI bus ids in the blobs
-            want_poll = os.environ.get("MOEINF_EP_PEER_POLL", "0") == "1"  # default for ranks that share a GPU: wait kernels
+            want_poll = os.environ.get("MOEINF_EP_PEER_POLL", "0") == "1" and only == ""  # default for ranks that share a GPU: wait kernels
             assert t["transport"] == "peer-store" and t["shared_device"] and t["poll_in_kernels"] == want_poll, t
         dist.barrier()
         for t in (1, 1, 3 + rank, tmax - 3 * rank, 1):  # batch 1 (twice: decision path, then sync-free), ragged small batches (fixed form), prefill-sized (variable split), batch 1 again

@@ -116,7 +116,7 @@ class _FakeEngine:
 
     def __init__(self, rank, world, fail_rank, fail_step):
         self.rank, self.world, self.fail_rank, self.fail_step = rank, world, fail_rank, fail_step
-        self.attached_with, self.selected, self.uniform, self.forwards = None, None, None, 0
+        self.attached_with, self.selected, self.uniform, self.forwards, self.released = None, None, None, 0, 0
 
     def _maybe_fail(self, step):
         if self.rank == self.fail_rank and step == self.fail_step:
@@ -135,6 +135,10 @@ class _FakeEngine:
     def ep_peer_selftest(self):
         self._maybe_fail("selftest")
         return not (self.rank == self.fail_rank and self.fail_step == "selftest_false")
+
+    def ep_peer_release(self):
+        self.released += 1
+        self.attached_with = None
 
     def ep_transport(self):
         return {"transport": "peer-store", "shared_device": False, "poll_in_kernels": True, "exchanges": 1}
@@ -163,14 +167,17 @@ def _bootstrap_worker(rank, world, port, q, fail_rank, fail_step):
         ws = make_weights("mixtral", h, f, e, 90, torch.bfloat16)
         ops = OracleEpOps([ws[1]], rank, world, k, e, h)
         ops.engine = _FakeEngine(rank, world, fail_rank, fail_step)
-        ep = ExpertParallelMoE(ops, h, k, 4, torch.bfloat16, "cpu", num_experts=e, transport="peer-store", uniform_tokens=True)
+        # fail_step "one_rank_not_uniform": rank fail_rank does not promise equal token counts -> NO rank may take the broadcast form
+        uniform = not (fail_step == "one_rank_not_uniform" and rank == fail_rank)
+        ep = ExpertParallelMoE(ops, h, k, 4, torch.bfloat16, "cpu", num_experts=e, transport="peer-store", uniform_tokens=uniform)
         ep.forward(0, acts(2, h, torch.bfloat16, 91 + rank), ws[0])  # collective either way: native (fake) or torch transport (oracle ops)
-        q.put((rank, ep.transport, ep.native, ep.native_note, ops.engine.selected, ops.engine.uniform, ops.engine.forwards))
+        q.put((rank, ep.transport, ep.native, ep.native_note, ops.engine.selected, ops.engine.uniform, ops.engine.forwards, ops.engine.released))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fail_rank,fail_step", [(2, -1, ""), (3, 1, "export"), (3, 2, "attach"), (2, 0, "selftest"), (3, 1, "selftest_false")])
+@pytest.mark.parametrize("world,fail_rank,fail_step", [(2, -1, ""), (3, 1, "export"), (3, 2, "attach"), (2, 0, "selftest"), (3, 1, "selftest_false"),
+                                                       (3, 2, "one_rank_not_uniform")])
 def test_transport_bootstrap_is_all_or_nothing(world, fail_rank, fail_step):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -182,11 +189,15 @@ def test_transport_bootstrap_is_all_or_nothing(world, fail_rank, fail_step):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = "peer-store" if fail_rank < 0 else "torch"
-    for rank, transport, native, note, selected, uniform, forwards in res:
+    want = "peer-store" if fail_rank < 0 or fail_step == "one_rank_not_uniform" else "torch"
+    for rank, transport, native, note, selected, uniform, forwards, released in res:
         assert transport == want and native == (want != "torch"), (rank, transport, note)
         if want == "peer-store":
-            assert selected == "peer-store" and uniform is True and forwards == 1 and "self-test passed on every rank" in note
+            # the exchange FORM is a group decision: one rank that does not promise uniform token counts switches the
+            # broadcast form off on EVERY rank (advisor finding, round 4)
+            assert selected == "peer-store" and uniform is (fail_rank < 0) and forwards == 1 and "self-test passed on every rank" in note
+            assert released == 0
         else:  # every rank — the one that failed AND the ones that did not — stayed on torch.distributed and says why
             assert forwards == 0 and selected is None, (rank, note)
+            assert released == 1, "a transport the group turned down gives its window and mappings back on every rank"
             assert ("failed" in note) or ("another rank" in note) or ("self-test" in note), note

@@ -25,9 +25,11 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,transport,poll,uniform", [(2, "peer-store", "0", "0"), (3, "peer-store", "0", "0"), (2, "peer-store", "1", "0"),
-                                                          (2, "peer-store", "1", "1"), (3, "peer-store", "1", "1"), (2, "torch", "", "0")],
+                                                          (2, "peer-store", "1", "1"), (3, "peer-store", "1", "1"), (2, "torch", "", "0"),
+                                                          (3, "peer-store", "only_rank_1", "1")],
                          ids=["world2_peer_store_wait_kernels", "world3_peer_store_wait_kernels", "world2_peer_store_polls_inside_the_consumer_kernels",
-                              "world2_batch1_broadcast_form", "world3_batch1_broadcast_form", "world2_torch_host_staged"])
+                              "world2_batch1_broadcast_form", "world3_batch1_broadcast_form", "world2_torch_host_staged",
+                              "world3_one_rank_alone_asks_for_polls_and_is_outvoted"])
 def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport, poll, uniform):
     """poll: MOEINF_EP_PEER_POLL — "0" = the mode ranks that share a GPU get by default (one-wave wait kernels), "1" = the mode
     of one rank per GPU (the consumer kernels poll their flag words themselves), forced here so that it, too, has run between
@@ -35,7 +37,9 @@ def test_expert_parallel_ranks_as_processes_on_one_gpu(world, transport, poll, u
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ep_gpu_worker.py")]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EP_TRANSPORT=transport)
-    if poll:
+    if poll.startswith("only_rank_"):  # the knob in ONE rank's environment: the group must still agree on one exchange form
+        env["EP_POLL_ONLY_RANK"] = poll[len("only_rank_"):]
+    elif poll:
         env["MOEINF_EP_PEER_POLL"] = poll
     env["EP_UNIFORM"] = uniform  # "1": every rank promises equal token counts -> one-token forwards take the broadcast form
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
