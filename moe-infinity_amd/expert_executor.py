@@ -13,8 +13,15 @@ import torch
 
 
 class ExpertDispatcher:
+    """``engine``: one MoEEngine, or a list of them — one per expert device, in ``gpu_id`` order (every engine holds the
+    experts with ``expert % len(engines) == its index``, the reference's placement, model_topology.cpp:533-536).
+    ``enqueue_expert``'s ``gpu_id`` picks the engine, modulo their number (expert_dispatcher.cpp:135-137 queues on
+    ``gpu_id``); results come back on the hidden states' device (:405).  The drop-in over the reference's pybind
+    constructor signature is ``prefetch_op.expert_dispatcher``."""
+
     def __init__(self, engine):
-        self.engine = engine
+        self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+        self.engine = self.engines[0]
         self._queue = []
         self._expected = 0
         self._hidden = None
@@ -22,7 +29,7 @@ class ExpertDispatcher:
 
     # register_expert(layer, expert, tensor_ids) in the reference; here the tensors themselves
     def register_expert(self, layer_idx: int, expert_idx: int, tensors: Sequence[torch.Tensor]):
-        self.engine.register_expert(layer_idx, expert_idx, tensors)
+        self.engines[expert_idx % len(self.engines)].register_expert(layer_idx, expert_idx, tensors)
 
     def set_inputs(self, hidden_states: torch.Tensor, router_mask: torch.Tensor):
         self._hidden = hidden_states.reshape(-1, hidden_states.shape[-1]).contiguous()
@@ -32,34 +39,46 @@ class ExpertDispatcher:
         self._expected = expected_pending
 
     def enqueue_expert(self, layer_idx: int, expert_idx: int, gpu_id: int = 0, remote: bool = False):
-        self._queue.append((layer_idx, expert_idx))
+        if len(self.engines) > 1 and int(gpu_id) % len(self.engines) != expert_idx % len(self.engines):
+            raise RuntimeError(f"expert {expert_idx} lives on engine {expert_idx % len(self.engines)}, not on gpu_id {gpu_id} "
+                               "(this mirror does not move experts between devices; prefetch_op.expert_dispatcher does)")
+        self._queue.append((layer_idx, expert_idx, expert_idx % len(self.engines)))
 
     def wait_expert(self) -> List[Tuple[torch.Tensor, int, int, int]]:
         if len(self._queue) != self._expected:
             raise RuntimeError(f"expected {self._expected} enqueued experts, got {len(self._queue)}")
         if not self._queue:
             return []
-        layers = {l for l, _ in self._queue}
+        layers = {l for l, _, _ in self._queue}
         if len(layers) != 1:
             raise RuntimeError("one wait_expert() serves one layer (as dispatch_local uses it)")
         layer = layers.pop()
-        enq = sorted({e for _, e in self._queue})
-        mask = self._mask
-        if len(enq) != mask.shape[1]:  # only enqueued experts run
-            keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=mask.device)
-            keep[torch.tensor(enq, device=mask.device)] = True
-            mask = mask.bool() & keep
-        y, counts, hit = self.engine.dispatch_mask(layer, self._hidden, mask)
-        out, row = [], 0
-        for e in range(len(counts)):
-            if counts[e] > 0:
-                out.append((y[row:row + counts[e]], layer, e, int(hit[e])))
-                row += int(counts[e])
+        home = self._hidden.device
+        out = []
+        for slot in sorted({s for _, _, s in self._queue}):
+            eng = self.engines[slot]
+            enq = sorted({e for _, e, s in self._queue if s == slot})
+            hidden = self._hidden if self._hidden.device == eng.device else self._hidden.to(eng.device)
+            mask = self._mask if self._mask.device == eng.device else self._mask.to(eng.device)
+            if len(enq) != mask.shape[1]:  # only the experts enqueued on this engine run
+                keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=mask.device)
+                keep[torch.tensor(enq, device=mask.device)] = True
+                mask = mask.bool() & keep
+            y, counts, hit = eng.dispatch_mask(layer, hidden, mask)
+            if y.device != home:
+                y = y.to(home)
+            row = 0
+            for e in range(len(counts)):
+                if counts[e] > 0:
+                    out.append((y[row:row + counts[e]], layer, e, int(hit[e])))
+                    row += int(counts[e])
+        out.sort(key=lambda r: r[2])
         self._queue = []
         return out
 
     def clear_expert_cache_counts(self):
-        self.engine.clear_expert_cache_counts()
+        for eng in self.engines:
+            eng.clear_expert_cache_counts()
 
 
 class DistributedExpertExecutor:

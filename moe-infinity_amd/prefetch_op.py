@@ -25,10 +25,24 @@ Who owns what (as in the reference, SURVEY.md section 8b "Ownership"):
 One handle per process (the reference creates six process-wide singletons in the handle's constructor,
 archer_prefetch_handle.cpp:18-27); ``expert_dispatcher`` attaches to it.
 
+Several GPUs from ONE process (the reference's own multi-GPU form: sparse nodes are dealt round-robin over the visible
+devices, model_topology.cpp:533-536; ``dispatch_local`` passes ``gpu_id = expert_id % total_gpus``,
+moe_infinity/distributed/expert_executor.py:49-54, and ``Enqueue`` queues the expert on that GPU unless it is resident
+elsewhere, core/parallel/expert_dispatcher.cpp:135-137; inputs travel with ``tensor.to(device)`` and outputs come back
+to the hidden states' device, :284,405): the handle keeps ONE HIP engine per device of ``configure(devices=[...])``
+(default: every visible device when the process is not a torch.distributed rank, else the current device only).
+``enqueue_expert(layer, expert, gpu_id, remote)`` runs the expert on the engine of ``gpu_id`` (or where it is resident);
+``wait_expert`` issues one grouped launch per FFN stage PER DEVICE, all devices concurrently, and returns the rows on the
+hidden states' device.  ``devices=[0, 0]`` puts two engines on one GPU — how the multi-device path is tested on a
+one-GPU box.  Dense nodes stay on the handle's own device (``device_id``).  For one PROCESS per GPU with routed rows
+exchanged between ranks (RCCL / peer stores) use ``ExpertParallelMoE`` (ep.py).
+
 Additions that have no counterpart in the reference's signatures are set through ``configure()`` before the handle
 is created: ``device_memory_bytes`` (explicit expert-cache budget), ``host_memory_bytes``, ``cache_policy``,
 ``max_tokens`` (initial workspace; grows on demand) and ``top_k`` (workspace rows per token for dense masks).
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -41,7 +55,7 @@ from .offload_store import TORCH_DTYPE, OffloadStore
 _ALIGN = 4096  # kAioAlignment
 _CURRENT: Optional["prefetch_handle"] = None
 _OPTIONS = dict(device_memory_bytes=0, host_memory_bytes=0, cache_policy="lfu_incache", max_tokens=256, top_k=0, device_id=None,
-                dense_cache_fraction=0.7)
+                dense_cache_fraction=0.7, devices=None)
 
 
 def configure(**kw):
@@ -84,7 +98,18 @@ class prefetch_handle:
         self._last_node: Optional[_Node] = None
         self._last_layer = 0
         self._child_visit = None                      # set_trace / get_trace
-        self.engine: Optional[MoEEngine] = None
+        # one engine per expert device ("slot" = index into self.devices = the reference's gpu_id)
+        if _OPTIONS["devices"] is not None:
+            self.devices = [int(d) for d in _OPTIONS["devices"]]
+        elif _OPTIONS["device_id"] is None and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            self.devices = list(range(torch.cuda.device_count()))
+        else:
+            self.devices = [self.device_id]
+        if not self.devices or any(d < 0 or d >= torch.cuda.device_count() for d in self.devices):
+            raise RuntimeError(f"configure(devices={self.devices}): not visible devices (device_count {torch.cuda.device_count()})")
+        self.engines: List[Optional[MoEEngine]] = [None] * len(self.devices)
+        self._slot_of: Dict[Tuple[int, int], int] = {}    # (layer, expert) -> slot whose engine holds the expert
+        self._expert_ids: Dict[Tuple[int, int], List[int]] = {}
         self._dispatcher = None
         self._dense_bytes = 0
         self._cleaned = False
@@ -207,6 +232,23 @@ class prefetch_handle:
             raise RuntimeError(f"Tensor {tensor_id} not found in tensor id to node map") from None
 
     # ---- acquire / release (dense modules' forward hooks) --------------------------------------------------
+    # ---- the engines ---------------------------------------------------------------------------------------
+    @property
+    def engine(self) -> Optional[MoEEngine]:
+        """the first engine (single-device callers and tests)"""
+        return self.engines[0]
+
+    def _live_engines(self) -> List[MoEEngine]:
+        return [e for e in self.engines if e is not None]
+
+    def _engine_of(self, expert: Tuple[int, int]) -> Optional[MoEEngine]:
+        s = self._slot_of.get(expert)
+        return None if s is None else self.engines[s]
+
+    def _resident(self, expert: Tuple[int, int]) -> bool:
+        eng = self._engine_of(expert)
+        return eng is not None and eng.is_resident(*expert)
+
     def begin(self, request_id: int, tensor: torch.Tensor):
         """AcquireTensor (archer_prefetch_handle.cpp:83-130)"""
         tid = self._tensor_id(tensor)
@@ -215,7 +257,7 @@ class prefetch_handle:
         if not self._acquired.get(id(n)):
             self._acquired[id(n)] = set(int(t) for t in n.ids)
             n.visit += 1
-            if n.slab is not None or (n.sparse and n.expert and self.engine and self.engine.is_resident(*n.expert)):
+            if n.slab is not None or (n.sparse and n.expert and self._resident(n.expert)):
                 n.hit += 1
             n.in_use = True
             if not (n.sparse and n.expert):
@@ -250,8 +292,8 @@ class prefetch_handle:
         every id to its device at the most urgent level"""
         for tid in tensor_ids:
             n = self._node(tid)
-            if n.sparse and n.expert and self.engine is not None:
-                self.engine.prefetch(n.expert[0], [n.expert[1]], scores=[1.0])
+            if n.sparse and n.expert and self._engine_of(n.expert) is not None:
+                self._engine_of(n.expert).prefetch(n.expert[0], [n.expert[1]], scores=[1.0])
             elif not n.sparse:
                 self._to_device(n)
 
@@ -265,13 +307,16 @@ class prefetch_handle:
 
     # ---- queries -------------------------------------------------------------------------------------------
     def get_node_default_device(self, tensor_ids: Sequence[int]) -> int:
-        self._node(tensor_ids[0])
+        """sparse nodes: dealt round-robin over the expert devices in node order (model_topology.cpp:533-536)"""
+        n = self._node(tensor_ids[0])
+        if n.sparse:
+            return self.devices[(self._slot_of.get(n.expert) if n.expert in self._slot_of else n.index % len(self.devices))]
         return self.device_id
 
     def get_node_device(self, tensor_ids: Sequence[int]) -> int:
         n = self._node(tensor_ids[0])
-        if n.sparse and n.expert and self.engine is not None:
-            return self.device_id if self.engine.is_resident(*n.expert) else -1
+        if n.sparse and n.expert and self._engine_of(n.expert) is not None:
+            return self.devices[self._slot_of[n.expert]] if self._resident(n.expert) else -1
         return self.device_id if n.slab is not None else -1
 
     def is_tensor_on_device(self, tensor_or_id) -> bool:
@@ -288,10 +333,11 @@ class prefetch_handle:
         # (:179-181: never requested); io_state is reset to NODE_STATE_NONE by the getter itself (:250).  unused_count is
         # real: evictions of a speculatively fetched node nobody visited (:304) — an engine counter for experts.
         rows = np.zeros((len(self._nodes), 11), np.int64)
-        c = self.engine.expert_counters() if self.engine is not None else None
+        cs = [None if e is None else e.expert_counters() for e in self.engines]
         for i, n in enumerate(self._nodes):
             v, h, p, unused = n.visit, n.hit, n.prefetch, 0
-            if n.sparse and n.expert and c is not None:
+            c = cs[self._slot_of[n.expert]] if (n.sparse and n.expert in self._slot_of) else None
+            if c is not None:
                 v, h, _m, p = (int(x) for x in c[n.expert[0], n.expert[1], :4])
                 unused = int(c[n.expert[0], n.expert[1], 6])
             rows[i] = [v, v, 0, h, h, 0, len(n.ids), p, unused, 0, int(n.sparse)]
@@ -329,14 +375,22 @@ class prefetch_handle:
         return out
 
     def replace_cache_candidates(self, tensor_ids: Sequence[int]):
-        if self.engine is not None:
-            self.engine.protect(self._experts(tensor_ids))
+        """every engine gets the candidates it holds (an engine without any drops its protected set)"""
+        per = {s: [] for s in range(len(self.engines))}
+        for ex in self._experts(tensor_ids):
+            if ex in self._slot_of:
+                per[self._slot_of[ex]].append(ex)
+        for s, eng in enumerate(self.engines):
+            if eng is not None:
+                eng.protect(per[s])
 
     def enqueue_prefetch(self, tensor_id: int, gpu_id: int = 0):
-        if self.engine is None:
-            return
+        """EnqueuePrefetch(tensor_id, gpu_id) (archer_prefetch_handle.cpp:195-206): the reference's caller passes the node's
+        default device (memory/expert_prefetcher.py:56-59) — the device whose engine holds the expert here."""
         layer, expert = self._experts([tensor_id])[0]
-        self.engine.prefetch(layer, [expert])
+        eng = self._engine_of((layer, expert))
+        if eng is not None:
+            eng.prefetch(layer, [expert])
 
     def clean_up_resources(self):
         global _CURRENT
@@ -345,9 +399,10 @@ class prefetch_handle:
         self._flush()
         for n in self._nodes:
             n.slab = None
-        if self.engine is not None:
-            self.engine.close()
-            self.engine = None
+        for s, eng in enumerate(self.engines):
+            if eng is not None:
+                eng.close()
+                self.engines[s] = None
         self.store.close()
         self._cleaned = True
         if _CURRENT is self:
@@ -377,10 +432,12 @@ class expert_dispatcher:
         self.num_experts, self.num_layers, self.dtype, self.expert_type = int(num_experts), int(num_layers), int(dtype), int(expert_type)
         self.handle._dispatcher = self
         self._queue, self._expected, self._hidden, self._mask = [], 0, None, None
+        self._placed = set()  # (layer, expert, slot): the blob is in that engine's host arena
 
-    def _engine(self, tensor_ids: Sequence[int]) -> MoEEngine:
+    def _engine(self, slot: int, tensor_ids: Sequence[int]) -> MoEEngine:
+        """the engine of expert device ``slot`` (created on first use: the dispatcher's constructor carries no shapes)"""
         h = self.handle
-        if h.engine is None:
+        if h.engines[slot] is None:
             m = h.store.meta(int(tensor_ids[0]))  # first tensor of every expert type is [F, H]
             if m is None or len(m["shape"]) != 2:
                 raise RuntimeError(f"tensor {tensor_ids[0]} is not a [F, H] matrix in the offload index")
@@ -391,26 +448,45 @@ class expert_dispatcher:
             # (max_tokens * K rows).  Without configure(top_k=...) the engine's own limit min(8, E) is used: an upper
             # bound for every supported model (K <= 8), i.e. more workspace, never too little.
             k = {Cf.ROUTER_SWITCH: 1, Cf.ROUTER_NLLB: 2}.get(rk, _OPTIONS["top_k"] or min(8, self.num_experts))
+            # engines that share a physical device (devices=[0, 0], tests) share its budget
+            share = h.devices.count(h.devices[slot])
             cfg = Cf.EngineConfig(num_layers=self.num_layers, num_experts=self.num_experts, expert_type=self.expert_type,
-                                  hidden=hid, inter=f, top_k=k, router_kind=rk, dtype=self.dtype, device_id=h.device_id,
-                                  device_memory_ratio=h.device_memory_ratio, device_memory_bytes=int(_OPTIONS["device_memory_bytes"]),
-                                  host_memory_bytes=int(_OPTIONS["host_memory_bytes"]),
+                                  hidden=hid, inter=f, top_k=k, router_kind=rk, dtype=self.dtype, device_id=h.devices[slot],
+                                  device_memory_ratio=h.device_memory_ratio / share, device_memory_bytes=int(_OPTIONS["device_memory_bytes"]) // share,
+                                  host_memory_bytes=int(_OPTIONS["host_memory_bytes"]) // len(h.devices),
                                   policy=Cf.POLICY_LRU if _OPTIONS["cache_policy"] == "lru" else Cf.POLICY_LFU_INCACHE,
                                   max_tokens=int(_OPTIONS["max_tokens"]))
-            h.engine = MoEEngine(cfg)
-        return h.engine
+            with torch.cuda.device(h.devices[slot]):  # (the C side selects its device per call; torch's current device comes back)
+                h.engines[slot] = MoEEngine(cfg)
+        return h.engines[slot]
+
+    def _place(self, layer: int, expert: int, slot: int) -> MoEEngine:
+        """the expert's blob goes to the pinned arena of ``slot``'s engine (disk -> host), once per (expert, slot)"""
+        h = self.handle
+        ids = h._expert_ids[(layer, expert)]
+        eng = self._engine(slot, ids)
+        if (layer, expert, slot) not in self._placed:
+            h._flush()
+            with torch.cuda.device(h.devices[slot]):
+                h.store.register_expert(eng, layer, expert, ids)
+            self._placed.add((layer, expert, slot))
+        return eng
 
     def register_expert(self, layer_idx: int, expert_idx: int, tensor_ids: Sequence[int]):
-        """RegisterExpert (expert_dispatcher.cpp:160-173): every id must belong to ONE node of the topology"""
+        """RegisterExpert (expert_dispatcher.cpp:160-173): every id must belong to ONE node of the topology.  The expert is
+        placed on its default device: dealt round-robin over the expert devices (model_topology.cpp:533-536) — the same
+        device dispatch_local will name (expert_id % total_gpus, expert_executor.py:51)."""
         h = self.handle
         ids = [int(t) for t in tensor_ids]
         nodes = {id(h._node(t)) for t in ids}
         if len(nodes) != 1:
             raise RuntimeError(f"RegisterExpert: tensor_id has multiple nodes {ids}")
-        eng = self._engine(ids)
-        h._flush()
-        h.store.register_expert(eng, int(layer_idx), int(expert_idx), ids)
-        h._node(ids[0]).expert = (int(layer_idx), int(expert_idx))
+        key = (int(layer_idx), int(expert_idx))
+        h._expert_ids[key] = ids
+        slot = key[1] % len(h.devices)
+        h._slot_of[key] = slot
+        self._place(key[0], key[1], slot)
+        h._node(ids[0]).expert = key
 
     def set_inputs(self, hidden_states: torch.Tensor, router_mask: torch.Tensor):
         self._hidden = hidden_states.reshape(-1, hidden_states.shape[-1]).contiguous()
@@ -420,38 +496,80 @@ class expert_dispatcher:
         self._expected = int(expected_pending)
 
     def enqueue_expert(self, layer_idx: int, expert_idx: int, gpu_id: int = 0, remote: bool = False):
-        self._queue.append((int(layer_idx), int(expert_idx)))
+        """EnqueueExpert -> Enqueue (expert_dispatcher.cpp:108-158): the expert runs on ``gpu_id`` unless it is resident on
+        another device already (:135-137).  ``remote`` has no effect in the reference either (it is only stored)."""
+        h = self.handle
+        key = (int(layer_idx), int(expert_idx))
+        if key not in h._expert_ids:
+            raise RuntimeError(f"ExpertDispatcher::Enqueue: expert (layer {key[0]}, expert {key[1]}) was never registered")
+        gpu_id = int(gpu_id)
+        if gpu_id < 0 or gpu_id >= len(h.devices):
+            raise RuntimeError(f"enqueue_expert: gpu_id {gpu_id} out of range: this handle drives {len(h.devices)} expert device(s) "
+                               f"{h.devices} (prefetch_op.configure(devices=[...]); one process per GPU: ExpertParallelMoE, INTEGRATION.md section 6)")
+        slot = gpu_id
+        home = h._slot_of.get(key)
+        if home is not None and home != slot and h.engines[home] is not None and h.engines[home].is_resident(*key):
+            slot = home  # "if (expert_node->node->device.is_cuda()) args.gpu_id = device.index()"
+        if slot != home:
+            self._place(key[0], key[1], slot)  # a device the expert has not been on yet: its arena gets the blob now
+            h._slot_of[key] = slot
+        self._queue.append((key[0], key[1], slot))
 
     def wait_expert(self) -> List[Tuple[torch.Tensor, int, int, int]]:
-        """WaitExpert (expert_dispatcher.cpp:436-450): [(output [t_e, H], layer, expert, hit)] in ascending expert id"""
+        """WaitExpert (expert_dispatcher.cpp:436-450): [(output [t_e, H], layer, expert, hit)] in ascending expert id, every
+        output on the hidden states' device (OutputFunc, :397-434)."""
         queue, self._queue = self._queue, []
         if len(queue) != self._expected:
             raise RuntimeError(f"expected {self._expected} enqueued experts, got {len(queue)}")
         if not queue:
             return []
-        layers = {l for l, _ in queue}
+        layers = {l for l, _, _ in queue}
         if len(layers) != 1:
             raise RuntimeError("one wait_expert() serves one layer (as dispatch_local uses it)")
         layer = layers.pop()
-        eng = self.handle.engine
-        if eng is None:
+        h = self.handle
+        if not h._live_engines():
             raise RuntimeError("no expert was registered")
-        mask = self._mask
-        enq = sorted({e for _, e in queue})
-        if len(enq) != mask.shape[1]:  # only enqueued experts run
-            keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=mask.device)
-            keep[torch.tensor(enq, device=mask.device)] = True
-            mask = mask.bool() & keep
-        if self._hidden.shape[0] > eng.cfg.max_tokens:
-            eng.reserve_tokens(self._hidden.shape[0])
-        y, counts, hit = eng.dispatch_mask(layer, self._hidden, mask)
-        out, row = [], 0
-        for e in range(len(counts)):
-            if counts[e] > 0:
-                out.append((y[row:row + counts[e]], layer, e, int(hit[e])))
-                row += int(counts[e])
+        home_dev = self._hidden.device
+        by_slot: Dict[int, List[int]] = {}
+        for _, e, slot in queue:
+            by_slot.setdefault(slot, []).append(e)
+
+        def run(slot: int):
+            eng = h.engines[slot]
+            dev = torch.device("cuda", h.devices[slot])
+            with torch.cuda.device(dev):
+                hidden = self._hidden if self._hidden.device == dev else self._hidden.to(dev)   # GPUFetchFunc: input.to(node device)
+                mask = self._mask if self._mask.device == dev else self._mask.to(dev)
+                enq = sorted(set(by_slot[slot]))
+                if len(enq) != mask.shape[1]:  # only the experts enqueued on this device run here
+                    keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=dev)
+                    keep[torch.tensor(enq, device=dev)] = True
+                    mask = mask.bool() & keep
+                if hidden.shape[0] > eng.cfg.max_tokens:
+                    eng.reserve_tokens(hidden.shape[0])
+                y, counts, hit = eng.dispatch_mask(layer, hidden, mask)
+                if dev != home_dev:
+                    y = y.to(home_dev)  # OutputFunc: output.to(output_device)
+                    torch.cuda.current_stream(dev).synchronize()
+            return y, counts, hit
+
+        slots = sorted(by_slot)
+        if len(slots) == 1:
+            results = [run(slots[0])]
+        else:  # the devices work concurrently (the reference: one fetch + exec thread set per GPU); ctypes drops the GIL in the call
+            with ThreadPoolExecutor(max_workers=len(slots)) as pool:
+                results = list(pool.map(run, slots))
+        out = []
+        for y, counts, hit in results:
+            row = 0
+            for e in range(len(counts)):
+                if counts[e] > 0:
+                    out.append((y[row:row + counts[e]], layer, e, int(hit[e])))
+                    row += int(counts[e])
+        out.sort(key=lambda r: r[2])
         return out
 
     def clear_expert_cache_counts(self):
-        if self.handle.engine is not None:
-            self.handle.engine.clear_expert_cache_counts()
+        for eng in self.handle._live_engines():
+            eng.clear_expert_cache_counts()

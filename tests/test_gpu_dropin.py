@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import R, acts, assert_block_close, make_weights
+from helpers import R, acts, assert_block_close, assert_model_close, make_weights
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -23,7 +23,8 @@ class _Param:
 def _build(tmp_path, L, E, H, Fd, seed, dense_cache_fraction=0.7, **opts):
     from moe_infinity_amd import prefetch_op as P
 
-    P.configure(dense_cache_fraction=dense_cache_fraction, device_memory_bytes=opts.get("device_memory_bytes", 0), max_tokens=8)
+    P.configure(dense_cache_fraction=dense_cache_fraction, device_memory_bytes=opts.get("device_memory_bytes", 0), max_tokens=8,
+                devices=opts.get("devices"))
     handle = P.prefetch_handle(str(tmp_path), 0.5)
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(seed)
@@ -63,7 +64,23 @@ def _build(tmp_path, L, E, H, Fd, seed, dense_cache_fraction=0.7, **opts):
     return P, handle, disp, layers, params
 
 
-def _forward(handle, disp, layers, params, x, k=2):
+class _VisibleGpus:
+    """``torch.cuda.device_count()`` as dispatch_local reads it (expert_executor.py:49: total_gpus), for the duration of
+    one dispatch_local call"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self._real = torch.cuda.device_count
+        if self.n:
+            torch.cuda.device_count = lambda: self.n
+
+    def __exit__(self, *a):
+        torch.cuda.device_count = self._real
+
+
+def _forward(handle, disp, layers, params, x, k=2, total_gpus=0):
     from moe_infinity_amd.expert_executor import DistributedExpertExecutor
 
     ex = DistributedExpertExecutor(None)
@@ -87,9 +104,11 @@ def _forward(handle, disp, layers, params, x, k=2):
         sel, wts, _ = R.route_mixtral(ref_h, gw.cpu(), k)  # the block's router (oracle arithmetic: deterministic)
         handle.end(0, gw)
         router_mask, weights_mask = R.masks_from_topk(sel, wts, len(lay["experts"]))
-        res = ex.dispatch_local(h, router_mask.to(DEV), l)  # mixtral.py:87-94
+        with _VisibleGpus(total_gpus):
+            res = ex.dispatch_local(h, router_mask.to(DEV), l)  # mixtral.py:87-94
         final = torch.zeros_like(ref_h)
         for out, layer, idx, _hit in res:  # mixtral.py:96-101
+            assert out.device == h.device  # OutputFunc: results come back to the hidden states' device
             tok = router_mask[:, idx]
             final[tok, :] += out.cpu() * weights_mask[tok, idx][:, None]
         ref = R.block_mixtral(ref_h[None], lay["gate"], lay["experts"], top_k=k)
@@ -150,6 +169,62 @@ def test_dense_nodes_over_the_cache_limit_are_dropped_and_refetched(tmp_path):
     finally:
         handle.clean_up_resources()
         P.configure(dense_cache_fraction=0.7, device_memory_bytes=0)
+
+
+def test_dispatch_local_with_two_expert_devices_runs_every_expert_on_the_gpu_it_names(tmp_path):
+    """The reference's multi-GPU form: ONE process, ``total_gpus = torch.cuda.device_count()``, dispatch_local enqueues
+    expert e with ``gpu_id = e % total_gpus`` (expert_executor.py:49-54) and the dispatcher runs it THERE
+    (expert_dispatcher.cpp:135-137), rows travelling with ``.to(device)`` both ways (:284,405).  Here total_gpus = 2 over
+    ``configure(devices=[0, 0])``: two engines (own arena, slots, streams, cache policy) on the one GPU of this box."""
+    L, E, H, Fd = 2, 8, 256, 512
+    P, handle, disp, layers, params = _build(tmp_path, L, E, H, Fd, 2300, devices=[0, 0])
+    try:
+        assert handle.devices == [0, 0] and len(handle.engines) == 2 and all(e is not None for e in handle.engines)
+        x = acts(6, H, torch.bfloat16, 2301)
+        for _ in range(2):
+            _forward(handle, disp, layers, params, x, total_gpus=2)  # asserts every layer against the oracle
+        c0, c1 = handle.engines[0].expert_counters(), handle.engines[1].expert_counters()
+        assert c0[:, 0::2, 0].sum() > 0 and c1[:, 1::2, 0].sum() > 0, "both devices ran experts"
+        assert c0[:, 1::2, 0].sum() == 0 and c1[:, 0::2, 0].sum() == 0, "an expert runs on gpu_id = expert % total_gpus only"
+        hr = handle.get_hit_rate()
+        assert int(hr[hr[:, 10] == 1][:, 0].sum()) == int(c0[:, :, 0].sum() + c1[:, :, 0].sum())
+        # an expert that is RESIDENT on another device than the gpu_id named runs where it is (expert_dispatcher.cpp:135-137)
+        lay = layers[0]
+        visited = [e for e in range(1, E, 2) if c1[0, e, 0] > 0]
+        assert visited and handle.get_node_device(lay["ex_ids"][visited[0]]) == 0
+        e = visited[0]
+        hdn = acts(3, H, torch.bfloat16, 2302).to(DEV)
+        mask = torch.zeros(3, E, dtype=torch.bool, device=DEV)
+        mask[:, e] = True
+        disp.set_inputs(hdn, mask)
+        disp.set_expected_queue(1)
+        disp.enqueue_expert(0, e, 0, False)
+        (out, layer, idx, hit), = disp.wait_expert()
+        assert (layer, idx, hit) == (0, e, 1) and handle._slot_of[(0, e)] == 1
+        want = R.expert_ffn(hdn.cpu(), lay["experts"][e], R.MIXTRAL_DENSE_ACT_DENSE)
+        assert_model_close(out.cpu(), want, torch.bfloat16, "expert FFN rows on the device the expert is resident on")
+        # ... and one that is NOT resident moves to the gpu_id named: its blob enters that engine's arena, it runs there.
+        # (cache of device 1 cut to one slot, another of its experts dispatched: e is evicted)
+        other = next(o for o in range(1, E, 2) if o != e)
+        handle.engines[1].set_cache_budget(handle.engines[1].stats()["slot_bytes"])
+        mask_o = torch.zeros(3, E, dtype=torch.bool, device=DEV)
+        mask_o[:, other] = True
+        disp.set_inputs(hdn, mask_o)
+        disp.set_expected_queue(1)
+        disp.enqueue_expert(0, other, 1, False)
+        disp.wait_expert()
+        assert handle.get_node_device(lay["ex_ids"][e]) == -1
+        disp.set_inputs(hdn, mask)
+        disp.set_expected_queue(1)
+        disp.enqueue_expert(0, e, 0, False)
+        (out2, _, _, hit2), = disp.wait_expert()
+        assert handle._slot_of[(0, e)] == 0 and hit2 == 0 and torch.equal(out2.cpu(), out.cpu())
+        assert handle.engines[0].expert_counters()[0, e, 0] == 1
+        with pytest.raises(RuntimeError, match="gpu_id 2 out of range"):
+            disp.enqueue_expert(0, 0, 2, False)
+    finally:
+        handle.clean_up_resources()
+        P.configure(devices=None)
 
 
 # ---- (f)-2 with the reference's OWN caller ---------------------------------------------------------------------------
