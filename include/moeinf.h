@@ -140,6 +140,14 @@ int moeinf_abi_version(void);
 /* the row estimate moeinf_moe_forward passes to the FFN launchers when every expert of the layer is resident (sync-free path) */
 int moeinf_rows_estimate(int tokens, int top_k, int num_experts);
 int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5);
+/* The item table of the one-launch batch-1 decode layer (csrc/layer_fused.hip: a persistent grid of num_cus * wgs_per_cu
+ * workgroups, each walking its own list of work items; replaces one layer's router + dispatch_local + expert GEMMs + combine,
+ * moe_infinity/models/deepseek.py:55-136): pure host logic, exported so that tests can check it without a GPU.
+ * out[workgroup * (*list_len) + j] = role << 24 | index, 0 = end of the list; roles 1 gate (index: expert), 2 shared stage 1
+ * (16-row group), 3 meta, 4 routed stage 1 (slot * ceil(F/16) + row group), 5 shared stage 2 (16-column tile), 6 routed stage 2
+ * (slot * ceil(H/16) + column tile).  cap: int32 entries `out` holds (MOEINF_ERR_INVALID if too small). */
+int moeinf_layer1_table(int num_experts, int top_k, int hidden, int inter, int shared_inter, int elem_bytes, int gate_elem_bytes,
+                        int num_cus, int wgs_per_cu, int32_t* out, int64_t cap, int32_t* list_len);
 
 /* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------
  * (core/prefetch/archer_prefetch_handle.cpp:18-64,73-81) */
@@ -286,6 +294,7 @@ typedef struct moeinf_profile {
   int64_t ffn1_bytes, ffn2_bytes, route_bytes, combine_bytes;
   double route_ms, ffn1_ms, ffn2_ms, combine_ms;
   double host_wait_ms; /* wall-clock time the host spent blocked on the routing D2H */
+  int64_t fused_layers; /* forwards that ran as ONE launch (csrc/layer_fused.hip): all their bytes and time are under ffn1 */
 } moeinf_profile;
 int moeinf_set_profiling(moeinf_engine* eng, int enabled); /* bit 0: per-kernel events; bit 1: per-phase events of moeinf_ep_moe_forward */
 /* synchronises the last stream, returns the accumulated numbers and resets them */

@@ -53,7 +53,7 @@ class Profile(C.Structure):
         ("forwards", C.c_int64), ("ffn1_launches", C.c_int64), ("ffn2_launches", C.c_int64),
         ("ffn1_bytes", C.c_int64), ("ffn2_bytes", C.c_int64), ("route_bytes", C.c_int64), ("combine_bytes", C.c_int64),
         ("route_ms", C.c_double), ("ffn1_ms", C.c_double), ("ffn2_ms", C.c_double), ("combine_ms", C.c_double),
-        ("host_wait_ms", C.c_double),
+        ("host_wait_ms", C.c_double), ("fused_layers", C.c_int64),
     ]
 
     def as_dict(self):
@@ -79,6 +79,7 @@ PROTOTYPES = {
     "moeinf_last_error": (C.c_char_p, []),
     "moeinf_abi_version": (C.c_int, []),
     "moeinf_ffn_ring2_form": (C.c_int, [C.c_int] * 8 + [_I32P]),
+    "moeinf_layer1_table": (C.c_int, [C.c_int] * 9 + [_I32P, C.c_int64, _I32P]),
     "moeinf_rows_estimate": (C.c_int, [C.c_int] * 3),
     "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "moeinf_destroy": (C.c_int, [_P]),

@@ -292,6 +292,15 @@ struct moeinf_engine {
   // last forward
   bool last_hidden_shared = false;
   bool last_selfroute = false;      // the last forward used the self-routing FFN stage 1 (batch-1 decode)
+  bool last_layer1 = false;         // ... and ran as ONE launch (layer_fused.hip)
+  uint32_t* d_layer_ctr = nullptr;  // its counters (kernels.h LayerSync): only grow, zeroed at creation and after an error
+  uint32_t layer1_launches = 0;
+  int32_t* d_layer_tab = nullptr;   // item table of the persistent one-launch layer (built at the first launch)
+  int layer1_nwg = 0, layer1_maxi = 0;
+  bool layer1_scalar_poll = false;
+  unsigned long long* d_layer_trace = nullptr;  // MOEINF_LAYER1_TRACE=<file>: per-workgroup timestamps of the last one-launch layer, written out at destroy
+  int layer1_trace_blocks = 0;
+  int64_t layer1_timeout_ticks = 0;
   int last_T = 0, last_layer = -1;
   hipStream_t last_stream = nullptr;
   int last_rows = 0;
@@ -369,6 +378,17 @@ extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
 // at most T.  Picks the FORM of the FFN kernels only; an expert with more rows takes more passes.
 static inline int rows_estimate(int T, int K, int E) { return (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1); }
 extern "C" int moeinf_rows_estimate(int tokens, int top_k, int num_experts) { return rows_estimate(tokens, top_k, num_experts); }
+extern "C" int moeinf_layer1_table(int num_experts, int top_k, int hidden, int inter, int shared_inter, int elem_bytes, int gate_elem_bytes,
+                                   int num_cus, int wgs_per_cu, int32_t* out, int64_t cap, int32_t* list_len) {
+  if (!out || !list_len || num_experts <= 0 || top_k <= 0 || hidden <= 0 || inter <= 0 || shared_inter < 0 || num_cus <= 0 || wgs_per_cu <= 0)
+    return fail(MOEINF_ERR_INVALID, "moeinf_layer1_table: bad arguments");
+  std::vector<int32_t> tab;
+  *list_len = layer1_table(num_experts, top_k, hidden, inter, shared_inter, elem_bytes, gate_elem_bytes, num_cus, wgs_per_cu, tab);
+  if ((int64_t)tab.size() > cap) return fail(MOEINF_ERR_INVALID, "moeinf_layer1_table: out holds %lld entries, the table has %zu", (long long)cap, tab.size());
+  memcpy(out, tab.data(), tab.size() * sizeof(int32_t));
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5) {
   if (!out5 || (nmat != 1 && nmat != 2) || K <= 0 || R <= 0 || active <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_ffn_ring2_form: bad arguments");
   const bool two_bytes = dtype == MOEINF_DTYPE_BF16 || dtype == MOEINF_DTYPE_F16;
@@ -450,6 +470,18 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
   hipSetDevice(g->cfg.device_id);
   hipDeviceSynchronize();
+  if (g->d_layer_trace) {  // debugging aid: "block t0 t1 t2 t3" (100 MHz ticks) of the last one-launch layer
+    std::vector<unsigned long long> tr((size_t)g->layer1_trace_blocks * 4);
+    if (hipMemcpy(tr.data(), g->d_layer_trace, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = fopen(getenv("MOEINF_LAYER1_TRACE") ? getenv("MOEINF_LAYER1_TRACE") : "/dev/null", "w")) {
+        std::vector<int32_t> tb((size_t)g->layer1_trace_blocks, 0);
+        if (g->d_layer_tab) (void)hipMemcpy(tb.data(), g->d_layer_tab, tb.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        for (int b = 0; b < g->layer1_trace_blocks; ++b)  // "workgroup item role index t0 t1 t2 t3"
+          if (tb[b]) fprintf(f, "%d %d %d %d %llu %llu %llu %llu\n", b / g->layer1_maxi, b % g->layer1_maxi, tb[b] >> 24, tb[b] & 0xffffff, tr[b * 4], tr[b * 4 + 1], tr[b * 4 + 2], tr[b * 4 + 3]);
+        fclose(f);
+      }
+    hipFree(g->d_layer_trace);
+  }
   for (auto& n : g->nodes) { for (auto& h : n.disk_reqs) PrioAioPool::wait(h); n.disk_reqs.clear(); set_node_store(n, nullptr); }  // reads into the arena
   g->aio.reset();
   if (g->ep_comm) { std::string e; if (const RcclApi* api = RcclApi::get(&e)) api->CommDestroy(g->ep_comm); g->ep_comm = nullptr; }
@@ -465,7 +497,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_layer_ctr, g->d_layer_tab, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -552,6 +584,16 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
   TRYHIP(hipMemset(g->d_miss, 0, sizeof(int32_t)));
   TRY(dmalloc(&g->d_dec_w, 8)); TRY(dmalloc(&g->d_dec_cw, 8));
+  {
+    // the counters of the one-launch layer: uncached memory, so that the scalar unit can poll them (no cache level of this GPU
+    // keeps a line; MOEINF_LAYER1_POLL=vector: ordinary memory, agent-scope vector loads)
+    const bool scalar = !(getenv("MOEINF_LAYER1_POLL") && !strcmp(getenv("MOEINF_LAYER1_POLL"), "vector"));
+    const size_t cb = (size_t)LAYER1_CTRS * LAYER1_CTR_STRIDE * sizeof(uint32_t);
+    if (scalar && hipExtMallocWithFlags((void**)&g->d_layer_ctr, cb, hipDeviceMallocUncached) == hipSuccess) g->layer1_scalar_poll = true;
+    else { (void)hipGetLastError(); g->d_layer_ctr = nullptr; TRY(dmalloc(&g->d_layer_ctr, LAYER1_CTRS * LAYER1_CTR_STRIDE)); }
+    TRYHIP(hipMemset(g->d_layer_ctr, 0, cb));
+  }
+  g->layer1_timeout_ticks = (int64_t)(getenv("MOEINF_LAYER1_TIMEOUT_MS") ? std::max(1, atoi(getenv("MOEINF_LAYER1_TIMEOUT_MS"))) : 2000) * 100000;
   TRYHIP(hipMemset(g->d_dec_w, 0, 8 * sizeof(uint64_t))); TRYHIP(hipMemset(g->d_dec_cw, 0, 8 * sizeof(float)));
   TRYHIP(hipMemset(g->d_active, 0, (size_t)E1 * sizeof(int32_t)));  // the FFN kernels read active[u] before they know n_active
   TRYHIP(hipMemset(g->d_n_active, 0, sizeof(int32_t)));
@@ -1086,6 +1128,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
 // FFN over received rows only
 static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool local = true) {
   const int E = g->E, K = g->K;
+  const moeinf_profile p0 = g->prof;
   int64_t U = 0, rows = 0;
   for (int e = 0; e < E; ++e) { if (mirror[1 + e] > 0) { ++U; rows += mirror[1 + e]; } }
   const bool hidden = g->has_shared && local && g->last_hidden_shared;  // the shared expert ran inside the router launches
@@ -1107,6 +1150,14 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   }
   g->prof.forwards += 1;
   if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
+  if (local && g->last_layer1) {
+    // the one-launch layer: every byte of the forward moves inside the launch timed as "ffn1" (the other intervals are empty)
+    g->prof.ffn1_bytes = p0.ffn1_bytes + (g->prof.ffn1_bytes - p0.ffn1_bytes) + (g->prof.ffn2_bytes - p0.ffn2_bytes) + (g->prof.route_bytes - p0.route_bytes) +
+                         (g->prof.combine_bytes - p0.combine_bytes);
+    g->prof.ffn2_bytes = p0.ffn2_bytes; g->prof.route_bytes = p0.route_bytes; g->prof.combine_bytes = p0.combine_bytes;
+    if (mirror[0] > 0) g->prof.ffn2_launches -= 1;
+    g->prof.fused_layers += 1;
+  }
 }
 
 // ExpertPredictor.predict + ExpertPrefetcher.prefetch_experts (moe_infinity/memory/expert_predictor.py:17-35,
@@ -1360,6 +1411,8 @@ struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn
   const RouteArgs* ra;
   const IndexArgs* ia;
   const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
+  const FfnStage* sh1 = nullptr;  // layer1: its stage 1
+  bool layer1 = false;  // the whole layer as ONE launch (launch_moe_layer1): the caller has NOT launched the gate
 };
 static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
                             hipStream_t st, bool prof, moeinf_engine::ProfRec* pr, const MirrorPlan& mp,
@@ -1381,6 +1434,36 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
+    if (sr && sr->layer1) {
+      if (!fuse || !sr->sh1 || !sr->sh2) return fail(MOEINF_ERR_STATE, "internal: the one-launch layer needs the fused combine and the hidden shared expert's stages");
+      LayerSync sy;
+      sy.ctr = g->d_layer_ctr; sy.launch = ++g->layer1_launches; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
+      static const int l1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
+      sy.sleep = l1_sleep; sy.trace = nullptr; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
+      if (!g->d_layer_tab) {  // first one-launch layer of this engine: size the persistent grid to the chip, build the item table
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
+        int wpc = layer1_wgs_per_cu(sr->ra->gate_dtype);
+        if (const char* e = getenv("MOEINF_LAYER1_WPC")) wpc = std::min(wpc, std::max(1, atoi(e)));
+        if (ncu <= 0 || wpc <= 0) return fail(MOEINF_ERR_HIP, "occupancy query of the one-launch layer failed");
+        std::vector<int32_t> tab;
+        g->layer1_maxi = layer1_table(g->E, g->K, g->H, g->F, g->Fs, g->es, sr->ra->gate_dtype == DT_F32 ? 4 : 2, ncu, wpc, tab);
+        g->layer1_nwg = ncu * wpc;
+        if (hipMalloc((void**)&g->d_layer_tab, tab.size() * sizeof(int32_t)) != hipSuccess) { g->d_layer_tab = nullptr; (void)hipGetLastError(); return fail(MOEINF_ERR_OOM, "item table of the one-launch layer"); }
+        HIPCHK(hipMemcpy(g->d_layer_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      }
+      sy.tab = g->d_layer_tab; sy.maxi = g->layer1_maxi;
+      if (getenv("MOEINF_LAYER1_TRACE")) {
+        const int nb = g->layer1_nwg * g->layer1_maxi;
+        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
+        sy.trace = g->d_layer_trace;
+      }
+      FfnStage sh2c = *sr->sh2;
+      sh2c.fuse_combine = 1;  // (its y_shared rows are combined by another workgroup of the same launch)
+      HIPCHK(launch_moe_layer1(*sr->ra, *sr->ia, *sr->sh1, sh2c, s1, s2, sy, g->layer1_nwg, st));
+      if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
+      return MOEINF_OK;
+    }
     if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
     else if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
@@ -1522,12 +1605,21 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool selfroute = selfroute_env && !route_only && mp.fast && K <= 8 && E <= 64 && !g->ovr_out &&
                          ((T == 1 && (sr_gated || sr_switch)) || sr_multi);
   g->last_selfroute = selfroute;
+  // ... and with a hidden shared expert (DeepSeek) the whole layer CAN be one launch: gate, shared expert, self-routing stage 1,
+  // stage 2 and the combine as work items of one persistent grid (layer_fused.hip).  OPT-IN (MOEINF_LAYER1=1): measured in round 5
+  // it does not beat the three launches (DeepSeek-V2-Lite 1.09 vs 0.958 ms/token; DESIGN.md section 4.5 has the timelines and why).
+  static const bool layer1_env = getenv("MOEINF_LAYER1") ? atoi(getenv("MOEINF_LAYER1")) != 0 : false;
+  const bool layer1 = layer1_env && selfroute && T == 1 && sr_gated && hide_shared && g->dt == DT_BF16 && !(flags & MOEINF_FWD_NO_COMBINE) &&
+                      fuse_mode() != 0 && (getenv("MOEINF_FUSE_COMBINE") ? atoi(getenv("MOEINF_FUSE_COMBINE")) != 0 : true);
+  g->last_layer1 = layer1;
   FfnStage sh1, sh2;
   if (hide_shared) {
     hidden_shared_stages(g, layer, x_dev, sh1, sh2);
     ia.shared = 0;  // the index lists routed experts only
   }
-  if (selfroute) {
+  if (layer1) {
+    // nothing here: dispatch_experts launches the layer
+  } else if (selfroute) {
     if (hide_shared) HIPCHK(launch_gate_shared1(ra, sh1, st));
     else HIPCHK(launch_gate_logits(ra, st));
   } else if (hide_shared) {
@@ -1568,7 +1660,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK ||
                          (selfroute && sr_switch));  // (Switch: only the batch-1 stage 2 knows its combine)
   bool fused = false;
-  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr};
+  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        rows_estimate(T, K, E), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));
@@ -1704,6 +1796,12 @@ static int check_device_flag(moeinf_engine* g) {
   if (f == 0) return MOEINF_OK;
   HIPCHK(hipMemset(g->d_miss, 0, sizeof f));
   if (g->ep_err_host) *g->ep_err_host = 0;
+  if (f == 4) {  // the counters of the one-launch layer may be out of step now: start them again
+    HIPCHK(hipMemset(g->d_layer_ctr, 0, LAYER1_CTRS * LAYER1_CTR_STRIDE * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));
+    g->layer1_launches = 0;
+    return fail(MOEINF_ERR_STATE, "device error flag 4: a workgroup of the one-launch decode layer gave up waiting for another one (MOEINF_LAYER1_TIMEOUT_MS), results of the last forwards are invalid");
+  }
   if (f == 3) return fail(MOEINF_ERR_STATE, "device error flag 3: a kernel of the peer-store exchange found another rank AHEAD of this one (an earlier call failed on one side), results of the last forwards are invalid");
   if (f == 2) return fail(MOEINF_ERR_STATE, "device error flag 2: a kernel of the peer-store exchange gave up waiting for another rank's rows (MOEINF_EP_PEER_TIMEOUT_MS), results of the last forwards are invalid");
   return fail(MOEINF_ERR_STATE, "device error flag %d: an FFN workgroup found no resident blob for an active expert, results of the last forwards are invalid", f);

@@ -288,6 +288,13 @@ __device__ __forceinline__ void epi_switch(int epi, F&& f) {
 }
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// 16 bytes written by ANOTHER workgroup of this launch (write-through stores + a counter, layer_fused.hip): two 8-byte
+// agent-scope loads (a relaxed __hip_atomic_load lowers to an sc1 load up to 8 bytes; the compiler counts them like any load)
+__device__ __forceinline__ u32x4 ld16_coherent(const void* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = ld_coherent(q), b = ld_coherent(q + 1);
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
@@ -427,7 +434,9 @@ __device__ __forceinline__ void combine_cols(const CombineArgs& a, const int t, 
 // One work item of ffn_rows: 16 output rows [16*bx, 16*bx+16) of one expert (blob W, rows off..off+cnt of the
 // expert-sorted activations).  Shared by ffn_rows_kernel and by the router kernels that carry the always-resident
 // shared expert's FFN along (gate_shared1_kernel / route_shared2_kernel).
-template <typename T, int NMAT, int NW, int U, int NT>
+// COHI / COHO (layer_fused.hip): the activation rows were written / the output rows are read by OTHER workgroups of the same
+// launch — agent-scope loads, write-through stores
+template <typename T, int NMAT, int NW, int U, int NT, bool COHI = false, bool COHO = false>
 __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, const char* W, const bool sh, const int cnt, const int off,
                                               float (*red)[NMAT][256], const int xrow_fixed = -1,
                                               const int* in_rows = nullptr, const int* out_rows = nullptr, const EpPeers* pvp = nullptr,
@@ -485,7 +494,7 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
           if (NMAT == 2) bv[i] = ld16_nt(a1 + (size_t)(kb + i * NW) * 1024);
 #pragma unroll
           for (int tt = 0; tt < NT; ++tt)
-            if (tt < ntl) xv[i][tt] = ld16(xr[tt] + (size_t)(kb + i * NW) * EPT);
+            if (tt < ntl) xv[i][tt] = COHI ? ld16_coherent(xr[tt] + (size_t)(kb + i * NW) * EPT) : ld16(xr[tt] + (size_t)(kb + i * NW) * EPT);
         }
       }
 #pragma unroll
@@ -509,7 +518,7 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         if (tt < ntl) {
-          const u32x4 x0 = (KBfull * EPT + kq < K) ? ld16(xr[tt] + (size_t)KBfull * EPT) : z;
+          const u32x4 x0 = (KBfull * EPT + kq < K) ? (COHI ? ld16_coherent(xr[tt] + (size_t)KBfull * EPT) : ld16(xr[tt] + (size_t)KBfull * EPT)) : z;
           mma16<T>(acc0[tt], w0, x0);
           if (NMAT == 2) mma16<T>(acc1[tt], w1, x0);
         }
@@ -555,7 +564,7 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
             DT<T>::store_system(reinterpret_cast<T*>(ep_peer_ret_row(*pvp, drow, (int64_t)s.ld_out * sizeof(T))) + orow, v);
           } else {
             T* op = reinterpret_cast<T*>(s.out) + (size_t)drow * s.ld_out + orow;
-            if (NMAT == 1 && NT == 1 && s.fuse_combine) DT<T>::store_coherent(op, v);
+            if (COHO || (NMAT == 1 && NT == 1 && s.fuse_combine)) DT<T>::store_coherent(op, v);
             else DT<T>::store(op, v);
           }
         }
@@ -632,7 +641,7 @@ __device__ __forceinline__ void load8<float>(const float* p, float out[8]) {
   for (int j = 0; j < 4; ++j) { out[j] = __uint_as_float(a[j]); out[4 + j] = __uint_as_float(b[j]); }
 }
 
-template <typename XT, typename WT, int TT>
+template <typename XT, typename WT, int TT, bool COHO = false>  // COHO: the logits are read by other workgroups of this launch
 __device__ __forceinline__ void gate_body(const XT* __restrict__ x, const WT* __restrict__ wg, float* __restrict__ logits,
                                           int T, int H, int E, int round_bf16, double (*red)[TT], const int e, const int t0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -665,7 +674,8 @@ __device__ __forceinline__ void gate_body(const XT* __restrict__ x, const WT* __
     const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     float f = (float)v;
     if (round_bf16 == 1) f = bf2f(f2bf(f)); else if (round_bf16 == 2) f = h2f(f2h(f));  // (1: bf16, 2: fp16 — the model dtype of Mixtral's gate)
-    logits[(size_t)(t0 + tid) * E + e] = f;
+    if (COHO) st_coherent(&logits[(size_t)(t0 + tid) * E + e], f);
+    else logits[(size_t)(t0 + tid) * E + e] = f;
   }
 }
 
@@ -756,6 +766,7 @@ struct Routed {
   float val0;     // Switch: probability of the top-1 expert
 };
 
+template <bool COHL = false>  // COHL: the logits were written by other workgroups of this launch (layer_fused.hip)
 __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, const int lane, Routed& o) {
   const int E = a.E, K = a.K;
   const float* lg = a.logits + (size_t)t * E;
@@ -764,7 +775,7 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = lane + 64 * j;
-    l[j] = (e < E) ? lg[e] : -INFINITY;
+    l[j] = (e < E) ? (COHL ? ld_coherent(lg + e) : lg[e]) : -INFINITY;
     m = fmaxf(m, l[j]);
   }
   m = wave_max(m);
@@ -1145,9 +1156,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return r;
 }
 // round_p_dtype: Switch's top-1 runs on probabilities cast to the model's dtype (route_core, kind 2)
+template <bool COHL = false>
 __device__ __forceinline__ uint64_t route_set_lean(const float* __restrict__ logits, const int E, const int K, const int lane, const int round_p_dtype = 1 /*DT_F32: none*/) {
   const bool in = lane < E;
-  const float l = in ? logits[lane] : -INFINITY;
+  const float l = in ? (COHL ? ld_coherent(logits + lane) : logits[lane]) : -INFINITY;
   const float m = wave_max(l);
   float p = in ? expf(l - m) : 0.f;
   const float ssum = wave_sum(p);

@@ -231,6 +231,29 @@ hipError_t launch_ffn1_selfroute_multi(const RouteArgs& r, const IndexArgs& a, c
 // ... and its stage 2 (s2.fuse_combine set, K = s2.comb.K active experts, one token): blob pointers and combine weights
 // come from the records the self-routing launch left in s2.dec_w / s2.dec_cw
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st);
+// A whole batch-1 decode layer (gated family, hidden shared expert) in ONE launch (layer_fused.hip): gate | shared stage 1 |
+// meta | self-routing stage 1 | shared stage 2 | stage 2 + combine as workgroups of one grid; what used to be a kernel boundary
+// is a counter that only grows.  ctr: LAYER1_CTRS words, LAYER1_CTR_STRIDE apart (one cache line each), zeroed once; launch =
+// 1, 2, ... per counter set (every launch of a set must have the same shapes: the targets are launch * arrivals per launch).
+constexpr int LAYER1_CTR_STRIDE = 1024, LAYER1_CTRS = 3 + 8;  // (one 4 KB page per counter: polls of different counters land on different memory channels)
+struct LayerSync {
+  uint32_t* ctr;
+  uint32_t launch;
+  int64_t timeout_ticks;  // bound of every wait, wall_clock64 ticks (100 MHz); on expiry *err = 4 and the workgroup goes on
+  int32_t* err;
+  unsigned long long* trace;  // debugging (MOEINF_LAYER1_TRACE=<file>): [workgroup][maxi][4] wall-clock ticks (start, first wait over, second wait over, end); else nullptr
+  int sleep;                  // s_sleep(2) repetitions between two polls
+  int scalar_poll;            // 1: the counters are polled with scalar loads (they live in uncached memory); 0: agent-scope vector loads
+  const int32_t* tab;         // item table [workgroups][maxi] (layer1_table), device memory
+  int maxi;
+};
+}  // namespace moeinf
+#include <vector>
+namespace moeinf {
+int layer1_table(int E, int K, int H, int F, int Fs, int elem_bytes, int gate_bytes, int ncu, int wpc, std::vector<int32_t>& tab);
+int layer1_wgs_per_cu(int gate_dtype);
+hipError_t launch_moe_layer1(const RouteArgs& r, const IndexArgs& a, const FfnStage& sh1, const FfnStage& sh2, const FfnStage& s1, const FfnStage& s2,
+                             const LayerSync& sy, int nwg, hipStream_t st);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wait = nullptr);  // wait: poll these flags first (peer-store exchange)
 // out[i] = valid[i] ? idx[i] : -1
