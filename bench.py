@@ -83,7 +83,7 @@ def fill_experts(eng, cfg, rank, world, dev, seed=1234):
     g = torch.Generator(device=dev)
     off, siz, tot = eng.expert_layout(0)
     dt = eng.dtype
-    es = 2 if dt == torch.bfloat16 else 4
+    es = 4 if dt == torch.float32 else 2
     t0 = time.time()
     n = 0
     for l in range(cfg.num_layers):
@@ -118,7 +118,7 @@ def host_expert_tensors(eng, cfg, layer, expert, owned=True, dev=None):
     if owned:
         raw = eng.expert_host_view(layer, expert)
     else:
-        es = 2 if eng.dtype == torch.bfloat16 else 4
+        es = 4 if eng.dtype == torch.float32 else 2
         raw = expert_blob(torch.Generator(device=dev), layer, expert, tot // es, eng.dtype, dev).cpu().view(torch.uint8)
     H, F = cfg.hidden, cfg.inter
     from moe_infinity_amd import config as Cf
@@ -155,16 +155,67 @@ def latest_pmc_traffic(workload_key, kernel_substr):
     return None, None
 
 
-def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, dist):
-    """One workload end to end.  main=True: every leg; main=False (other_configs): timing + roofline + parity."""
+def measure_traffic_live(workload, kernel_substr, timeout_s=170):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under rocprofv3 --pmc
+    (FETCH_SIZE, then WRITE_SIZE — separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes; gfx950 correction of that guide: FETCH_SIZE reports half of a wide streaming read -> x2; unit KiB), 8 layers x
+    3 decode steps of the same workload.  Returns (bytes or None, note)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return None, "rocprofv3 not found"
+    vals = {}
+    cmd_tail = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+                "--miss-heavy-frac", "0", "--windows", "1", "--layers", "8", "--prompt", "0", "--no-traffic"]
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="moeinf_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "m", "--"] + cmd_tail,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            path = None
+            for root, _dirs, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        path = os.path.join(root, fn)
+            if path is None:
+                return None, f"rocprofv3 --pmc {ctr}: no counter file (rc {r.returncode}): {r.stderr[-300:]}"
+            acc = []
+            for row in csv.DictReader(open(path)):
+                if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name", ctr) == ctr:
+                    acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, f"rocprofv3 --pmc {ctr}: no launch of {kernel_substr} in the counter file"
+            vals[ctr] = (sum(acc) / len(acc), len(acc))
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {ctr}: timed out after {timeout_s}s"
+        except Exception as ex:  # noqa: BLE001
+            return None, f"rocprofv3 --pmc {ctr}: {ex!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = vals["FETCH_SIZE"][0] * 1024 * 2.0
+    write = vals["WRITE_SIZE"][0] * 1024
+    return int(fetch + write), (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over 8 layers x 4 decode steps of "
+                                f"this workload, mean of {vals['FETCH_SIZE'][1]} launches; FETCH_SIZE x2 (gfx950 correction), KiB units")
+
+
+def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, dist, dtype_id=None, sample=None):
+    """One workload end to end.  main=True: every leg; main=False (other_configs): timing + roofline + parity.
+    dtype_id: expert dtype override (config.DTYPE_F16: the fp16 legs); sample = (layers, steps) of the CPU / parity sample."""
     from moe_infinity_amd import MoEEngine
     from moe_infinity_amd import config as Cf
     from moe_infinity_amd.ep import ExpertParallelMoE, HipEpOps
 
     factory, family, label = WORKLOADS[workload]
     steps, warmup = args.steps, args.warmup
+    selfroute = False
     prompt = args.prompt if main else 0
-    cfg = getattr(Cf, factory)(device_id=local_rank, device_memory_ratio=args.ratio,
+    kw_dt = {} if dtype_id is None else {"dtype": dtype_id}
+    cfg = getattr(Cf, factory)(**kw_dt, device_id=local_rank, device_memory_ratio=args.ratio,
                                device_memory_bytes=int(args.budget_gib * 2**30) if main else 0,
                                policy=Cf.POLICY_LRU if args.policy == "lru" else Cf.POLICY_LFU_INCACHE,
                                ep_rank=rank, ep_size=world, max_tokens=max(B * world, B * prompt if world == 1 else 0))
@@ -466,6 +517,8 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         full = not use_ep  # (round 4: the other_configs legs check EVERY layer too — DeepSeek-V2-Lite 78 pairs, NLLB / Switch 36)
         n_ls = args.cpu_sample_layers if args.cpu_sample_layers > 0 else (L if full else 4)
         n_ss = args.cpu_sample_steps if args.cpu_sample_steps > 0 else (5 if (full and main) else 3)
+        if sample is not None:
+            n_ls, n_ss = sample
         ls = list(range(min(n_ls, L)))
         ss = list(range(warmup, warmup + min(n_ss, steps)))
 
@@ -518,6 +571,41 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                              f"({layer_steps} MoE-layer passes, {cpu_s:.1f}s)" + ("" if len(ls) == L else f", extrapolated x{L}/{len(ls)} layers") + "; "
                              f"torch CPU ops, {best_nt} threads (best of the sweep)"
                              + (f"; rank 0 of {world} (one rank's batch, all {E} experts)" if use_ep else "")}
+            # ... and the REFERENCE'S OWN expert FFN beside the restatement: core/parallel/expert_module.cpp compiled from
+            # /root/reference by oracle/build_ref.py (oracle/_ref/libmoeinf_ref.so travels with the snapshot) — the same sample,
+            # the same thread count, router and combine from the restatement (the reference has them in Python only)
+            try:  # (still the cpu_baseline leg: checker code only)
+                from oracle import ref_lib
+
+                if ref_lib.available():
+                    et = {"mixtral": R.MIXTRAL_DENSE_ACT_DENSE, "deepseek": R.DEEPSEEK_DENSE_ACT_DENSE, "nllb": R.NLLB_DENSE_ACT_DENSE,
+                          "switch": R.SWITCH_DENSE_ACT_DENSE}[family]
+                    port_ffn = R.expert_ffn
+                    same = True
+
+                    def ref_ffn(x, tensors, expert_type):
+                        return ref_lib.expert_ffn(x, tensors, expert_type)
+
+                    R.expert_ffn = ref_ffn
+                    try:
+                        oracle_layer(ls[0], x0)  # (first call: library load)
+                        t0 = time.perf_counter()
+                        for s in ss:
+                            for l in ls:
+                                rr = oracle_layer(l, xs[s][l].cpu())
+                                same &= bool(torch.equal(rr.out, refs[(s, l)].out))
+                        ref_s = time.perf_counter() - t0
+                    finally:
+                        R.expert_ffn = port_ffn
+                    ref_ms = ref_s * 1e3 / layer_steps * L / B
+                    cpu["reference_compiled"] = {"value": round(1e3 / ref_ms, 4), "unit": "tokens/s", "cores": best_nt, "kind": "reference-compiled",
+                                                 "ms_per_token": round(ref_ms, 2), "same_sample": True,
+                                                 "bit_identical_to_the_restatement": same,
+                                                 "what": "expert FFN = <reference module>.forward of core/parallel/expert_module.cpp"
+                                                         f" (expert type {et}) compiled from the reference's source (oracle/_ref, oracle/build_ref.py); router, dispatch "
+                                                         "and combine = the restatement of the reference's Python blocks (oracle/moe_ref.py)"}
+            except Exception as ex:  # noqa: BLE001 — a missing checker library must not take the measured line down
+                cpu["reference_compiled"] = {"error": repr(ex)}
         if world > 1:
             dist.barrier()  # rank 0 timed the oracle alone on the host cores; now the other ranks compute theirs
             if rank != 0:
@@ -572,7 +660,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                                      "exact": "the block in fp32 (fp64 for an fp32 model) on up-cast weights with the oracle's routing: nothing rounded to the model dtype after the router"},
                   "max_abs_err": float(f"{max_abs:.3e}"), "max_rel_err": float(f"{max_rel:.3e}"), "mean_rel_err": float(f"{mean_rel:.3e}"),
                   "tolerance": ("routing indices bit-exact; block output per element |err| <= ulp*(2*sum_k|w_k*y_k| + max(|ref|, mean|ref|)), "
-                                f"ulp = {'2^-7 (bf16)' if dt == torch.bfloat16 else '2e-5 (fp32)'}, AND mean relative error <= 1e-3 (north_star's 1e-3); "
+                                f"ulp = {'2^-7 (bf16)' if dt == torch.bfloat16 else ('2^-10 (fp16)' if dt == torch.float16 else '2e-5 (fp32)')}, AND mean relative error <= 1e-3 (north_star's 1e-3); "
                                 "max_rel_err = max |err| / max(|ref|, mean|ref|): one bf16 rounding flip is 3.9e-3 relative, so the elementwise "
                                 "figure sits at a few bf16 ulps by construction while mean_rel_err is the quantity held to 1e-3"),
                   "bar": "oracle/parity.py block_report (= tests/helpers.py assert_block_close)", "pairs_checked": len(refs),
@@ -581,40 +669,123 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
         if family == "nllb":
             parity["elements_on_the_eq0_passthrough_discontinuity"] = amb
 
-    # ---- miss-heavy leg (BASELINE config 3): same engine, expert cache cut to a byte budget
+    # ---- offload regime (BASELINE configs 2 and 3): the same engine with the expert cache cut to a byte budget.
+    # One sub-leg = (routing, replacement policy, attention stand-in, speculation): cache flushed, two settling steps, counters
+    # reset, `msteps` decode steps timed.  Routing "natural" = what the random gate produces (uniform over experts: the hit
+    # rate is the capacity fraction whatever the policy); "zipf1.2" = SURVEY.md section 8d's skew: every layer ranks its experts
+    # (fixed seed) and adds -1.2 ln(rank) to their logits (coordinate 0 of every activation is a constant 4, the gate's column
+    # 0 carries the bias / 4), so a few experts per layer are hot — where LFU-in-cache and LRU can differ.
     miss = None
-    if main and rank == 0 and world == 1 and not use_ep and args.miss_heavy_frac > 0 and not args.budget_gib:
+    offload_frac = args.miss_heavy_frac if main else (args.offload_frac_other if family == "deepseek" else 0.0)
+    if rank == 0 and world == 1 and not use_ep and offload_frac > 0 and not args.budget_gib:
+        import numpy as np
+
         slot = st["slot_bytes"]
-        budget = int(args.miss_heavy_frac * L * E * slot)
-        eng.set_cache_budget(budget)
+        budget = int(offload_frac * L * E * slot)
         msteps = max(5, min(steps, args.miss_heavy_steps))
-        run_steps(0, min(3, nsteps))  # settle the smaller cache
-        eng.sync_copies()
-        torch.cuda.synchronize(dev)
-        eng.clear_expert_cache_counts()
-        eng.reset_stats()
-        t0 = time.perf_counter()
-        for s in range(msteps):
-            for l in range(L):
-                layer_fwd(l, xs[warmup + (s % steps)][l])
-        torch.cuda.synchronize(dev)
-        mel = time.perf_counter() - t0
-        eng.sync_copies()
-        ms_ = eng.stats()
-        misses = ms_["expert_misses"]
-        link = ms_["h2d_bytes"] / ms_["h2d_busy_ms"] / 1e6 if ms_["h2d_busy_ms"] > 0 else None
+        rng = np.random.default_rng(7)
+        gates_z = []
+        for l in range(L):
+            gz = gates[l].clone()
+            gz[:, 0] = torch.from_numpy(-1.2 * np.log(rng.permutation(E) + 1.0) / 4.0).to(gz.dtype).to(dev)
+            gates_z.append(gz)
+
+        def x_zipf(s, l):
+            x = xs[warmup + (s % steps)][l].clone()
+            x[:, 0] = 4.0
+            return x
+
+        # attention stand-in (the MoE layers of a real model sit between attention blocks: profiles/r04_attention_block_time_*,
+        # tools/attn_time.py): a bf16 matmul on the compute stream, repeated to the measured time
+        attn_us = 0.0 if main else args.offload_attn_us
+        reps, one_us = 0, 0.0
+        if attn_us > 0:
+            ma = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+            mb = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+            for _ in range(5):
+                ma @ mb
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ma @ mb
+            torch.cuda.synchronize(dev)
+            one_us = (time.perf_counter() - t0) / 50 * 1e6
+            reps = max(1, int(round(attn_us / one_us)))
+
+        def offload_leg(routing, policy, with_attn, speculate, nsteps_leg):
+            zipf = routing != "natural"
+            gl = gates_z if zipf else gates
+            eng.set_cache_policy(Cf.POLICY_LRU if policy == "lru" else Cf.POLICY_LFU_INCACHE)
+            eng.set_cache_budget(slot)      # flush: one slot ...
+            eng.set_cache_budget(budget)    # ... and back to the budget of this leg
+            native, nseq = None, -1
+            if speculate:
+                # the engine-side predictor (moeinf_set_predictor; reference: memory/expert_tracer.py + expert_predictor.py +
+                # expert_prefetcher.py): history = activation matrices of 8 earlier sequences under the same routing
+                from moe_infinity_amd.engine import FWD_ROUTE_ONLY, ExpertTracerNative
+
+                hist = np.zeros((8, L, E), np.float32)
+                for sq in range(8):
+                    for s in range(8):
+                        for l in range(L):
+                            eng.forward(l, x_zipf(sq * 8 + s, l) if zipf else xs[(sq * 8 + s) % nsteps][l], gl[l], batch_rows=batch_rows, flags=FWD_ROUTE_ONLY)
+                            for i in eng.routing()["topk_idx"].reshape(-1):
+                                if i >= 0:
+                                    hist[sq, l, i] += 1
+                native = ExpertTracerNative(L, E, 8)
+                native.load_trace(hist)
+                nseq = native.create_entry()
+                eng.set_predictor(native, nseq, lookahead_layers=2)
+                eng.set_prefetch_governor(0.5, 16)
+
+            def steps_(s0, n):
+                for s in range(s0, s0 + n):
+                    for l in range(L):
+                        if with_attn:
+                            for _ in range(reps):
+                                ma @ mb
+                        eng.forward(l, x_zipf(s, l) if zipf else xs[warmup + (s % steps)][l], gl[l], batch_rows=batch_rows, out=out)
+
+            steps_(0, 2)  # settle the cache
+            eng.sync_copies()
+            torch.cuda.synchronize(dev)
+            eng.clear_expert_cache_counts()
+            eng.reset_stats()
+            t0 = time.perf_counter()
+            steps_(2, nsteps_leg)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            eng.sync_copies()
+            s_ = eng.stats()
+            if speculate:
+                eng.set_predictor(None)
+                native.finish_entry(nseq)
+                eng.set_prefetch_governor(0.0, 16)
+            mis = s_["expert_misses"]
+            link = s_["h2d_bytes"] / s_["h2d_busy_ms"] / 1e6 if s_["h2d_busy_ms"] > 0 else None
+            attn_ms = L * reps * one_us / 1e3 if with_attn else 0.0
+            return {"routing": routing, "policy": policy, "speculation": "engine predictor, lookahead 2, governor 0.5" if speculate else "none (on-demand fetches only)",
+                    "attention_standin_us_per_layer": round(reps * one_us, 1) if with_attn else 0.0,
+                    "steps": nsteps_leg, "ms_per_token": round(el * 1e3 / nsteps_leg / B, 3),
+                    "moe_ms_per_token_without_the_standin": round(el * 1e3 / nsteps_leg / B - attn_ms / B, 3),
+                    "hit_rate": round(s_["expert_hits"] / max(1, s_["expert_hits"] + mis), 4), "misses_per_token": round(mis / nsteps_leg / B, 2),
+                    "prefetch_issued": s_["prefetch_issued"], "prefetch_useful": s_["prefetch_useful"],
+                    "h2d_GiB": round(s_["h2d_bytes"] / 2**30, 2), "h2d_link_busy_ms": round(s_["h2d_busy_ms"], 1),
+                    "h2d_GBps": None if link is None else round(link, 2),
+                    "h2d_frac_of_pcie5_x16": None if link is None else round(link / PCIE_GBS, 3),
+                    "h2d_frac_of_hbm_peak": None if link is None else round(link / HBM_PEAK_GBS, 4),
+                    "exposed_wait_ms": round(s_["exposed_wait_ms"], 1),
+                    "overlap": None if s_["h2d_busy_ms"] <= 0 else round(max(0.0, 1.0 - s_["exposed_wait_ms"] / s_["h2d_busy_ms"]), 4),
+                    "_raw": (el, s_, mis, link)}
+
+        eng.set_cache_budget(budget)
+        base = offload_leg("natural", args.policy, False, False, msteps)
+        mel, ms_, misses, link = base.pop("_raw")
         bound_ms = misses * slot / (56.0e9) * 1e3 / msteps  # every miss crosses the link once at the measured 56 GB/s
-        miss = {"what": f"{label}, expert cache = {args.miss_heavy_frac:.0%} of the expert bytes ({budget / 2**30:.1f} GiB, "
-                        f"{ms_['slots_total']} of {L * E} experts), on-demand fetches only",
-                "steps": msteps, "ms_per_token": round(mel * 1e3 / msteps / B, 3), "tokens_per_s": round(B * msteps / mel, 3),
-                "hit_rate": round(ms_["expert_hits"] / max(1, ms_["expert_hits"] + misses), 4),
-                "misses_per_token": round(misses / msteps / B, 2),
-                "h2d_GiB": round(ms_["h2d_bytes"] / 2**30, 2), "h2d_link_busy_ms": round(ms_["h2d_busy_ms"], 1),
-                "h2d_GBps": None if link is None else round(link, 2),
-                "h2d_frac_of_pcie5_x16": None if link is None else round(link / PCIE_GBS, 3),
-                "h2d_frac_of_hbm_peak": None if link is None else round(link / HBM_PEAK_GBS, 4),
-                "exposed_wait_ms": round(ms_["exposed_wait_ms"], 1),
-                "overlap": None if ms_["h2d_busy_ms"] <= 0 else round(max(0.0, 1.0 - ms_["exposed_wait_ms"] / ms_["h2d_busy_ms"]), 4),
+        miss = {"what": f"{label}, expert cache = {offload_frac:.0%} of the expert bytes ({budget / 2**30:.1f} GiB, "
+                        f"{ms_['slots_total']} of {L * E} experts), on-demand fetches only, natural routing, {args.policy}",
+                **{k: v for k, v in base.items() if k not in ("routing", "policy", "speculation", "attention_standin_us_per_layer", "moe_ms_per_token_without_the_standin")},
+                "tokens_per_s": round(B * msteps / mel, 3),
                 "pcie_bound_ms_per_token": round(bound_ms / B, 3),
                 "ms_per_token_over_pcie_bound": round(mel * 1e3 / msteps / max(bound_ms, 1e-9), 3),
                 # why `overlap` is what it is: one miss is `copy_ms_per_miss` of link time, the compute stream has
@@ -625,12 +796,28 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 "overlap_ceiling_on_demand": None if link is None else round(min(1.0, (ms_per_step / L) / max(1e-9, (misses / msteps / L) * slot / (link * 1e9) * 1e3)), 4),
                 "physics": "on-demand: a miss is issued when its layer routes and the layer's FFN needs it at once, so at most "
                            "compute_ms_per_layer of every (misses_per_layer x copy_ms_per_miss) can overlap (overlap_ceiling_on_demand); "
-                           "hiding more needs copies issued LAYERS ahead (speculation, see the prefetch leg / profiles/r03_prefetch_study_*)"}
+                           "hiding more needs copies issued LAYERS ahead (speculation: the sub-legs below / profiles/r04_prefetch_study_*)"}
+        # the matrix SURVEY.md section 8d asks for: routing x replacement policy, same engine, same budget, same steps
+        zsteps = max(msteps, args.offload_zipf_steps)
+        legs = []
+        for routing, policy in (("natural", "lru"), ("zipf1.2", "lfu_incache"), ("zipf1.2", "lru")):
+            lg = offload_leg(routing, policy, False, False, zsteps if routing != "natural" else msteps)
+            lg.pop("_raw")
+            legs.append(lg)
+        first = dict(base)
+        legs.insert(0, first)
+        if attn_us > 0:  # BASELINE config 2: "prefetch stream overlap" with real attention time between the MoE layers
+            for speculate in (False, True):
+                lg = offload_leg("zipf1.2", "lfu_incache", True, speculate, zsteps)
+                lg.pop("_raw")
+                legs.append(lg)
+        miss["sub_legs"] = legs
+        eng.set_cache_policy(Cf.POLICY_LRU if args.policy == "lru" else Cf.POLICY_LFU_INCACHE)
 
     res = {"label": label, "family": family, "cfg": cfg, "L": L, "E": E, "K": K, "H": H, "B": B, "dt": dt,
            "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
            "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prefill_kernels": prefill_kernels, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
-           "warm": warm, "st": st, "ep_phases": ep_phases,
+           "warm": warm, "st": st, "ep_phases": ep_phases, "selfroute": selfroute,
            "ep_transport": None if ep is None else {
                "chosen": ep.transport,
                "what": {"peer-store": "rows stored straight into the owners' / home ranks' windows by the router and FFN kernels, flag words instead of a collective; one host call per layer (moeinf_ep_moe_forward)",
@@ -690,7 +877,12 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=0, help="decode steps of that sample (0: 5 for the main workload, 3 for other_configs)")
     ap.add_argument("--miss-heavy-frac", type=float, default=0.5, help="miss_heavy leg: cache budget as a fraction of the expert bytes (0 = skip)")
     ap.add_argument("--miss-heavy-steps", type=int, default=6)
+    ap.add_argument("--offload-zipf-steps", type=int, default=16, help="decode steps of the Zipf-routing sub-legs of the offload regime (cache locality needs more steps to show)")
+    ap.add_argument("--offload-frac-other", type=float, default=0.5, help="other_configs: DeepSeek-V2-Lite's offload-regime leg, cache budget as a fraction of the expert bytes (0 = skip)")
+    ap.add_argument("--offload-attn-us", type=float, default=270.1, help="that leg's attention stand-in per layer (profiles/r04_attention_block_time_stock_pytorch.jsonl: DeepSeek-V2-Lite batch 1, context 2048)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
+    ap.add_argument("--no-fp16-legs", action="store_true", help="skip the fp16-expert legs of other_configs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic pass (two rocprofv3 --pmc child runs, ~1 min): roofline.traffic then comes from profiles/ (static)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -729,6 +921,22 @@ def main():
         dist.barrier()
 
     r = run_workload(args, args.workload, args.batch, world, rank, local_rank, dev, use_ep, True, dist)
+    # roofline.traffic measured in THIS run (the main engine is closed: its HBM and pinned memory are free for the children)
+    if rank == 0 and world == 1 and not use_ep and not args.no_traffic and r.get("roof"):
+        t0 = time.time()
+        sub = "ffn1_selfroute_kernel" if r.get("selfroute") else "ffn_rows_kernel"
+        tb, note = measure_traffic_live(args.workload, sub)
+        log(f"live traffic pass: {tb} bytes per launch of {sub} ({note}) in {time.time() - t0:.0f}s")
+        if tb is not None:
+            alg = r["roof"]["bytes_per_launch"]
+            r["roof"]["traffic"] = tb
+            r["roof"]["traffic_source"] = note
+            r["roof"]["traffic_over_algorithmic"] = round(tb / alg, 4)
+            r["roof"]["traffic_ok"] = bool(tb <= 1.05 * alg)  # more than 5 % over the algorithmic bytes = wasted re-reads: the leg FAILS (reported, exit code stays 0)
+            if not r["roof"]["traffic_ok"]:
+                print(f"[bench] TRAFFIC LEG FAILED: {tb} HBM bytes per launch against {alg} algorithmic (x{tb / alg:.3f} > 1.05)", file=sys.stderr)
+        else:
+            r["roof"]["traffic_live_attempt"] = note
     others = []
     default_main = (args.workload == "mixtral-8x7b" and args.batch == 1 and not args.layers and not args.budget_gib)
     if world == 1 and not use_ep and default_main and not args.no_other_configs:
@@ -748,10 +956,33 @@ def main():
                                "algorithmic_GB_per_step": None if not (k1 and k2) else round(step_bytes / 1e9, 3),
                                "frac_of_hbm_peak_whole_step": None if not (k1 and k2) else round(step_bytes / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "ffn_stage1": k1, "ffn_stage2": k2, "route": o["kernels"].get("route(gate+topk+index)"),
-                               "parity": o["parity"], "cpu_baseline": o["cpu"]})
+                               "parity": o["parity"], "cpu_baseline": o["cpu"],
+                               # BASELINE config 2 (DeepSeek-V2-Lite: "prefetch stream overlap"): cache = half of the expert bytes,
+                               # Zipf routing, the measured attention time between the MoE layers, with and without speculation
+                               "offload_regime": o.get("miss")})
             except Exception as ex:  # an extra leg must not take the measured line down
                 log(f"other_configs leg {wl} failed: {ex!r}")
                 others.append({"workload": wl, "error": repr(ex)})
+        # fp16 experts (the reference's dtype id 2, core/parallel/expert_module.h:20-23): the dtype north_star's tolerance is
+        # stated for ("within 1e-3 fp16").  The three bf16 families again with fp16 weights and activations, short legs:
+        # timing + full-size parity on a small sample, max / mean relative error next to the literal 1e-3.
+        if not args.no_fp16_legs and not args.no_cpu_baseline:
+            from moe_infinity_amd import config as Cf
+
+            for wl, b in (("mixtral-8x7b", 1), ("deepseek-v2-lite", 1), ("nllb-moe-54b", 32)):
+                try:
+                    o = run_workload(args, wl, b, world, rank, local_rank, dev, False, False, dist, dtype_id=Cf.DTYPE_F16, sample=(2, 2))
+                    pr = o["parity"] or {}
+                    others.append({"workload": f"{o['label']} MoE layers with fp16 experts (dtype id 2): L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}, decode batch {b}",
+                                   "dtype": "fp16", "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2), "windows_ms": o["windows_ms"],
+                                   "north_star_tolerance": "within 1e-3 fp16",
+                                   "mean_rel_err": pr.get("mean_rel_err"), "max_rel_err": pr.get("max_rel_err"),
+                                   "mean_rel_err_within_1e-3": None if pr.get("mean_rel_err") is None else bool(pr["mean_rel_err"] <= 1e-3),
+                                   "max_rel_err_within_1e-3": None if pr.get("max_rel_err") is None else bool(pr["max_rel_err"] <= 1e-3),
+                                   "parity": pr})
+                except Exception as ex:  # noqa: BLE001
+                    log(f"fp16 leg {wl} failed: {ex!r}")
+                    others.append({"workload": wl + " fp16", "error": repr(ex)})
 
     parity_ok = True
     if rank == 0:
@@ -762,7 +993,7 @@ def main():
             "metric": f"decode tokens/s through all MoE layers (expert-offload hot path), {label}, device_memory_ratio={args.ratio}",
             "value": round(r["tokens_per_s"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if r["dt"] == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": "bf16" if r["dt"] == torch.bfloat16 else ("f16" if r["dt"] == torch.float16 else "f32"), "data": "synthetic",
             "config": {"workload": f"{label} MoE layers: L={L} E={E} K={K} H={H} F={cfg.inter}"
                                    + (f" +shared F={cfg.shared_inter}" if cfg.shared_inter else "")
                                    + f", decode batch {B}/rank, device_memory_ratio={args.ratio}"

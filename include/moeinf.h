@@ -264,6 +264,10 @@ int moeinf_sync_copies(moeinf_engine* eng);
 /* DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink (evicting by
  * the replacement policy, freeing the slots' memory) or grow the expert cache.  Synchronises the device. */
 int moeinf_set_cache_budget(moeinf_engine* eng, int64_t device_memory_bytes);
+/* The replacement policy (MOEINF_POLICY_*) at run time: which resident expert the next miss evicts — the reference's
+ * LFU over in-cache visit counts (core/parallel/expert_dispatcher.cpp:227-266, core/prefetch/task_scheduler.cpp:236-317) or
+ * LRU.  Takes effect with the next eviction; nothing is evicted by the call (bench.py compares the two on ONE warm engine). */
+int moeinf_set_cache_policy(moeinf_engine* eng, int policy);
 /* Speculation governor (no counterpart in the reference, whose prefetcher enqueues everything it predicts).  The engine
  * keeps a running average of how speculative copies END — dispatched before eviction (1) or evicted unused (0); once 8
  * have ended and the average is below min_useful_fraction, speculative requests are dropped except one probe in

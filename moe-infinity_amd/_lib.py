@@ -79,6 +79,7 @@ PROTOTYPES = {
     "moeinf_last_error": (C.c_char_p, []),
     "moeinf_abi_version": (C.c_int, []),
     "moeinf_ffn_ring2_form": (C.c_int, [C.c_int] * 8 + [_I32P]),
+    "moeinf_set_cache_policy": (C.c_int, [_P, C.c_int]),
     "moeinf_layer1_table": (C.c_int, [C.c_int] * 9 + [_I32P, C.c_int64, _I32P]),
     "moeinf_rows_estimate": (C.c_int, [C.c_int] * 3),
     "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),

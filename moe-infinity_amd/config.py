@@ -87,11 +87,11 @@ def mixtral_8x7b(dtype=DTYPE_BF16, **kw):
                         router_kind=ROUTER_MIXTRAL, dtype=dtype, **kw)
 
 
-def deepseek_v2_lite(**kw):
-    """DeepSeek-V2-Lite: H=2048 F=1408 E=64 K=6, 26 MoE layers, 2 shared experts (F=2816), bf16, greedy,
-    norm_topk_prob=False, routed_scaling_factor=1.0."""
+def deepseek_v2_lite(dtype=DTYPE_BF16, **kw):
+    """DeepSeek-V2-Lite: H=2048 F=1408 E=64 K=6, 26 MoE layers, 2 shared experts (F=2816), bf16 (dtype=DTYPE_F16: fp16
+    experts), greedy, norm_topk_prob=False, routed_scaling_factor=1.0."""
     return EngineConfig(num_layers=26, num_experts=64, expert_type=EXPERT_DEEPSEEK, hidden=2048, inter=1408, top_k=6,
-                        router_kind=ROUTER_DEEPSEEK, dtype=DTYPE_BF16, shared_inter=2816, **kw)
+                        router_kind=ROUTER_DEEPSEEK, dtype=dtype, shared_inter=2816, **kw)
 
 
 def switch_base_8(**kw):

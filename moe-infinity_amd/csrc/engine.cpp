@@ -2059,6 +2059,13 @@ extern "C" int moeinf_set_prefetch_governor(moeinf_engine* g, float min_useful_f
 // DeviceMemoryPool::SetMemoryRatio (core/memory/memory_pool.cpp:150-158) at run time, in bytes: shrink or grow the
 // expert cache.  Shrinking evicts by the replacement policy until the resident set fits and returns the freed slots'
 // memory to the device; the host copies are authoritative, nothing is written back.
+extern "C" int moeinf_set_cache_policy(moeinf_engine* g, int policy) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (policy != MOEINF_POLICY_LFU_INCACHE && policy != MOEINF_POLICY_LRU) return fail(MOEINF_ERR_INVALID, "policy must be MOEINF_POLICY_LFU_INCACHE or MOEINF_POLICY_LRU");
+  g->cfg.policy = policy;
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_bytes) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (device_memory_bytes < g->slot_bytes) return fail(MOEINF_ERR_OOM, "budget %lld bytes cannot hold one expert of %lld bytes", (long long)device_memory_bytes, (long long)g->slot_bytes);

@@ -105,11 +105,10 @@ static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_
 #define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
   if (many_tokens) {  // grouped GEMM kernels (ffn_gemm.hip); MOEINF_FFN_GEMM=0: the decode kernel looping 4 token tiles
     if constexpr (sizeof(T) == 2 && !std::is_same<T, uint16_t>::value) {
-      // fp16 experts: of the GEMM kernels the register ring (long reductions, up to 340 rows per expert) and the 256 x 256 one
-      // are built for the f16 matrix instruction; the latter takes over from 65 rows per expert elsewhere (below that the
-      // decode kernel looping token tiles re-streams the weights at most 4 times)
+      // fp16 experts: the register ring first (long reductions, up to 340 rows per expert; its own translation unit), then
+      // the same choice between the hybrid / LDS-staged / 256 x 256 kernels as bf16 (ffn_gemm_f16.hip, round 5)
       if (launch_ffn_gemm_ring2_f16(s, NMAT, grid, max_rows, st)) return;
-      if (max_rows > 64 && launch_ffn_gemm_big(s, NMAT, grid, max_rows, st)) return;
+      if (launch_ffn_gemm<T, NMAT>(s, grid, max_rows, st)) return;
     } else {
       if (launch_ffn_gemm<T, NMAT>(s, grid, max_rows, st)) return;
     }

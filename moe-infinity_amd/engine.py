@@ -260,6 +260,11 @@ class MoEEngine:
         """SetMemoryRatio at run time, in bytes (shrinking evicts by policy and frees the slots)."""
         check(self.lib.moeinf_set_cache_budget(self._h, int(device_memory_bytes)))
 
+    def set_cache_policy(self, policy: int):
+        """config.POLICY_LFU_INCACHE / POLICY_LRU from the next eviction on (moeinf_set_cache_policy)"""
+        check(self.lib.moeinf_set_cache_policy(self._h, int(policy)))
+        self.cfg.policy = int(policy)
+
     def set_prefetch_governor(self, min_useful_fraction: float = 0.5, probe_every: int = 16):
         """Stop issuing speculative copies while fewer than ``min_useful_fraction`` of the finished ones were ever
         dispatched (one probe in ``probe_every`` keeps watching); 0 switches the governor off."""

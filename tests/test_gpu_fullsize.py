@@ -96,9 +96,12 @@ def test_deepseek_v2_lite_layer(t):
     # That these are flips and not lost precision is what the fp32-exact arm below asserts: over the same rows the GPU is as
     # close to the fp32 computation as the oracle is (ratio printed; a biased or lossy epilogue would push it above 1.15).
     got_rows = eng.expert_outputs(rows.shape[0])
-    assert_model_close(got_rows, rows, torch.bfloat16, "expert FFN outputs", ulps=1.0 if t <= 512 else 1.5)
-    assert_block_close(out, ref, torch.bfloat16, f"DeepSeek-V2-Lite layer, {t} tokens")
+    # (the exact arm first: its ratio over the SAME rows is what justifies the 1.5-ulp bar at 4096 tokens, and the assertion
+    # message of the row bar carries it)
     acc = assert_as_accurate_as_the_oracle(out, ref, "deepseek", x[None], experts, torch.bfloat16, f"DeepSeek-V2-Lite layer, {t} tokens", shared=shared, rows=got_rows)
+    assert_model_close(got_rows, rows, torch.bfloat16, f"expert FFN outputs (fp32-exact arm over these rows: |gpu-exact| / |oracle-exact| = {acc['rows']['ratio']:.4f})",
+                       ulps=1.0 if t <= 512 else 1.5)
+    assert_block_close(out, ref, torch.bfloat16, f"DeepSeek-V2-Lite layer, {t} tokens")
     print(f"deepseek t={t}: |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f} (block), {acc['rows']['ratio']:.4f} (expert rows)")
     eng.close()
 
@@ -180,6 +183,59 @@ def test_mixtral_8x7b_layer_fp16_decode_and_prefill():
         print(f"mixtral fp16 t={t}: mean rel err {rep['mean_rel']:.2e}, max rel err {rep['max_rel_err']:.2e}; |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f}")
         assert rep["mean_rel"] <= 1e-3
         eng.close()
+
+
+@pytest.mark.parametrize("t", [1, 512, 4096], ids=["decode_b1", "prefill_t512_hybrid_and_lds_kernels_on_the_f16_matrix_instruction", "prefill_t4096_compute_bound_gemm"])
+def test_deepseek_v2_lite_layer_fp16(t):
+    """fp16 experts (the reference's dtype id 2, core/parallel/expert_module.h:20-23) at DeepSeek-V2-Lite's full shape.  The
+    tolerance north_star states is stated for THIS dtype ("within 1e-3 fp16"): fp16 ulp 2^-10 in every bar, mean relative error of
+    the block output <= 1e-3, the fp32-exact arm.  512 tokens = 48 rows per expert: the hybrid kernel; the shared expert's 512 rows
+    and the 4096-token case: the LDS-staged and the 256 x 256 kernel (ffn_gemm_f16.hip, round 5)."""
+    from moe_infinity_amd import config as Cf
+
+    eng, cfg = _engine("deepseek_v2_lite", t, dtype=Cf.DTYPE_F16)
+    experts, shared = fill_layer_on_gpu(eng, "deepseek", 0, 2234)
+    gate = _gate(cfg.num_experts, cfg.hidden, eng.gate_dtype, 4322, 0.02)
+    x = acts(t, cfg.hidden, torch.float16, 2025)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_deepseek(x[None], gate, experts, cfg.top_k, shared=shared, norm_topk_prob=bool(cfg.norm_topk_prob),
+                           routed_scaling_factor=cfg.routed_scaling_factor)
+    r = _check_index(eng, ref)
+    assert np.array_equal(_mask_from_idx(r["topk_idx"], cfg.num_experts), ref.router_mask.numpy()), "routing sets must be bit-exact"
+    rows = oracle_expert_rows(ref, cfg.num_experts)
+    got_rows = eng.expert_outputs(rows.shape[0])
+    acc = assert_as_accurate_as_the_oracle(out, ref, "deepseek", x[None], experts, torch.float16, f"DeepSeek-V2-Lite fp16 layer, {t} tokens", shared=shared, rows=got_rows)
+    assert_model_close(got_rows, rows, torch.float16, f"fp16 expert FFN outputs (fp32-exact arm over these rows: ratio {acc['rows']['ratio']:.4f})", ulps=1.0 if t <= 512 else 1.5)
+    rep = assert_block_close(out, ref, torch.float16, f"DeepSeek-V2-Lite fp16 layer, {t} tokens")
+    print(f"deepseek fp16 t={t}: mean rel err {rep['mean_rel']:.2e}, max rel err {rep['max_rel_err']:.2e}; |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f} (block), {acc['rows']['ratio']:.4f} (rows)")
+    assert rep["mean_rel"] <= 1e-3
+    eng.close()
+
+
+def test_nllb_moe_54b_layer_batch32_fp16():
+    """NLLB-MoE-54B (128 experts, biases) at batch 32 with fp16 experts: the 1e-3 of north_star read literally."""
+    from moe_infinity_amd import config as Cf
+
+    t = 32
+    eng, cfg = _engine("nllb_moe_54b", t, dtype=Cf.DTYPE_F16)
+    experts, _ = fill_layer_on_gpu(eng, "nllb", 0, 3234)
+    gate = _gate(cfg.num_experts, cfg.hidden, eng.gate_dtype, 4323, 0.5)
+    x = acts(t, cfg.hidden, torch.float16, 2026)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+    ref = R.block_nllb(x[None], gate, experts)
+    r = _check_index(eng, ref)
+    assert np.array_equal(_mask_from_idx(r["topk_idx"], cfg.num_experts), ref.router_mask.numpy()), "routing sets must be bit-exact"
+    rows = oracle_expert_rows(ref, cfg.num_experts)
+    got_rows = eng.expert_outputs(rows.shape[0])
+    acc = assert_as_accurate_as_the_oracle(out, ref, "nllb", x[None], experts, torch.float16, "NLLB-MoE-54B fp16 layer, batch 32", rows=got_rows)
+    # (bias epilogue: two rounding points on the output — see the bf16 test above)
+    assert_model_close(got_rows, rows, torch.float16, f"fp16 expert FFN outputs (fp32-exact arm over these rows: ratio {acc['rows']['ratio']:.4f})", ulps=2.0)
+    rep = assert_block_close(out, ref, torch.float16, "NLLB-MoE-54B fp16 layer, batch 32")
+    print(f"nllb fp16 b=32: mean rel err {rep['mean_rel']:.2e}, max rel err {rep['max_rel_err']:.2e}; |gpu-exact| / |oracle-exact| = {acc['ratio']:.4f}")
+    assert rep["mean_rel"] <= 1e-3
+    eng.close()
 
 
 def test_many_experts_long_reduction_prefill_takes_the_128_token_ring():
