@@ -735,7 +735,9 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 native = ExpertTracerNative(L, E, 8)
                 native.load_trace(hist)
                 nseq = native.create_entry()
-                eng.set_predictor(native, nseq, lookahead_layers=2)
+                # (min_share 0.05: with K of E = 6 of 64 an expert that EVERY token picks has 1/6 of its layer's activations; the
+                # reference's prefetcher has no threshold at all — it enqueues every predicted expert)
+                eng.set_predictor(native, nseq, lookahead_layers=2, min_share=0.05, max_experts=16)
                 eng.set_prefetch_governor(0.5, 16)
 
             def steps_(s0, n):
@@ -764,7 +766,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             mis = s_["expert_misses"]
             link = s_["h2d_bytes"] / s_["h2d_busy_ms"] / 1e6 if s_["h2d_busy_ms"] > 0 else None
             attn_ms = L * reps * one_us / 1e3 if with_attn else 0.0
-            return {"routing": routing, "policy": policy, "speculation": "engine predictor, lookahead 2, governor 0.5" if speculate else "none (on-demand fetches only)",
+            return {"routing": routing, "policy": policy, "speculation": "engine predictor, lookahead 2, min_share 0.05, governor 0.5" if speculate else "none (on-demand fetches only)",
                     "attention_standin_us_per_layer": round(reps * one_us, 1) if with_attn else 0.0,
                     "steps": nsteps_leg, "ms_per_token": round(el * 1e3 / nsteps_leg / B, 3),
                     "moe_ms_per_token_without_the_standin": round(el * 1e3 / nsteps_leg / B - attn_ms / B, 3),

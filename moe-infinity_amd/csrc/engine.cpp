@@ -1104,6 +1104,7 @@ static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s
   s.n_active_host = -1;
   s.E = g->E;
   s.dtype = g->dt;
+  s.rows_bound = (int64_t)g->cfg.max_tokens * (g->K + 1);
   const int et = g->cfg.expert_type;
   if (stage == 1) {
     s.K = g->H; s.R = g->F; s.K_sh = g->H; s.R_sh = g->Fs;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_ring2_kernel(FfnStage s) {
   constexpr int XSTAGE = KT * NTB * 1024;   // activation bytes per stage
   constexpr int NX = 3;                       // LDS ring
   constexpr int CW = 8 / NMAT;              // token groups per chunk: 8 MFMAs between two fragment batches
+  static_assert(NX * XSTAGE <= 160 * 1024, "the activation ring must fit the 160 KB of LDS of a gfx950 CU (this kernel is built for gfx950 only)");
   __shared__ __attribute__((aligned(16))) char smem[NX * XSTAGE];
 
   // TAIL: 1-D grid over units (expert slot, row block); units from ring2_split on are shared by two workgroups (half 0 / 1)

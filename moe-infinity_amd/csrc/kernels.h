@@ -109,6 +109,9 @@ struct FfnStage {
   // ring2_split on are dealt to TWO workgroups of four working waves each (64 rows), so a half-empty last round fills the chip
   int ring2_nblk;          // row blocks per expert (0: the plain 2-D grid)
   int ring2_split;
+  // upper bound of the row index the stage reads from `in` (engine: max_tokens * (K + 1)); 0 = unknown.  ffn_gemm_ring2 keeps
+  // element offsets into `in` in 32 bits: its launchers decline a stage whose rows_bound * ld_in does not fit (round-4 advice)
+  int64_t rows_bound;
 };
 // ---- which form of ffn_gemm_ring2 a stage takes: pure host logic, shared by the launchers (ffn_gemm.hip) and the introspection
 // export moeinf_ffn_ring2_form (engine.cpp), which tests/test_kernel_selection_cpu.py pins against DESIGN.md section 4.3.
