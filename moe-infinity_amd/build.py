@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmoeinf_hip.so")
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")) + ["engine.cpp"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")) + ["engine.cpp", "engine_ep.cpp", "capi_host.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "moeinf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -1,5 +1,6 @@
-// engine.cpp — host side of libmoeinf_hip.so: memory tiers, residency, the per-layer hot path
-// orchestration, and the C ABI (include/moeinf.h).
+// engine.cpp — host side of libmoeinf_hip.so: lifecycle, registration, the memory tiers (pinned arena as a cache over the
+// offload directory, HBM slots, copy lanes), the local per-layer hot path and its cache control (include/moeinf.h).
+// Shared records and the engine object: engine_internal.h; expert parallelism: engine_ep.cpp; host-only handles: capi_host.cpp.
 //
 // Replaces (reference, /root/reference): core/parallel/expert_dispatcher.cpp (ExpertDispatcher),
 // core/model/model_topology.cpp Node::SetDevice (tier mover), core/memory/* (pools, allocators,
@@ -8,328 +9,7 @@
 // hipMemcpyAsync from the pinned arena into a fixed-size HBM slot on a dedicated copy stream and
 // is ordered against the compute stream with events (hipStreamWaitEvent), so the host never blocks
 // on a copy and a slot is never recycled while a kernel may still read it.
-#include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <chrono>
-#include <deque>
-#include <string>
-#include <vector>
-
-#include "../../include/moeinf.h"
-#include "cache_policy.h"
-#include "kernels.h"
-#include <map>
-#include <mutex>
-#include "aio_pool.h"
-#include "ep_comm.h"
-#include "ep_peer.h"
-#include "offload_store.h"
-#include "prefetch_queue.h"
-#include "tracer.h"
-
-using namespace moeinf;
-
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
-}
-#define HIPCHK(call)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (call);                                                                       \
-    if (e_ != hipSuccess) return fail(MOEINF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-#define CHK(call)              \
-  do {                         \
-    int r_ = (call);           \
-    if (r_ != MOEINF_OK) return r_; \
-  } while (0)
-
-static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
-static constexpr int64_t kAioAlignment = 4096;  // core/aio/archer_aio_utils.h kAioAlignment (model_topology.cpp:429-431)
-
-// ------------------------------------------------------------------------------------------------
-// blob layout
-// ------------------------------------------------------------------------------------------------
-struct BlobLayout {
-  int n = 0;
-  int64_t off[4] = {0, 0, 0, 0}, size[4] = {0, 0, 0, 0};
-  int64_t total = 0;
-};
-static BlobLayout make_layout(int expert_type, int64_t H, int64_t F, int64_t es) {
-  BlobLayout b;
-  auto add = [&](int64_t bytes) {
-    b.off[b.n] = b.total;
-    b.size[b.n] = bytes;
-    b.total += align_up(bytes, kAioAlignment);
-    ++b.n;
-  };
-  switch (expert_type) {
-    case MOEINF_EXPERT_MIXTRAL:   // w1[F,H] w2[H,F] w3[F,H]
-    case MOEINF_EXPERT_DEEPSEEK:  // gate[F,H] up[F,H] down[H,F]
-      add(F * H * es); add(F * H * es); add(F * H * es);
-      break;
-    case MOEINF_EXPERT_NLLB:
-    case MOEINF_EXPERT_FSGPT:  // fc1.w fc1.b fc2.w fc2.b
-      add(F * H * es); add(F * es); add(H * F * es); add(H * es);
-      break;
-    case MOEINF_EXPERT_SWITCH:  // wi wo
-      add(F * H * es); add(H * F * es);
-      break;
-    default: break;
-  }
-  return b;
-}
-
-// Device-side (HBM slot) layout: matrices in MFMA-tile order (kernels.hip), biases raw; 4 KiB aligned.
-struct DevLayout {
-  int n = 0;
-  int64_t off[4] = {0, 0, 0, 0}, size[4] = {0, 0, 0, 0};
-  int R[4] = {0, 0, 0, 0}, K[4] = {0, 0, 0, 0};  // K == 0: not a matrix (bias vector, copied as is)
-  int64_t total = 0;
-};
-static DevLayout make_dev_layout(int expert_type, int64_t H, int64_t F, int dt, int64_t es) {
-  DevLayout d;
-  auto mat = [&](int64_t R, int64_t K) {
-    d.off[d.n] = d.total; d.R[d.n] = (int)R; d.K[d.n] = (int)K; d.size[d.n] = tiled_bytes(R, K, dt);
-    d.total += align_up(d.size[d.n], kAioAlignment); ++d.n;
-  };
-  auto vec = [&](int64_t n) {
-    d.off[d.n] = d.total; d.R[d.n] = (int)n; d.K[d.n] = 0; d.size[d.n] = n * es;
-    d.total += align_up(d.size[d.n], kAioAlignment); ++d.n;
-  };
-  switch (expert_type) {
-    case MOEINF_EXPERT_MIXTRAL: mat(F, H); mat(H, F); mat(F, H); break;
-    case MOEINF_EXPERT_DEEPSEEK: mat(F, H); mat(F, H); mat(H, F); break;
-    case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: mat(F, H); vec(F); mat(H, F); vec(H); break;
-    case MOEINF_EXPERT_SWITCH: mat(F, H); mat(H, F); break;
-    default: break;
-  }
-  return d;
-}
-
-// ------------------------------------------------------------------------------------------------
-// engine
-// ------------------------------------------------------------------------------------------------
-struct Node {
-  void* host = nullptr;        // pinned arena blob (reference layout); nullptr + store != nullptr: on disk only
-  int slot = -1;
-  hipEvent_t ready1 = nullptr; // recorded once the tensors FFN stage 1 reads are in the slot
-  hipEvent_t ready = nullptr;  // recorded once the whole expert is in the slot
-  bool waited1 = true;         // compute stream already ordered after `ready1`
-  bool ready_waited = true;    // compute stream already ordered after `ready`
-  bool copy_inflight = false;  // an H2D transfer out of `host` was issued and has not been OBSERVED complete yet
-  bool prefetched = false;     // resident because of a prefetch, not yet dispatched
-  int64_t visit = 0, hit = 0, miss = 0, prefetch_cnt = 0;
-  int64_t unused = 0;          // evicted after a speculative copy that no dispatch ever used (Node::unused_count, task_scheduler.cpp:304)
-  // disk tier (register_expert_from_store): where the host blob can be re-read from when the arena evicted it
-  const OffloadStore* store = nullptr;
-  uint32_t store_ids[4] = {0, 0, 0, 0};
-  uint64_t host_clock = 0;     // last time the host blob was needed (host-tier LRU)
-  // a disk -> pinned-host read in flight on the priority block reader (speculative requests read at LOW priority in
-  // the background; a demand promotes and waits): the blob becomes `host` once every tensor's request has finished
-  void* host_pending = nullptr;
-  std::vector<PrioAioPool::Handle> disk_reqs;
-};
-struct Slot {
-  void* dev = nullptr;
-  int node = -1;
-  uint64_t last_use_seq = 0;  // sequence number of the last forward whose kernels read this slot
-};
-
-static constexpr int kFenceRing = 64;
-static constexpr int kHideSharedMaxTokens = 16;  // forwards up to this many tokens hide the shared expert under the router
-
-// One H2D lane = a copy stream (hipMemcpyAsync, served by an SDMA engine) + a re-tile stream (kernels) + a ring of two
-// staging buffers, each large enough for the biggest tensor of a blob.  Tensor i+1 is copied into the other
-// buffer while tensor i is re-tiled into its slot, so the link never waits for a kernel; the slot-reuse fences are
-// waited for by the RE-TILE stream only (the copy into staging does not touch the slot).
-struct StageBuf {
-  void* dev = nullptr;
-  hipEvent_t filled = nullptr, freed = nullptr;
-  bool used = false;
-};
-struct CopyLane {
-  hipStream_t copy = nullptr, retile = nullptr;
-  StageBuf ring[2];
-  int next = 0;
-};
-
-struct moeinf_engine {
-  moeinf_config cfg;
-  int64_t es = 2;  // element size
-  int dt = DT_BF16;
-  BlobLayout lay, lay_sh;   // host blob (reference layout)
-  DevLayout dlay, dlay_sh;  // HBM slot (tiled)
-  CopyLane demand, prefetch;  // on-demand misses (high priority) / speculative copies (low priority)
-  int64_t stage_bytes = 0;
-  int64_t slot_bytes = 0;
-  int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
-  bool has_shared = false;
-
-  // host tier: pinned arena in chunks
-  std::vector<void*> arena_chunks;
-  int64_t arena_chunk_bytes = 0, arena_used_in_chunk = 0, arena_total = 0;
-
-  // device tier
-  std::vector<Slot> slots;
-  std::vector<int> free_slots;
-  int64_t max_slots = 0;
-  bool slab_exhausted = false;
-  std::vector<Node> nodes;           // [e*L + l]  (expert-major: the reference's eviction scan order)
-  std::vector<PolicyEntry> pol;      // same indexing
-  std::vector<void*> shared_dev;     // [L]
-  uint64_t clock = 0;
-  std::vector<int> resident_per_layer;  // #experts of layer l resident AND ordered (ready_waited)
-
-  // pending speculative transfers (reference: ArcherTaskPool's unified_queue_) and the copies in flight
-  PrefetchQueue pq;
-  std::unique_ptr<PrioAioPool> aio;   // disk tier reader (created with the first expert registered from a store)
-  std::deque<QueuedTask> disk_inflight;  // speculative tasks whose host blob is being read from disk (low priority)
-  std::vector<int> stale_disk;        // nodes whose speculative disk read outlived its task (stale layer): adopted when done
-  int disk_window = 2;                // such reads in flight at most
-  bool draining = false;              // moeinf_sync_copies: serve the queue even while demand copies are in flight
-  std::deque<int> demand_inflight;    // node indices whose copy was issued on the demand lane and not yet observed complete
-  // speculation governor (moeinf_set_prefetch_governor): running usefulness of finished speculative copies
-  float gov_min_useful = 0.f;         // 0 = off
-  int gov_probe_every = 16;
-  float gov_score = 1.f;              // exponential average of outcomes (1 = dispatched before eviction, 0 = evicted unused)
-  int gov_outcomes = 0, gov_skipped = 0;
-  std::deque<int> prefetch_inflight;  // node indices whose copy was issued on the prefetch lane, oldest first
-  int prefetch_window = 2;            // experts in flight on the prefetch lane at most
-  std::vector<void*> host_free;       // arena blocks returned by host-tier eviction
-  uint64_t host_clock = 0;
-
-  // streams / events
-  hipEvent_t route_ev = nullptr;
-  hipEvent_t fence_ev[kFenceRing];
-  uint64_t seq = 0;  // forwards issued
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> copy_timers;  // (start, end) pairs not yet accumulated
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_timers;  // compute-stream stalls on copies
-  std::vector<hipEvent_t> event_pool;
-
-  // device workspace
-  uint64_t* d_wptr = nullptr;  // [L][E+1]
-  float* d_logits = nullptr;
-  int32_t *d_topk_idx = nullptr, *d_pair_valid = nullptr, *d_pair_order = nullptr, *d_pair_slot = nullptr;
-  float *d_topk_w = nullptr, *d_router_prob = nullptr;
-  int32_t *d_counts = nullptr, *d_offsets = nullptr, *d_active = nullptr, *d_n_active = nullptr;
-  int32_t *d_slot_token = nullptr, *d_slot_pair = nullptr, *d_miss = nullptr;
-  int32_t* d_arrive = nullptr;  // [ceil(H/16)] zeroed arrival counters of the fused combine's column tiles
-  int32_t* d_chunk = nullptr;   // [ceil(rows/1024) * E] scratch of the many-workgroup dispatch index
-  void *d_h = nullptr, *d_y = nullptr;
-  uint64_t* d_dec_w = nullptr;  // [8] batch-1 decode records written by the self-routing FFN stage 1 (kernels.h FfnStage::dec_w)
-  float* d_dec_cw = nullptr;    // [8]
-  void *d_h_sh = nullptr, *d_y_sh = nullptr;  // decode-sized DeepSeek: shared expert's h / y (its FFN rides with the router)
-  int64_t ldh = 0;
-  int32_t* h_mirror = nullptr;  // pinned, written by the index kernels themselves: {n_active, counts[E+1], active[E+1]}
-  int32_t* h_miss = nullptr;
-  std::vector<PokeArgs> pending_pokes;
-  // sync-free forwards: the index kernel writes the routing mirror straight into a pooled pinned buffer
-  // (no copy command on the compute stream); it is applied to the counters/statistics lazily, once the
-  // forward's end-of-forward fence has passed (no residency decision depends on it while every expert of
-  // the layer is resident)
-  struct PendingMirror { uint64_t seq; int32_t* buf; int layer; int T; bool prof; bool local; };
-  std::deque<PendingMirror> pend;
-  std::vector<int32_t*> mirror_pool;
-  int32_t* mirror_slab = nullptr;  // one pinned allocation holding every pooled mirror
-  int owned_experts = 0;
-
-  // EP workspace (lazily allocated)
-  EpOwnArgs::Rec* d_ep_rec = nullptr;  // [64] stage 1 -> stage 2 records of the self-indexing owner kernels
-  int32_t *d_ep_key = nullptr, *d_ep_counts = nullptr, *d_ep_offsets = nullptr, *d_ep_active = nullptr,
-          *d_ep_nactive = nullptr, *d_ep_pair_slot = nullptr, *d_ep_slot_token = nullptr, *d_ep_slot_pair = nullptr,
-          *d_ep_pair_pos = nullptr;
-  int ep_cap_rows = 0;   // per-peer capacity of the last ep_pack (0: compact, variable-split exchange)
-  int ep_alloc_cap = 0;  // what the EP workspace is sized for
-  int64_t ep_alloc_np = 0;  // ... and the max_tokens*K it was built for
-
-  // activation-aware speculation inside the engine (moeinf_set_predictor): the attached tracer is fed from the routing
-  // mirrors the index kernels write — no read-back, no Python between "layer l routed" and "layer l+k experts requested"
-  Tracer* pred_tracer = nullptr;
-  int64_t pred_seq = -1;
-  int pred_lookahead = 0, pred_max = 0;
-  float pred_min_share = 0.f;
-  std::vector<float> pred_matrix;
-  int64_t pred_calls = 0, pred_enqueued = 0;
-
-  // native transport of the exchange (moeinf_ep_comm_init): RCCL communicator + engine-owned exchange buffers
-  RcclComm ep_comm = nullptr;
-  int ep_cap_tokens = 0, ep_x_cap_rows = 0;
-  void *ep_x_send = nullptr, *ep_x_recv = nullptr, *ep_x_y = nullptr, *ep_x_ret = nullptr;
-  // ... or the direct peer-store exchange (moeinf_ep_peer_export / _attach, ep_peer.h): no collective at all
-  EpPeerWindow ep_win;
-  int ep_win_cap_tokens = 0;
-  bool ep_use_peer = false;        // moeinf_ep_moe_forward takes this transport (moeinf_ep_select_transport)
-  bool ep_uniform = false;         // the caller guarantees equal token counts on every rank (moeinf_ep_set_uniform_tokens): batch 1 = broadcast form
-  std::vector<int32_t> ep_peer_pids;
-  std::vector<uint64_t> ep_peer_ptrs;
-  bool ep_peer_poll = true;        // consumer kernels poll their flags themselves (false: a one-wave wait kernel in front); agreed by all ranks (ep_peer.h: poll_agreed)
-  bool ep_bcast_ok = true;         // the broadcast form may be taken: agreed by all ranks (ep_peer.h: bcast_agreed)
-  int32_t* ep_err_host = nullptr;  // pinned copy of the device error flag, refreshed by the exchange itself (see ep_peer_forward)
-  uint32_t ep_err_every = 16;      // ... every so many exchanges (MOEINF_EP_ERR_CHECK_EVERY)
-  int64_t ep_peer_timeout_ticks = 0;
-  struct EpProfRec { hipEvent_t ev[6]; };
-  std::vector<EpProfRec> ep_prof_pending;
-  moeinf_ep_profile ep_prof;
-
-  // stage-2 output override of the expert-parallel FFN: rows go straight to the reply buffer, in arrival order
-  void* ovr_out = nullptr;
-  const int32_t* ovr_map = nullptr;
-
-  // last forward
-  bool last_hidden_shared = false;
-  bool last_selfroute = false;      // the last forward used the self-routing FFN stage 1 (batch-1 decode)
-  bool last_layer1 = false;         // ... and ran as ONE launch (layer_fused.hip)
-  uint32_t* d_layer_ctr = nullptr;  // its counters (kernels.h LayerSync): only grow, zeroed at creation and after an error
-  uint32_t layer1_launches = 0;
-  int32_t* d_layer_tab = nullptr;   // item table of the persistent one-launch layer (built at the first launch)
-  int layer1_nwg = 0, layer1_maxi = 0;
-  bool layer1_scalar_poll = false;
-  unsigned long long* d_layer_trace = nullptr;  // MOEINF_LAYER1_TRACE=<file>: per-workgroup timestamps of the last one-launch layer, written out at destroy
-  int layer1_trace_blocks = 0;
-  int64_t layer1_timeout_ticks = 0;
-  int last_T = 0, last_layer = -1;
-  hipStream_t last_stream = nullptr;
-  int last_rows = 0;
-
-  moeinf_stats st;
-
-  // profiling
-  bool profiling = false, ep_profiling = false;
-  struct ProfRec { hipEvent_t ev[6]; };
-  std::vector<ProfRec> prof_pending;
-  moeinf_profile prof;
-};
-
-// Events that only TIME things (profiling intervals, exposed-wait timers): a record that fails must not fail the forward it
-// brackets — the interval is simply lost (hipEventElapsedTime on it fails and the reader skips it) — but its error must not
-// linger in the runtime's sticky last-error slot either.
-static inline void record_timing(hipEvent_t ev, hipStream_t st) {
-  if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError();
-}
-
-static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }
-// a node's disk backing, reference-counted on the store so that it cannot be closed under a live engine
-static void set_node_store(Node& n, const OffloadStore* st) {
-  if (n.store == st) return;
-  if (n.store) n.store->users -= 1;
-  n.store = st;
-  if (st) st->users += 1;
-}
-static bool owns(const moeinf_engine* g, int expert) { return g->cfg.ep_size <= 1 || (expert % g->cfg.ep_size) == g->cfg.ep_rank; }
+#include "engine_internal.h"
 
 // ---- host arena ----------------------------------------------------------------------------
 static int arena_alloc(moeinf_engine* g, int64_t bytes, void** out) {
@@ -360,7 +40,7 @@ static int arena_alloc(moeinf_engine* g, int64_t bytes, void** out) {
   return MOEINF_OK;
 }
 
-static hipEvent_t get_event(moeinf_engine* g) {
+hipEvent_t get_event(moeinf_engine* g) {
   if (!g->event_pool.empty()) {
     hipEvent_t e = g->event_pool.back();
     g->event_pool.pop_back();
@@ -372,7 +52,13 @@ static hipEvent_t get_event(moeinf_engine* g) {
 }
 
 // ---- lifecycle -----------------------------------------------------------------------------
-extern "C" const char* moeinf_last_error(void) { return g_err.c_str(); }
+#undef g_err
+std::string& moeinf_err_slot() {
+  static thread_local std::string err;
+  return err;
+}
+#define g_err (moeinf_err_slot())
+extern "C" const char* moeinf_last_error(void) { return moeinf_err_slot().c_str(); }
 extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
 // rows of the busiest expert as the sync-free path assumes them (the host does not know the routing there): 1.5 x the mean + 1,
 // at most T.  Picks the FORM of the FFN kernels only; an expert with more rows takes more passes.
@@ -430,11 +116,6 @@ static int validate(const moeinf_config* c) {
   return MOEINF_OK;
 }
 
-template <typename T>
-static int dmalloc(T** p, size_t n) {
-  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
-  return MOEINF_OK;
-}
 
 // the part of the device workspace that is sized by max_tokens (re-allocated by moeinf_reserve_tokens)
 static void free_token_workspace(moeinf_engine* g) {
@@ -442,7 +123,7 @@ static void free_token_workspace(moeinf_engine* g) {
                    (void**)&g->d_topk_w, (void**)&g->d_router_prob, (void**)&g->d_slot_token, (void**)&g->d_slot_pair, (void**)&g->d_chunk, &g->d_h, &g->d_y};
   for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
 }
-static void free_ep_workspace(moeinf_engine* g) {
+void free_ep_workspace(moeinf_engine* g) {
   void** bufs[] = {(void**)&g->d_ep_key, (void**)&g->d_ep_counts, (void**)&g->d_ep_offsets, (void**)&g->d_ep_active, (void**)&g->d_ep_nactive,
                    (void**)&g->d_ep_pair_slot, (void**)&g->d_ep_slot_token, (void**)&g->d_ep_slot_pair, (void**)&g->d_ep_pair_pos};
   for (void** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
@@ -717,7 +398,7 @@ static void queue_poke(moeinf_engine* g, int layer, int expert, uint64_t val) {
   p.val[p.n] = val;
   ++p.n;
 }
-static int flush_pokes(moeinf_engine* g, hipStream_t st) {
+int flush_pokes(moeinf_engine* g, hipStream_t st) {
   for (auto& p : g->pending_pokes) HIPCHK(launch_poke(p, st));
   g->pending_pokes.clear();
   return MOEINF_OK;
@@ -1073,7 +754,7 @@ static int ensure_host(moeinf_engine* g, int idx) {
 static int pump_prefetch(moeinf_engine* g);
 // a layer is being dispatched: speculative transfers queued for layers the pass has already left are stale
 // (StartExec drops every queued task with a smaller layer id, task_scheduler.cpp:158-168)
-static inline void drop_stale_prefetches(moeinf_engine* g, int layer) {
+void drop_stale_prefetches(moeinf_engine* g, int layer) {
   if (!g->pq.empty()) g->st.prefetch_cancelled += g->pq.on_demand(-1, layer);
   // speculative disk reads for layers the pass has left: the read itself finishes (the blob is adopted into the host
   // tier by the next demand for it), but its task leaves the pipeline so that no H2D copy is issued for a stale layer
@@ -1082,7 +763,7 @@ static inline void drop_stale_prefetches(moeinf_engine* g, int layer) {
     else ++it;
   }
 }
-static inline int pump_if_pending(moeinf_engine* g) {
+int pump_if_pending(moeinf_engine* g) {
   if (g->pq.empty() && g->prefetch_inflight.empty() && g->disk_inflight.empty() && g->stale_disk.empty()) return MOEINF_OK;
   return pump_prefetch(g);
 }
@@ -1093,7 +774,7 @@ static int fuse_mode() {
   static const int m = (getenv("MOEINF_WIDE_OUT") && atoi(getenv("MOEINF_WIDE_OUT")) != 0) ? 2 : 1;
   return m;
 }
-static void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x = 0) {
+void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64_t ld_x) {
   const DevLayout& b = g->dlay;
   const DevLayout& bs = g->dlay_sh;
   memset(&s, 0, sizeof s);
@@ -1245,9 +926,8 @@ static void drain_mirrors(moeinf_engine* g, bool block) { drain_mirrors(g, block
 
 // Where the next index kernel writes its routing mirror, decided BEFORE that launch: a pooled pinned buffer when
 // the layer is fully resident (sync-free forward), the engine's h_mirror when the host has to look at it.
-struct MirrorPlan { bool fast = false; int32_t* target = nullptr; };
 static void settle_ready(moeinf_engine* g, int layer);
-static int plan_mirror(moeinf_engine* g, int layer, MirrorPlan& mp) {
+int plan_mirror(moeinf_engine* g, int layer, MirrorPlan& mp) {
   settle_ready(g, layer);
   mp.fast = g->resident_per_layer[layer] == g->owned_experts;
   if (mp.fast) {
@@ -1408,16 +1088,9 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
 //   does not wait for the routing result (the reference blocks on a D2H sum every layer,
 //   expert_executor.py:34-43).  The mirror is applied to the counters lazily.
 //   Decision path: some expert may be missing: small pinned D2H + event wait, then fetch/evict.
-struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn1_selfroute)
-  const RouteArgs* ra;
-  const IndexArgs* ia;
-  const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
-  const FfnStage* sh1 = nullptr;  // layer1: its stage 1
-  bool layer1 = false;  // the whole layer as ONE launch (launch_moe_layer1): the caller has NOT launched the gate
-};
-static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
+int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x, int T, int max_active, int exp_rows,
                             hipStream_t st, bool prof, moeinf_engine::ProfRec* pr, const MirrorPlan& mp,
-                            const CombineArgs* fuse, bool* fused, const SelfRoute* sr = nullptr) {
+                            const CombineArgs* fuse, bool* fused, const SelfRoute* sr) {
   const int E = g->E, E1 = E + 1;
   if (fused) *fused = false;
   if (mp.fast) {
@@ -1491,8 +1164,7 @@ static int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64
   return MOEINF_OK;
 }
 
-static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st);
-static void make_route_args(const moeinf_engine* g, const void* x_dev, const void* gate_w_dev, int T, RouteArgs& ra) {
+void make_route_args(const moeinf_engine* g, const void* x_dev, const void* gate_w_dev, int T, RouteArgs& ra) {
   memset(&ra, 0, sizeof ra);
   ra.x = x_dev; ra.gate_w = gate_w_dev; ra.logits = g->d_logits;
   ra.T = T; ra.H = g->H; ra.E = g->E; ra.K = g->K;
@@ -1502,7 +1174,7 @@ static void make_route_args(const moeinf_engine* g, const void* x_dev, const voi
   ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
   ra.router_prob = g->d_router_prob;
 }
-static void make_index_args(const moeinf_engine* g, int T, int batch_rows, int32_t* mirror, IndexArgs& ia) {
+void make_index_args(const moeinf_engine* g, int T, int batch_rows, int32_t* mirror, IndexArgs& ia) {
   memset(&ia, 0, sizeof ia);
   ia.topk_idx = g->d_topk_idx; ia.pair_valid = g->d_pair_valid; ia.T = T; ia.K = g->K; ia.E = g->E;
   ia.rows = batch_rows;
@@ -1512,11 +1184,11 @@ static void make_index_args(const moeinf_engine* g, int T, int batch_rows, int32
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mirror;
 }
 // decode-sized DeepSeek forwards: the shared expert (routing-independent, always resident) runs INSIDE the two router launches
-static bool can_hide_shared(const moeinf_engine* g, int T) {
+bool can_hide_shared(const moeinf_engine* g, int T) {
   static const bool hide_env = getenv("MOEINF_HIDE_SHARED") ? atoi(getenv("MOEINF_HIDE_SHARED")) != 0 : true;
   return hide_env && g->has_shared && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * g->K <= 64 && g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
 }
-static void hidden_shared_stages(const moeinf_engine* g, int layer, const void* x_dev, FfnStage& sh1, FfnStage& sh2) {
+void hidden_shared_stages(const moeinf_engine* g, int layer, const void* x_dev, FfnStage& sh1, FfnStage& sh2) {
   fill_stage(g, layer, 1, sh1, 0);
   sh1.in = x_dev; sh1.row_map = nullptr; sh1.out = g->d_h_sh; sh1.ld_out = g->Fs;
   fill_stage(g, layer, 2, sh2, 0);
@@ -2149,98 +1821,10 @@ extern "C" int moeinf_reserve_tokens(moeinf_engine* g, int max_tokens) {
   return MOEINF_OK;
 }
 
-// ---- disk tier -------------------------------------------------------------------------------
-struct moeinf_store {
-  OffloadStore s;
-  void* bounce[2] = {nullptr, nullptr};  // pinned pieces of moeinf_store_get_device
-  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
-  bool bounce_used[2] = {false, false};
-};
-extern "C" int moeinf_store_open(const char* path, moeinf_store** out) {
-  if (!path || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  moeinf_store* st = new moeinf_store();
-  const std::string err = st->s.open(path);
-  if (!err.empty()) { delete st; return fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
-  *out = st;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_store_close(moeinf_store* st) {
-  if (!st) return MOEINF_OK;
-  if (st->s.users > 0) return fail(MOEINF_ERR_STATE, "offload store is still backing %d experts of a live engine: destroy the engine first", st->s.users);
-  int rc = MOEINF_OK;
-  if (st->s.dirty()) { const std::string err = st->s.flush(); if (!err.empty()) rc = fail(MOEINF_ERR_INVALID, "%s", err.c_str()); }
-  for (int i = 0; i < 2; ++i) { if (st->bounce[i]) hipHostFree(st->bounce[i]); if (st->bounce_ev[i]) hipEventDestroy(st->bounce_ev[i]); }
-  delete st;
-  return rc;
-}
-extern "C" int moeinf_store_put(moeinf_store* st, uint32_t id, const void* data, uint64_t nbytes, const int64_t* dims, int ndim, int scalar_type) {
-  if (!st || !data || ndim < 0 || ndim > 8 || (ndim > 0 && !dims)) return fail(MOEINF_ERR_INVALID, "bad store_put arguments");
-  const std::string err = st->s.put(id, data, nbytes, dims, ndim, scalar_type);
-  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-}
-extern "C" int moeinf_store_flush(moeinf_store* st) {
-  if (!st) return fail(MOEINF_ERR_INVALID, "store is NULL");
-  const std::string err = st->s.flush();
-  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-}
-extern "C" int moeinf_store_count(const moeinf_store* st, int64_t* n) {
-  if (!st || !n) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  *n = (int64_t)st->s.count();
-  return MOEINF_OK;
-}
-extern "C" int moeinf_store_ids(const moeinf_store* st, uint32_t* ids_out, int64_t capacity) {
-  if (!st || !ids_out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const auto v = st->s.ids();
-  if ((int64_t)v.size() > capacity) return fail(MOEINF_ERR_INVALID, "ids_out holds %lld ids, store has %zu", (long long)capacity, v.size());
-  std::copy(v.begin(), v.end(), ids_out);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_store_meta(const moeinf_store* st, uint32_t id, int32_t* found, uint64_t* nbytes, int64_t* offset, int32_t* ndim, int64_t* dims_out, int32_t* scalar_type) {
-  if (!st || !found) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const TensorMeta* m = st->s.find(id);
-  *found = m ? 1 : 0;
-  if (!m) return MOEINF_OK;
-  if (nbytes) *nbytes = m->size;
-  if (offset) *offset = m->offset;
-  if (ndim) *ndim = (int32_t)m->shape.size();
-  if (dims_out) for (size_t i = 0; i < m->shape.size() && i < 8; ++i) dims_out[i] = m->shape[i];
-  if (scalar_type) *scalar_type = m->dtype;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_store_get(const moeinf_store* st, uint32_t id, void* dst, uint64_t capacity) {
-  if (!st || !dst) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const std::string err = st->s.get(id, dst, capacity);
-  return err.empty() ? MOEINF_OK : fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-}
-// disk -> device for a DENSE tensor (Node::SetDevice's disk->host->device legs for non-expert nodes,
-// model_topology.cpp:76-119; AcquireTensor / FetchTensors, archer_prefetch_handle.cpp:83-130,220-227): the payload is
-// read in 32 MiB pieces into two pinned bounce buffers and copied with hipMemcpyAsync on `stream`, the read of piece
-// i+1 overlapping the copy of piece i.  Returns when the last copy has been ENQUEUED and the bounce buffers are free
-// again (the device data is stream-ordered after the call).
-extern "C" int moeinf_store_get_device(moeinf_store* st, uint32_t id, void* dst_dev, uint64_t capacity, void* stream) {
-  if (!st || !dst_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const TensorMeta* m = st->s.find(id);
-  if (!m) return fail(MOEINF_ERR_INVALID, "tensor %u is not in the offload index", id);
-  if (m->size > capacity) return fail(MOEINF_ERR_INVALID, "tensor %u is %llu bytes, destination holds %llu", id, (unsigned long long)m->size, (unsigned long long)capacity);
-  constexpr uint64_t kPiece = 32ull << 20;
-  if (!st->bounce[0]) {
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(hipHostMalloc(&st->bounce[i], kPiece, hipHostMallocDefault));
-      HIPCHK(hipEventCreateWithFlags(&st->bounce_ev[i], hipEventDisableTiming));
-    }
-  }
-  hipStream_t s = (hipStream_t)stream;
-  int b = 0;
-  for (uint64_t off = 0; off < m->size; off += kPiece, b ^= 1) {
-    const uint64_t n = std::min<uint64_t>(kPiece, m->size - off);
-    if (st->bounce_used[b]) HIPCHK(hipEventSynchronize(st->bounce_ev[b]));
-    const std::string err = st->s.get_range(id, off, st->bounce[b], n);
-    if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-    HIPCHK(hipMemcpyAsync((char*)dst_dev + off, st->bounce[b], n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(st->bounce_ev[b], s));
-    st->bounce_used[b] = true;
-  }
-  for (int i = 0; i < 2; ++i) if (st->bounce_used[i]) HIPCHK(hipEventSynchronize(st->bounce_ev[i]));
+
+int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st) {
+  if (ia.capacity <= 0 && (int64_t)ia.T * ia.K > 2048) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
+  else HIPCHK(launch_dispatch_index(ia, st));
   return MOEINF_OK;
 }
 
@@ -2277,187 +1861,6 @@ extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, in
   return MOEINF_OK;
 }
 
-// ---- cache simulator -----------------------------------------------------------------------
-struct moeinf_cache_sim { CacheSim* sim; };
-extern "C" int moeinf_cache_sim_create(int num_slots, int policy, moeinf_cache_sim** out) {
-  if (!out || num_slots <= 0 || (policy != POLICY_LFU_INCACHE && policy != POLICY_LRU)) return fail(MOEINF_ERR_INVALID, "bad cache_sim arguments");
-  *out = new moeinf_cache_sim{new CacheSim(num_slots, policy)};
-  return MOEINF_OK;
-}
-extern "C" int moeinf_cache_sim_destroy(moeinf_cache_sim* s) { if (s) { delete s->sim; delete s; } return MOEINF_OK; }
-extern "C" int moeinf_cache_sim_access(moeinf_cache_sim* s, int64_t id, int32_t* hit, int64_t* evicted) {
-  if (!s || id < 0) return fail(MOEINF_ERR_INVALID, "bad cache_sim_access arguments");
-  int64_t ev = -1;
-  const bool h = s->sim->access(id, &ev);
-  if (hit) *hit = h ? 1 : 0;
-  if (evicted) *evicted = ev;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_cache_sim_protect(moeinf_cache_sim* s, const int64_t* ids, int n) {
-  if (!s || n < 0 || (n > 0 && !ids)) return fail(MOEINF_ERR_INVALID, "bad cache_sim_protect arguments");
-  s->sim->protect(ids, n);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_cache_sim_clear_counts(moeinf_cache_sim* s) {
-  if (!s) return fail(MOEINF_ERR_INVALID, "sim is NULL");
-  s->sim->clear_counts();
-  return MOEINF_OK;
-}
-
-// ---- pending-transfer queue, standalone (host only) -----------------------------------------
-struct moeinf_pq { PrefetchQueue q; };
-extern "C" int moeinf_pq_create(moeinf_pq** out) {
-  if (!out) return fail(MOEINF_ERR_INVALID, "out is NULL");
-  *out = new moeinf_pq();
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_destroy(moeinf_pq* q) { delete q; return MOEINF_OK; }
-extern "C" int moeinf_pq_enqueue(moeinf_pq* q, int64_t node, int layer, int priority, int remove_layer, int32_t* dropped) {
-  if (!q || node < 0) return fail(MOEINF_ERR_INVALID, "bad pq_enqueue arguments");
-  const int d = q->q.enqueue(node, layer, priority, remove_layer != 0);
-  if (dropped) *dropped = d;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_on_demand(moeinf_pq* q, int64_t node, int layer, int32_t* dropped) {
-  if (!q) return fail(MOEINF_ERR_INVALID, "queue is NULL");
-  const int d = q->q.on_demand(node, layer);
-  if (dropped) *dropped = d;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_fetch(moeinf_pq* q, int64_t node, int layer, int already_there, int32_t* dropped) {
-  if (!q || node < 0) return fail(MOEINF_ERR_INVALID, "bad pq_fetch arguments");
-  const int d = q->q.fetch(node, layer, already_there != 0);
-  if (dropped) *dropped = d;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_clear_prefetch(moeinf_pq* q, int32_t* dropped) {
-  if (!q) return fail(MOEINF_ERR_INVALID, "queue is NULL");
-  const int d = q->q.clear_prefetch();
-  if (dropped) *dropped = d;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_pop(moeinf_pq* q, int64_t* node, int32_t* layer, int32_t* priority, int32_t* found) {
-  if (!q || !found) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  QueuedTask t;
-  *found = q->q.pop(&t) ? 1 : 0;
-  if (*found) { if (node) *node = t.node; if (layer) *layer = t.layer; if (priority) *priority = t.priority; }
-  return MOEINF_OK;
-}
-extern "C" int moeinf_pq_snapshot(const moeinf_pq* q, int64_t* nodes, int32_t* layers, int32_t* priorities, int capacity, int32_t* n) {
-  if (!q || !n) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const auto v = q->q.snapshot();
-  if ((int)v.size() > capacity) return fail(MOEINF_ERR_INVALID, "snapshot needs room for %zu tasks", v.size());
-  for (size_t i = 0; i < v.size(); ++i) { if (nodes) nodes[i] = v[i].node; if (layers) layers[i] = v[i].layer; if (priorities) priorities[i] = v[i].priority; }
-  *n = (int32_t)v.size();
-  return MOEINF_OK;
-}
-extern "C" int moeinf_priority_from_score(float score, int32_t* level) {
-  if (!level) return fail(MOEINF_ERR_INVALID, "level is NULL");
-  *level = priority_from_score(&score, 0);
-  return MOEINF_OK;
-}
-
-// ---- priority block reader, standalone (host only) -------------------------------------------
-struct moeinf_aio {
-  PrioAioPool pool;
-  std::mutex mu;
-  std::map<int64_t, PrioAioPool::Handle> reqs;
-  int64_t next = 1;
-  moeinf_aio(int threads, int64_t block) : pool(threads, block) {}
-};
-extern "C" int moeinf_aio_create(int threads, int64_t block_bytes, moeinf_aio** out) {
-  if (!out || threads <= 0 || block_bytes <= 0) return fail(MOEINF_ERR_INVALID, "bad aio arguments");
-  *out = new moeinf_aio(threads, block_bytes);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_aio_destroy(moeinf_aio* a) { delete a; return MOEINF_OK; }
-extern "C" int moeinf_aio_submit_read(moeinf_aio* a, const char* path, void* dst, int64_t nbytes, int64_t offset, int high_prio, int try_direct, int64_t* request) {
-  if (!a || !path || !dst || !request || nbytes < 0 || offset < 0) return fail(MOEINF_ERR_INVALID, "bad aio read arguments");
-  auto h = a->pool.submit(path, dst, nbytes, offset, high_prio != 0, try_direct != 0);
-  std::lock_guard<std::mutex> lk(a->mu);
-  *request = a->next++;
-  a->reqs[*request] = h;
-  return MOEINF_OK;
-}
-static PrioAioPool::Handle aio_find(moeinf_aio* a, int64_t request, bool take) {
-  std::lock_guard<std::mutex> lk(a->mu);
-  auto it = a->reqs.find(request);
-  if (it == a->reqs.end()) return nullptr;
-  auto h = it->second;
-  if (take) a->reqs.erase(it);
-  return h;
-}
-extern "C" int moeinf_aio_promote(moeinf_aio* a, int64_t request) {
-  if (!a) return fail(MOEINF_ERR_INVALID, "aio is NULL");
-  auto h = aio_find(a, request, false);
-  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
-  a->pool.promote(h);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_aio_done(moeinf_aio* a, int64_t request, int32_t* done) {
-  if (!a || !done) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  auto h = aio_find(a, request, false);
-  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
-  *done = PrioAioPool::done(h) ? 1 : 0;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_aio_wait(moeinf_aio* a, int64_t request) {
-  if (!a) return fail(MOEINF_ERR_INVALID, "aio is NULL");
-  auto h = aio_find(a, request, true);
-  if (!h) return fail(MOEINF_ERR_INVALID, "unknown aio request %lld", (long long)request);
-  const std::string err = PrioAioPool::wait(h);
-  if (!err.empty()) return fail(MOEINF_ERR_INVALID, "%s", err.c_str());
-  return MOEINF_OK;
-}
-extern "C" int moeinf_aio_stats(const moeinf_aio* a, int64_t out[5]) {
-  if (!a || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  const auto s = a->pool.stats();
-  out[0] = s.blocks_high; out[1] = s.blocks_low; out[2] = s.bytes; out[3] = s.promoted; out[4] = s.direct_fallbacks;
-  return MOEINF_OK;
-}
-
-// ---- tracer --------------------------------------------------------------------------------
-struct moeinf_tracer { Tracer* t; };
-extern "C" int moeinf_tracer_create(int L, int E, int capacity, moeinf_tracer** out) {
-  if (!out || L <= 0 || E <= 0 || capacity <= 0) return fail(MOEINF_ERR_INVALID, "bad tracer arguments");
-  *out = new moeinf_tracer{new Tracer(L, E, capacity)};
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_destroy(moeinf_tracer* t) { if (t) { delete t->t; delete t; } return MOEINF_OK; }
-extern "C" int moeinf_tracer_load(moeinf_tracer* t, const float* eams, int n) {
-  if (!t || !eams || n < 0 || n > t->t->capacity()) return fail(MOEINF_ERR_INVALID, "tracer_load: n must be in 0..capacity");
-  t->t->load(eams, n);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_create_entry(moeinf_tracer* t, int64_t* seq_id) {
-  if (!t || !seq_id) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  *seq_id = t->t->create_entry();
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_finish_entry(moeinf_tracer* t, int64_t seq_id) {
-  if (!t || !t->t->has(seq_id)) return fail(MOEINF_ERR_INVALID, "unknown seq_id");
-  t->t->finish_entry(seq_id);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_predict(moeinf_tracer* t, int64_t seq_id, int layer, const int32_t* experts, int n, float* matrix_out, int32_t* nearest_out) {
-  if (!t || !t->t->has(seq_id) || !matrix_out || n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "bad tracer_predict arguments");
-  if (layer < 0 || layer >= t->t->layers()) return fail(MOEINF_ERR_INVALID, "layer out of range");
-  for (int i = 0; i < n; ++i) if (experts[i] < 0 || experts[i] >= t->t->experts()) return fail(MOEINF_ERR_INVALID, "expert id out of range");
-  int nearest = t->t->predict(seq_id, layer, experts, n, matrix_out);
-  if (nearest_out) *nearest_out = nearest;
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_prefetch_order(const moeinf_tracer* t, int layer, const float* matrix, int32_t* layers_out, int32_t* experts_out, float* scores_out, int32_t* n_out) {
-  if (!t || !matrix || !layers_out || !experts_out || !n_out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (layer < 0 || layer >= t->t->layers()) return fail(MOEINF_ERR_INVALID, "layer out of range");
-  *n_out = t->t->prefetch_order(layer, matrix, layers_out, experts_out, scores_out);
-  return MOEINF_OK;
-}
-extern "C" int moeinf_tracer_get_eam(moeinf_tracer* t, int64_t seq_id, double* eam_out) {
-  if (!t || !t->t->has(seq_id) || !eam_out) return fail(MOEINF_ERR_INVALID, "bad tracer_get_eam arguments");
-  t->t->get_eam(seq_id, eam_out);
-  return MOEINF_OK;
-}
 
 extern "C" int moeinf_set_predictor(moeinf_engine* g, moeinf_tracer* tr, int64_t seq_id, int lookahead_layers, float min_share, int max_experts) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
@@ -2470,732 +1873,3 @@ extern "C" int moeinf_set_predictor(moeinf_engine* g, moeinf_tracer* tr, int64_t
   return MOEINF_OK;
 }
 
-// ---- expert-parallel helpers ---------------------------------------------------------------
-static int launch_index_auto(moeinf_engine* g, const IndexArgs& ia, hipStream_t st) {
-  if (ia.capacity <= 0 && (int64_t)ia.T * ia.K > 2048) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
-  else HIPCHK(launch_dispatch_index(ia, st));
-  return MOEINF_OK;
-}
-static int ep_alloc(moeinf_engine* g, int cap_rows) {
-  const size_t np = (size_t)g->cfg.max_tokens * g->K;
-  if (g->d_ep_key && g->ep_alloc_cap >= cap_rows && g->ep_alloc_np >= (int64_t)np) { g->ep_cap_rows = cap_rows; return MOEINF_OK; }
-  if (g->d_ep_key) HIPCHK(hipDeviceSynchronize());  // kernels of earlier layers may still use the old buffers
-  free_ep_workspace(g);
-  const size_t nr = std::max<size_t>(np, (size_t)g->cfg.ep_size * cap_rows);
-  const size_t nk = std::max<size_t>((size_t)g->cfg.ep_size, (size_t)g->E) + 2;
-  CHK(dmalloc(&g->d_ep_key, nr)); CHK(dmalloc(&g->d_ep_counts, nk)); CHK(dmalloc(&g->d_ep_offsets, nk + 1)); CHK(dmalloc(&g->d_ep_active, nk));
-  CHK(dmalloc(&g->d_ep_nactive, 1)); CHK(dmalloc(&g->d_ep_pair_slot, nr)); CHK(dmalloc(&g->d_ep_slot_token, nr + 1)); CHK(dmalloc(&g->d_ep_slot_pair, nr + 1));
-  CHK(dmalloc(&g->d_ep_pair_pos, np));
-  g->ep_cap_rows = cap_rows;
-  g->ep_alloc_cap = cap_rows;
-  g->ep_alloc_np = (int64_t)np;
-  return MOEINF_OK;
-}
-
-static int64_t ep_row_elems(const moeinf_engine* g) { return g->H + 16 / g->es; }
-// fewest row slots per peer that can never overflow: a token sends a rank at most one row per expert that rank owns
-static int ep_min_cap(const moeinf_engine* g, int T) {
-  const int per_rank = (g->E + g->cfg.ep_size - 1) / g->cfg.ep_size;
-  return T * std::min(g->K, per_rank);
-}
-static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st, const EpPeers* pv = nullptr);
-static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream);
-
-extern "C" int moeinf_ep_row_elems(const moeinf_engine* g, int32_t* elems) {
-  if (!g || !elems) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  *elems = (int32_t)ep_row_elems(g);
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
-  if (!g || !x_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack needs a preceding ROUTE_ONLY forward");
-  if (cap_rows < ep_min_cap(g, g->last_T)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank) (worst case: every pair a rank can receive from these tokens)", cap_rows, ep_min_cap(g, g->last_T));
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  CHK(ep_alloc(g, cap_rows));
-  return ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st);
-}
-static int ep_pack_fixed(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, int cap_rows, hipStream_t st, const EpPeers* pv) {
-  const int np = g->last_T * g->K, ep = g->cfg.ep_size;
-  if (np <= 64) {  // decode: one launch
-    EpPackArgs pa;
-    memset(&pa, 0, sizeof pa);
-    pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
-    pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
-    HIPCHK(launch_ep_pack_small(pa, g->d_pair_valid, np, send_counts_dev, st, pv));
-    return MOEINF_OK;
-  }
-  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
-  IndexArgs ia;
-  memset(&ia, 0, sizeof ia);
-  ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
-  ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
-  ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
-  HIPCHK(launch_dispatch_index(ia, st));
-  EpPackArgs pa;
-  memset(&pa, 0, sizeof pa);
-  pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
-  pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
-  pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = cap_rows; pa.dtype = g->dt;
-  HIPCHK(launch_ep_pack(pa, st, pv));
-  if (send_counts_dev) HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
-  return MOEINF_OK;
-}
-
-// Sender side of the fixed-capacity exchange in ONE call: gate (+ stage 1 of a hidden DeepSeek shared expert) -> top-k +
-// dispatch index (+ its stage 2) -> send rows.  For decode-sized forwards the send rows are written by the
-// single-workgroup router launch itself (EpFuse): two launches per layer before the all-to-all.
-static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
-                              void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream, const EpPeers* pv);
-extern "C" int moeinf_ep_route_pack(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
-                                    void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream) {
-  if (!g || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  return ep_route_pack_impl(g, layer, x_dev, tokens, batch_rows, gate_w_dev, send_dev, send_counts_dev, cap_rows, stream, nullptr);
-}
-// pv != nullptr: the peer-store exchange — the rows go straight into the destination ranks' windows (send_dev unused)
-static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
-                              void* send_dev, int32_t* send_counts_dev, int cap_rows, void* stream, const EpPeers* pv) {
-  if (!g || !x_dev || !gate_w_dev || (!send_dev && !pv)) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
-  if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
-  if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
-  if (cap_rows < ep_min_cap(g, tokens)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank)", cap_rows, ep_min_cap(g, tokens));
-  if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  const int T = tokens, K = g->K, np = T * K;
-  CHK(ep_alloc(g, cap_rows));
-  RouteArgs ra;
-  make_route_args(g, x_dev, gate_w_dev, T, ra);
-  IndexArgs ia;
-  make_index_args(g, T, batch_rows, nullptr, ia);
-  ia.shared = 0;  // the owner-side index is built from the received rows; the shared expert never crosses the fabric
-  const bool hide_shared = can_hide_shared(g, T);
-  g->last_hidden_shared = hide_shared;
-  g->last_selfroute = false;
-  // the pack rides in the router's single-workgroup launch while the rows are few KB (one workgroup copies them)
-  static const int fuse_kb = getenv("MOEINF_EP_FUSE_PACK_KB") ? atoi(getenv("MOEINF_EP_FUSE_PACK_KB")) : 64;
-  const bool fuse = np <= 64 && T <= 64 && (int64_t)np * g->H * g->es <= (int64_t)fuse_kb * 1024;
-  EpFuse pk;
-  memset(&pk, 0, sizeof pk);
-  pk.a.x = x_dev; pk.a.send = send_dev; pk.a.ld_send = ep_row_elems(g); pk.a.pair_pos = g->d_ep_pair_pos; pk.a.topk_idx = g->d_topk_idx;
-  pk.a.K = K; pk.a.H = g->H; pk.a.ep_size = g->cfg.ep_size; pk.a.cap_rows = cap_rows; pk.a.dtype = g->dt;
-  pk.pair_valid = g->d_pair_valid; pk.send_counts = send_counts_dev; pk.on = 1;
-  if (pv) pk.peers = *pv;
-  if (hide_shared) {
-    FfnStage sh1, sh2;
-    hidden_shared_stages(g, layer, x_dev, sh1, sh2);
-    HIPCHK(launch_gate_shared1(ra, sh1, st));
-    HIPCHK(launch_route_shared2(ra, ia, sh2, st, fuse ? &pk : nullptr));
-  } else {
-    HIPCHK(launch_gate_logits(ra, st));
-    if (T <= 64) {
-      HIPCHK(launch_route_index(ra, ia, st, fuse ? &pk : nullptr));
-    } else {
-      HIPCHK(launch_route_topk(ra, st));
-      CHK(launch_index_auto(g, ia, st));
-    }
-  }
-  g->last_T = T; g->last_layer = layer; g->last_stream = st;
-  g->st.forwards += 1;
-  if (!fuse) CHK(ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st, pv));
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_pack_compact(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, void* stream) {
-  if (!g || !x_dev || !send_dev || !send_counts_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack_compact needs a preceding ROUTE_ONLY forward");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  const int np = g->last_T * g->K, ep = g->cfg.ep_size;
-  CHK(ep_alloc(g, std::max(1, np)));
-  g->ep_cap_rows = 0;  // compact mode: ep_combine takes cap_rows == 0
-  HIPCHK(launch_ep_dest_key(g->d_topk_idx, g->d_pair_valid, g->d_ep_key, g->d_ep_pair_pos, np, ep, st));
-  IndexArgs ia;
-  memset(&ia, 0, sizeof ia);
-  ia.topk_idx = g->d_ep_key; ia.pair_valid = nullptr; ia.T = np; ia.K = 1; ia.E = ep; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
-  ia.counts = g->d_ep_counts; ia.offsets = g->d_ep_offsets; ia.active = g->d_ep_active; ia.n_active = g->d_ep_nactive;
-  ia.pair_slot = g->d_ep_pair_slot; ia.slot_token = g->d_ep_slot_token; ia.slot_pair = g->d_ep_slot_pair; ia.mirror = nullptr;
-  CHK(launch_index_auto(g, ia, st));
-  EpPackArgs pa;
-  memset(&pa, 0, sizeof pa);
-  pa.x = x_dev; pa.send = send_dev; pa.ld_send = ep_row_elems(g); pa.pair_pos = g->d_ep_pair_pos; pa.topk_idx = g->d_topk_idx;
-  pa.counts = g->d_ep_counts; pa.offsets = g->d_ep_offsets; pa.slot_pair = g->d_ep_slot_pair;
-  pa.K = g->K; pa.H = g->H; pa.ep_size = ep; pa.cap_rows = 0; pa.dtype = g->dt;
-  HIPCHK(launch_ep_pack_compact(pa, np, st));
-  HIPCHK(hipMemcpyAsync(send_counts_dev, g->d_ep_counts, (size_t)ep * 4, hipMemcpyDeviceToDevice, st));
-  return MOEINF_OK;
-}
-
-static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st, const EpPeers* pv = nullptr);
-
-extern "C" int moeinf_ep_expert_ffn(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int cap_rows, void* stream) {
-  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (cap_rows <= 0) return fail(MOEINF_ERR_INVALID, "cap_rows must be > 0");
-  return ep_expert_ffn_rows(g, layer, recv_dev, y_dev, g->cfg.ep_size * cap_rows, (hipStream_t)stream);
-}
-extern "C" int moeinf_ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, void* stream) {
-  if (!g || !recv_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (nrows < 0) return fail(MOEINF_ERR_INVALID, "nrows must be >= 0");
-  if (nrows == 0) return MOEINF_OK;  // nothing was routed to this rank
-  return ep_expert_ffn_rows(g, layer, recv_dev, y_dev, nrows, (hipStream_t)stream);
-}
-// pv != nullptr (peer-store exchange): recv_dev is this rank's window; the self-indexing kernels poll the row flags and
-// store their outputs into the home ranks' windows themselves, the generic path gets a wait kernel in front and a push
-// kernel behind (y_dev = a local staging buffer there)
-static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st, const EpPeers* pv) {
-  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  const int E = g->E;
-  if ((int64_t)nrows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "ep rows %d exceed workspace (max_tokens*K = %d): create the engine with max_tokens >= ep_size*cap_rows/K", nrows, g->cfg.max_tokens * g->K);
-  const int64_t ld = ep_row_elems(g);
-  IndexArgs ia;
-  memset(&ia, 0, sizeof ia);
-  // the expert id of every received row sits in the row's 16-byte tail
-  ia.topk_idx = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(recv_dev) + (size_t)g->H * g->es);
-  ia.idx_stride = (int)(ld * g->es / 4);
-  ia.pair_valid = nullptr; ia.T = nrows; ia.K = 1; ia.E = E; ia.rows = 1; ia.capacity = 0; ia.shared = 0;
-  ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-  MirrorPlan mp;
-  drop_stale_prefetches(g, layer);
-  CHK(plan_mirror(g, layer, mp));
-  const int owned = std::max(1, g->owned_experts);
-  // Decode-sized exchange on the sync-free path: both FFN stages index for themselves from the row tails
-  // (launch_ffn_ep_stage) — no dispatch-index launch between the all-to-all and the weight stream.
-  static const bool selfindex_env = getenv("MOEINF_EP_SELFINDEX") ? atoi(getenv("MOEINF_EP_SELFINDEX")) != 0 : true;
-  if (selfindex_env && mp.fast && nrows <= 64 && (E - 1) / g->cfg.ep_size < 64) {
-    moeinf_engine::PendingMirror pm;
-    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = nrows; pm.prof = g->profiling; pm.local = false;
-    g->pend.push_back(pm);
-    for (int e = 0; e < E; ++e) {  // any of the layer's slots may be read by this forward
-      const Node& n = g->nodes[node_index(g, layer, e)];
-      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
-    }
-    CHK(flush_pokes(g, st));
-    FfnStage s1, s2;
-    fill_stage(g, layer, 1, s1, ld);
-    s1.in = recv_dev; s1.row_map = nullptr;
-    fill_stage(g, layer, 2, s2);
-    s2.out = y_dev; s2.out_map = nullptr;
-    EpOwnArgs o;
-    memset(&o, 0, sizeof o);
-    o.recv = recv_dev; o.ld_recv = ld; o.H = g->H; o.nrows = nrows; o.ep_size = g->cfg.ep_size; o.ep_rank = g->cfg.ep_rank;
-    o.max_active = std::min(owned, nrows);
-    o.rec = g->d_ep_rec;
-    if (pv) {
-      o.peers = *pv;
-      o.tile_done = g->d_arrive;
-      if (!pv->poll) {  // ranks sharing a GPU: one wave waits, the wide kernel starts when the rows are there
-        EpWait w{g->ep_win.recv_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
-        HIPCHK(launch_ep_wait(w, st));
-      }
-    }
-    moeinf_engine::ProfRec pr;
-    const bool prof = g->profiling;
-    if (prof) {
-      for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-      record_timing(pr.ev[0], st); record_timing(pr.ev[1], st); record_timing(pr.ev[2], st);
-    }
-    o.stage = 1; o.mirror = mp.target;
-    HIPCHK(launch_ffn_ep_stage(s1, o, st));
-    if (prof) record_timing(pr.ev[3], st);
-    o.stage = 2; o.mirror = nullptr;
-    HIPCHK(launch_ffn_ep_stage(s2, o, st));
-    if (prof) { record_timing(pr.ev[4], st); record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
-    g->st.forwards += 1;
-    g->seq += 1;
-    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-    return pump_if_pending(g);
-  }
-  ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
-  if (pv) {  // the generic kernels know nothing of the exchange: wait in front of them ...
-    EpWait w{g->ep_win.recv_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
-    HIPCHK(launch_ep_wait(w, st));
-  }
-  CHK(launch_index_auto(g, ia, st));
-  // stage 2 scatters every output row to its arrival position in y_dev (slot_pair: expert-sorted row -> received
-  // row), so the reply needs no un-sort pass
-  g->ovr_out = y_dev; g->ovr_map = g->d_slot_pair;
-  // profiling: only the two FFN stages are bracketed here (events 2..4); the other intervals are empty
-  moeinf_engine::ProfRec pr;
-  const bool prof = g->profiling;
-  if (prof) {
-    for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) { g->ovr_out = nullptr; g->ovr_map = nullptr; return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } }
-    record_timing(pr.ev[0], st); record_timing(pr.ev[1], st);
-  }
-  const int rc = dispatch_experts(g, layer, recv_dev, ld, nrows, std::min(owned, nrows),
-                                  (int)std::min<int64_t>(nrows, ((int64_t)nrows * 3) / (2 * owned) + 1), st, prof, prof ? &pr : nullptr, mp, nullptr, nullptr);
-  g->ovr_out = nullptr; g->ovr_map = nullptr;
-  if (rc != MOEINF_OK) return rc;
-  if (pv) HIPCHK(launch_ep_push(y_dev, recv_dev, ld, g->H, g->dt, *pv, st));  // ... and send their outputs home behind them
-  if (prof) { record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
-  g->st.forwards += 1;
-  g->seq += 1;
-  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-  return pump_if_pending(g);
-}
-
-static int ep_combine_impl(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream, const EpPeers* pv);
-extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream) {
-  return ep_combine_impl(g, x_dev, ret_dev, out_dev, cap_rows, stream, nullptr);
-}
-static int ep_combine_impl(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream, const EpPeers* pv) {
-  if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows (0 after ep_pack_compact)");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  if (g->has_shared && !g->last_hidden_shared) {
-    // the shared expert (always resident, replicated on every rank) runs on this rank's own tokens; for decode-sized
-    // forwards it already ran inside the router launches of moeinf_ep_route_pack, i.e. UNDER the exchange
-    const int T = g->last_T;
-    if (!g->shared_dev[g->last_layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", g->last_layer);
-    IndexArgs ia;
-    memset(&ia, 0, sizeof ia);
-    ia.T = T; ia.K = 1; ia.E = g->E;
-    ia.counts = g->d_counts; ia.offsets = g->d_offsets; ia.active = g->d_active; ia.n_active = g->d_n_active;
-    ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair;
-    HIPCHK(launch_shared_only_index(ia, st));
-    FfnStage s1, s2;
-    fill_stage(g, g->last_layer, 1, s1);
-    s1.in = x_dev;
-    fill_stage(g, g->last_layer, 2, s2);
-    s1.n_active_host = 1; s2.n_active_host = 1;
-    HIPCHK(launch_ffn_stage(s1, 1, T, st));
-    HIPCHK(launch_ffn_stage(s2, 1, T, st));
-  }
-  CombineArgs ca;
-  memset(&ca, 0, sizeof ca);
-  ca.x = x_dev; ca.y = ret_dev; ca.out = out_dev;
-  ca.topk_idx = g->d_topk_idx; ca.topk_w = g->d_topk_w; ca.pair_slot = g->d_ep_pair_pos; ca.pair_order = g->d_pair_order;
-  ca.router_prob = g->d_router_prob; ca.y_shared = g->has_shared ? (g->last_hidden_shared ? g->d_y_sh : g->d_y) : nullptr; ca.shared_offsets = nullptr; ca.shared_E = g->E;
-  ca.T = g->last_T; ca.H = g->H; ca.K = g->K; ca.kind = g->cfg.router_kind; ca.dtype = g->dt;
-  if (pv) {  // the owners' outputs of exchange `epoch` must have landed in this rank's return region
-    EpWait w{g->ep_win.ret_flags(), pv->size, pv->epoch, pv->timeout_ticks, pv->err};
-    if (pv->poll) { HIPCHK(launch_combine(ca, st, &w)); return MOEINF_OK; }
-    HIPCHK(launch_ep_wait(w, st));
-  }
-  HIPCHK(launch_combine(ca, st));
-  return MOEINF_OK;
-}
-
-// ---- native transport of the exchange (ep_comm.h) ---------------------------------------------------------------
-extern "C" int moeinf_ep_comm_available(int32_t* available) {
-  if (!available) return fail(MOEINF_ERR_INVALID, "available is NULL");
-  std::string err;
-  *available = RcclApi::get(&err) ? 1 : 0;
-  if (!*available) g_err = err;
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_comm_unique_id(void* id_out, int nbytes) {
-  if (!id_out || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "id_out must hold %d bytes", (int)sizeof(RcclUniqueId));
-  std::string err;
-  const RcclApi* api = RcclApi::get(&err);
-  if (!api) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
-  RcclUniqueId id;
-  const int rc = api->GetUniqueId(&id);
-  if (rc) return fail(MOEINF_ERR_HIP, "ncclGetUniqueId: %s", api->GetErrorString(rc));
-  memcpy(id_out, &id, sizeof id);
-  return MOEINF_OK;
-}
-
-static void ep_comm_free_buffers(moeinf_engine* g) {
-  void** bufs[] = {&g->ep_x_send, &g->ep_x_ret};
-  for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-  if (g->ep_x_recv && !g->ep_win.base) { (void)hipFree(g->ep_x_recv); g->ep_x_recv = nullptr; }  // (shared with the peer-store transport)
-  if (g->ep_x_y && !g->ep_win.base) { (void)hipFree(g->ep_x_y); g->ep_x_y = nullptr; }  // (shared with the peer-store transport)
-  g->ep_cap_tokens = 0; g->ep_x_cap_rows = 0;
-}
-// Everything of the RCCL bootstrap that can fail on ONE rank, with no collective inside (round-3 advice: a rank that failed
-// here used to return while the others blocked in ncclCommInitRank): validation, library binding, exchange buffers.  The
-// host layer agrees on the outcome of this step before any rank enters moeinf_ep_comm_init.
-extern "C" int moeinf_ep_comm_prepare(moeinf_engine* g, int cap_tokens) {
-  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  if (cap_tokens <= 0 || cap_tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "cap_tokens %d not in 1..max_tokens(%d)", cap_tokens, g->cfg.max_tokens);
-  if (g->ep_comm) return fail(MOEINF_ERR_STATE, "the engine already has a communicator");
-  std::string err;
-  if (!RcclApi::get(&err)) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  // exchange buffers: cap_rows row slots per peer, both directions (send/recv rows carry the 16-byte id tail)
-  const int cap_rows = ep_min_cap(g, cap_tokens);
-  const size_t n = (size_t)g->cfg.ep_size * cap_rows;
-  if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
-  if (g->ep_x_cap_rows == cap_rows && g->ep_x_send) return MOEINF_OK;  // prepared already
-  if (g->ep_win.base && cap_rows != g->ep_win.cap_rows) return fail(MOEINF_ERR_STATE, "the peer-store window was built for another cap_tokens");
-  ep_comm_free_buffers(g);
-  hipError_t e = hipMalloc(&g->ep_x_send, n * ep_row_elems(g) * g->es);
-  if (e == hipSuccess && !g->ep_x_recv) e = hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es);
-  if (e == hipSuccess && !g->ep_x_y) e = hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es);
-  if (e == hipSuccess) e = hipMalloc(&g->ep_x_ret, n * (size_t)g->H * g->es);
-  if (e == hipSuccess) e = hipMemset(g->ep_x_y, 0, n * (size_t)g->H * g->es);  // padding rows travel as they are: keep them defined
-  if (e != hipSuccess) { ep_comm_free_buffers(g); (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "exchange buffers: %s", hipGetErrorString(e)); }
-  g->ep_cap_tokens = cap_tokens;
-  g->ep_x_cap_rows = cap_rows;
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_comm_init(moeinf_engine* g, const void* unique_id, int nbytes, int cap_tokens) {
-  if (!g || !unique_id || nbytes != (int)sizeof(RcclUniqueId)) return fail(MOEINF_ERR_INVALID, "unique_id must be %d bytes", (int)sizeof(RcclUniqueId));
-  CHK(moeinf_ep_comm_prepare(g, cap_tokens));  // (no-op after an explicit prepare with the same cap_tokens)
-  const RcclApi* api = RcclApi::get(nullptr);
-  RcclUniqueId id;
-  memcpy(&id, unique_id, sizeof id);
-  const int rc = api->CommInitRank(&g->ep_comm, g->cfg.ep_size, id, g->cfg.ep_rank);
-  if (rc) {
-    g->ep_comm = nullptr;
-    ep_comm_free_buffers(g);
-    return fail(MOEINF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", g->cfg.ep_rank, g->cfg.ep_size, api->GetErrorString(rc));
-  }
-  g->ep_use_peer = false;
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_all_to_all(moeinf_engine* g, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream) {
-  if (!g || !send_dev || !recv_dev || bytes_per_peer <= 0) return fail(MOEINF_ERR_INVALID, "bad all_to_all arguments");
-  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no communicator: call moeinf_ep_comm_init first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  const std::string err = rccl_all_to_all(RcclApi::get(nullptr), g->ep_comm, g->cfg.ep_size, send_dev, recv_dev, (size_t)bytes_per_peer, (hipStream_t)stream);
-  if (!err.empty()) return fail(MOEINF_ERR_HIP, "%s", err.c_str());
-  return MOEINF_OK;
-}
-
-// ---- direct peer-store exchange (ep_peer.h) ------------------------------------------------------------------------
-// Bootstrap, every step LOCAL (a rank that fails returns an error and leaves nobody blocked in a collective; the host layer
-// agrees on the outcome between the steps): export -> [exchange the blobs] -> attach -> selftest.
-extern "C" int moeinf_ep_peer_export(moeinf_engine* g, int cap_tokens, void* blob_out, int nbytes) {
-  if (!g || !blob_out || nbytes != kEpPeerBlobBytes) return fail(MOEINF_ERR_INVALID, "blob_out must hold %d bytes", kEpPeerBlobBytes);
-  if (cap_tokens <= 0 || cap_tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "cap_tokens %d not in 1..max_tokens(%d)", cap_tokens, g->cfg.max_tokens);
-  if (g->ep_win.base) {  // a second host-side exchange object over the same engine: hand out the same window again
-    if (cap_tokens != g->ep_win_cap_tokens) return fail(MOEINF_ERR_STATE, "the engine already has an exchange window for cap_tokens %d", g->ep_win_cap_tokens);
-    EpPeerBlob b;
-    const std::string err = g->ep_win.export_blob(g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id, &b);
-    if (!err.empty()) return fail(MOEINF_ERR_HIP, "%s", err.c_str());
-    memset(blob_out, 0, kEpPeerBlobBytes);
-    memcpy(blob_out, &b, sizeof b);
-    return MOEINF_OK;
-  }
-  if (g->cfg.ep_size > EP_MAX_PEERS) return fail(MOEINF_ERR_UNSUPPORTED, "peer-store exchange: ep_size %d > %d", g->cfg.ep_size, EP_MAX_PEERS);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  const int cap_rows = ep_min_cap(g, cap_tokens);
-  const size_t n = (size_t)g->cfg.ep_size * cap_rows;
-  if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
-  if (g->ep_x_send && g->ep_x_cap_rows != cap_rows)  // staging buffers of a communicator prepared for another capacity would be re-used below
-    return fail(MOEINF_ERR_STATE, "the RCCL exchange buffers were built for another cap_tokens (cap_rows %d, wanted %d)", g->ep_x_cap_rows, cap_rows);
-  if (!g->ep_err_host) {
-    if (hipHostMalloc((void**)&g->ep_err_host, 64, hipHostMallocDefault) != hipSuccess) { g->ep_err_host = nullptr; (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "pinned error word"); }
-    *g->ep_err_host = 0;
-    if (const char* ev = getenv("MOEINF_EP_ERR_CHECK_EVERY")) g->ep_err_every = (uint32_t)std::max(1, atoi(ev));
-  }
-  std::string err = g->ep_win.create(g->cfg.ep_size, cap_rows, ep_row_elems(g) * g->es, (int64_t)g->H * g->es, g->E);
-  if (err.empty() && !g->ep_x_recv) {  // routed-form staging of the broadcast form's slow path (launch_ep_bcast_unpack)
-    if (hipMalloc(&g->ep_x_recv, n * ep_row_elems(g) * g->es) != hipSuccess) { g->ep_x_recv = nullptr; err = "hipMalloc of the unpack staging buffer failed"; }
-  }
-  if (err.empty() && !g->ep_x_y) {  // staging of the owner's outputs on the generic path (more rows than the self-indexing kernels take)
-    if (hipMalloc(&g->ep_x_y, n * (size_t)g->H * g->es) != hipSuccess) { g->ep_x_y = nullptr; err = "hipMalloc of the output staging buffer failed"; }
-  }
-  EpPeerBlob b;
-  if (err.empty()) err = g->ep_win.export_blob(g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id, &b);
-  if (!err.empty()) { g->ep_win.destroy(); (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "%s", err.c_str()); }
-  memset(blob_out, 0, kEpPeerBlobBytes);
-  memcpy(blob_out, &b, sizeof b);
-  g->ep_win_cap_tokens = cap_tokens;
-  const char* t = getenv("MOEINF_EP_PEER_TIMEOUT_MS");
-  g->ep_peer_timeout_ticks = (int64_t)(t ? atoll(t) : 10000) * 100000;  // wall_clock64: 100 MHz
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_peer_attach(moeinf_engine* g, const void* blobs, int nbytes) {
-  if (!g || !blobs) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (nbytes != g->cfg.ep_size * kEpPeerBlobBytes) return fail(MOEINF_ERR_INVALID, "blobs must be ep_size * %d bytes, in rank order", kEpPeerBlobBytes);
-  if (!g->ep_win.base) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_export first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  std::vector<EpPeerBlob> bs(g->cfg.ep_size);
-  for (int p = 0; p < g->cfg.ep_size; ++p) memcpy(&bs[p], (const char*)blobs + (size_t)p * kEpPeerBlobBytes, sizeof(EpPeerBlob));
-  if (g->ep_win.attached) {  // again (see moeinf_ep_peer_export): the same peers, or an error
-    for (int p = 0; p < g->cfg.ep_size; ++p)
-      if (bs[p].magic != kEpPeerMagic || bs[p].rank != p || bs[p].pid != g->ep_peer_pids[p] || bs[p].ptr != g->ep_peer_ptrs[p])
-        return fail(MOEINF_ERR_STATE, "the engine is attached to other peers already");
-    g->ep_use_peer = true;
-    return MOEINF_OK;
-  }
-  const std::string err = g->ep_win.attach(bs.data(), g->cfg.ep_rank, g->cfg.ep_size, g->cfg.device_id);
-  if (!err.empty()) { (void)hipGetLastError(); return fail(MOEINF_ERR_HIP, "%s", err.c_str()); }
-  // ranks that share a GPU (tests on a one-GPU box) must not spin inside wide kernels — the rank they wait for needs CUs
-  // to run on; MOEINF_EP_PEER_POLL=0/1 overrides.  Both, and MOEINF_EP_BCAST, are GROUP decisions: every rank derives them
-  // from all ranks' blobs (ep_peer.h: attach), so that no two ranks can end up in different exchange forms.
-  g->ep_peer_poll = g->ep_win.poll_agreed;
-  g->ep_bcast_ok = g->ep_win.bcast_agreed;
-  g->ep_peer_pids.clear(); g->ep_peer_ptrs.clear();
-  for (auto& b : bs) { g->ep_peer_pids.push_back(b.pid); g->ep_peer_ptrs.push_back(b.ptr); }
-  g->ep_use_peer = true;
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_peer_set_timeout_ms(moeinf_engine* g, int ms) {
-  if (!g || ms <= 0) return fail(MOEINF_ERR_INVALID, "engine is NULL or ms <= 0");
-  g->ep_peer_timeout_ticks = (int64_t)ms * 100000;  // wall_clock64: 100 MHz
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_peer_release(moeinf_engine* g) {
-  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  HIPCHK(hipDeviceSynchronize());  // no kernel of this rank still reads or writes a window
-  g->ep_win.destroy();
-  g->ep_win_cap_tokens = 0;
-  g->ep_use_peer = false;
-  g->ep_peer_pids.clear(); g->ep_peer_ptrs.clear();
-  if (!g->ep_x_send) {  // the staging buffers belong to this transport alone (no communicator prepared)
-    for (void** b : {&g->ep_x_recv, &g->ep_x_y}) if (*b) { (void)hipFree(*b); *b = nullptr; }
-  }
-  return MOEINF_OK;
-}
-
-// which bootstrapped transport moeinf_ep_moe_forward takes (the last one set up is the default)
-extern "C" int moeinf_ep_select_transport(moeinf_engine* g, int kind) {
-  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  if (kind == MOEINF_EP_TRANSPORT_PEER_STORE) { if (!g->ep_win.attached) return fail(MOEINF_ERR_STATE, "peer-store exchange is not set up"); g->ep_use_peer = true; return MOEINF_OK; }
-  if (kind == MOEINF_EP_TRANSPORT_RCCL) { if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no RCCL communicator"); g->ep_use_peer = false; return MOEINF_OK; }
-  return fail(MOEINF_ERR_INVALID, "kind must be MOEINF_EP_TRANSPORT_PEER_STORE or MOEINF_EP_TRANSPORT_RCCL");
-}
-
-static void ep_peer_view(moeinf_engine* g, EpPeers* pv) {
-  g->ep_win.view(pv, g->cfg.ep_rank, g->cfg.ep_size, g->d_miss, g->ep_peer_timeout_ticks, g->ep_peer_poll);
-}
-
-// Collective in effect (every rank must call it the same number of times), but bounded: a rank whose peers never
-// show up gets ok = 0 after the poll timeout instead of a hang.
-extern "C" int moeinf_ep_peer_selftest(moeinf_engine* g, void* stream, int32_t* ok) {
-  if (!g || !ok) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  *ok = 0;
-  if (!g->ep_win.attached) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_attach first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  g->ep_win.epoch += 1;
-  EpPeers pv;
-  ep_peer_view(g, &pv);
-  const int words = (int)std::min<int64_t>(1024, std::min(pv.recv_row_bytes, pv.ret_row_bytes) * pv.cap_rows / 4);
-  int32_t* ok_dev = g->ep_win.done + 8;  // a spare word of the counter allocation
-  HIPCHK(hipMemsetAsync(ok_dev, 0, 4, st));
-  // fault injection for the liveness tests (tests/test_gpu_bench_ranks.py): this rank never publishes — what a rank behind a
-  // dead link looks like to its peers; they must come out of their self-test with ok = 0 after the bounded wait
-  const char* silent = getenv("MOEINF_EP_TEST_SILENT_RANK");
-  if (!silent || atoi(silent) != g->cfg.ep_rank) HIPCHK(launch_ep_selftest_send(pv, words, st));
-  HIPCHK(launch_ep_selftest_check(pv, words, ok_dev, st));
-  HIPCHK(hipMemcpyAsync(ok, ok_dev, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  int32_t f = 0;
-  HIPCHK(hipMemcpy(&f, g->d_miss, 4, hipMemcpyDeviceToHost));
-  if (f) { HIPCHK(hipMemset(g->d_miss, 0, 4)); *ok = 0; }
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_transport(const moeinf_engine* g, int32_t out[4]) {
-  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  out[0] = (g->ep_win.attached && g->ep_use_peer) ? MOEINF_EP_TRANSPORT_PEER_STORE : (g->ep_comm ? MOEINF_EP_TRANSPORT_RCCL : MOEINF_EP_TRANSPORT_NONE);
-  out[1] = g->ep_win.shared_device ? 1 : 0;
-  out[2] = g->ep_peer_poll ? 1 : 0;
-  out[3] = (int32_t)g->ep_win.epoch;
-  return MOEINF_OK;
-}
-
-// The caller's promise that EVERY rank passes the same token count to every moeinf_ep_moe_forward (decode loops do): with it,
-// a one-token forward over the peer-store transport takes the BROADCAST form (kernels.h: EpBcastArgs) — all ranks must then be
-// in that form together, which is why it cannot be inferred from this rank's own token count.
-extern "C" int moeinf_ep_set_uniform_tokens(moeinf_engine* g, int on) {
-  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  g->ep_uniform = on != 0;
-  return MOEINF_OK;
-}
-
-static bool ep_bcast_eligible(const moeinf_engine* g, int tokens) {
-  const bool env = g->ep_bcast_ok;  // (MOEINF_EP_BCAST of EVERY rank, see moeinf_ep_peer_attach)
-  const int et = g->cfg.expert_type;
-  // consumer kernels must poll for themselves (the broadcast rides in FFN stage 1: no room for a wait kernel in front of it)
-  return env && g->ep_uniform && tokens == 1 && g->ep_peer_poll && g->K <= 8 && g->E <= 64 && g->dt != DT_F32 &&
-         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
-         (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || can_hide_shared(g, 1));
-}
-
-// Batch-1 decode over the peer-store exchange, broadcast form: gate -> FFN stage 1 (block 0 broadcasts this rank's row +
-// logits and routes the home token; the other workgroups wait for every rank's broadcast, route all ep_size tokens and stream
-// the experts this rank owns) -> stage 2 (outputs stored into the home ranks' windows) -> combine.  FOUR launches.  If an
-// owned expert is not resident the host must see the routing: the broadcast becomes a launch of its own, an unpack kernel
-// turns the received (row, logits) pairs into the routed form locally and the generic owner path takes over.
-static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev, const void* gate_w_dev, void* out_dev, void* stream) {
-  if (!x_dev || !gate_w_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
-  if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  hipStream_t st = (hipStream_t)stream;
-  const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
-  const int64_t ld = ep_row_elems(g);
-  moeinf_engine::EpProfRec pr;
-  const bool prof = g->ep_profiling;
-  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
-  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-  CHK(ep_alloc(g, cap));
-  EpPeers pv;  // (the exchange number was taken by ep_peer_forward)
-  ep_peer_view(g, &pv);
-  RouteArgs ra;
-  make_route_args(g, x_dev, gate_w_dev, 1, ra);
-  drop_stale_prefetches(g, layer);
-  MirrorPlan mp;
-  CHK(plan_mirror(g, layer, mp));
-  EpBcastArgs b;
-  memset(&b, 0, sizeof b);
-  b.x = x_dev; b.pair_pos = g->d_ep_pair_pos; b.peers = pv;
-  g->last_T = 1; g->last_layer = layer; g->last_stream = st; g->last_selfroute = false;
-  mark(0);
-  if (mp.fast) {
-    const bool hide = g->has_shared;  // (eligibility says it can be hidden)
-    FfnStage sh1, sh2;
-    if (hide) { hidden_shared_stages(g, layer, x_dev, sh1, sh2); HIPCHK(launch_gate_shared1(ra, sh1, st)); }
-    else HIPCHK(launch_gate_logits(ra, st));
-    g->last_hidden_shared = hide;
-    moeinf_engine::PendingMirror pm;
-    pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = G; pm.prof = false; pm.local = false;
-    g->pend.push_back(pm);
-    for (int e = 0; e < g->E; ++e) {  // any of the layer's slots may be read by this forward
-      const Node& n = g->nodes[node_index(g, layer, e)];
-      if (n.slot >= 0) g->slots[n.slot].last_use_seq = g->seq + 1;
-    }
-    CHK(flush_pokes(g, st));
-    FfnStage s1, s2;
-    fill_stage(g, layer, 1, s1, ld);
-    s1.in = g->ep_win.recv_region(); s1.row_map = nullptr;
-    fill_stage(g, layer, 2, s2);
-    s2.out = g->ep_x_y; s2.out_map = nullptr;
-    b.mirror = mp.target;
-    const int per_rank = (g->E + G - 1) / G;
-    const int max_active = std::max(1, std::min(std::max(1, g->owned_experts), G * std::min(g->K, per_rank)));
-    mark(1); mark(2);
-    HIPCHK(launch_ffn_epb_stage1(ra, s1, hide ? &sh2 : nullptr, b, g->d_ep_rec, max_active, 1, st));
-    EpOwnArgs o;
-    memset(&o, 0, sizeof o);
-    o.recv = g->ep_win.recv_region(); o.ld_recv = ld; o.H = g->H; o.nrows = std::min(64, G * cap); o.ep_size = G; o.ep_rank = g->cfg.ep_rank;
-    o.stage = 2; o.max_active = max_active; o.rec = g->d_ep_rec; o.peers = pv; o.tile_done = g->d_arrive;
-    HIPCHK(launch_ffn_ep_stage(s2, o, st));
-    g->st.forwards += 2;  // (home routing + owner FFN, as the routed form counts them)
-    g->seq += 1;
-    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-    mark(3);
-  } else {
-    // plan_mirror handed out the engine's own mirror (nothing pooled to give back); the generic owner path plans again
-    HIPCHK(launch_gate_logits(ra, st));
-    g->last_hidden_shared = false;  // the shared expert runs on the home rank inside the combine step
-    HIPCHK(launch_ep_bcast(ra, b, st));
-    g->st.forwards += 1;
-    mark(1); mark(2);
-    HIPCHK(launch_ep_bcast_unpack(ra, b, g->ep_x_recv, ld, g->dt, st));
-    EpPeers pvw = pv;  // (the unpack kernel has waited already; the generic path's wait kernel returns at once)
-    CHK(ep_expert_ffn_rows(g, layer, g->ep_x_recv, g->ep_x_y, G * cap, st, &pvw));
-    mark(3);
-  }
-  mark(4);
-  CHK(ep_combine_impl(g, x_dev, g->ep_win.ret_region(), out_dev, cap, stream, &pv));
-  mark(5);
-  if (prof) g->ep_prof_pending.push_back(pr);
-  return mp.fast ? pump_if_pending(g) : MOEINF_OK;
-}
-
-// One expert-parallel MoE layer over the peer-store exchange: router (+ pack into the destinations' windows) -> owner FFN
-// (polls the row flags; stage 2 stores its outputs into the home ranks' windows) -> combine (polls the output flags).
-// Five launches on `stream`, no collective, no copy.
-static int ep_peer_forward_body(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream);
-
-// Exchange numbers are failure-atomic: EVERY entry takes the next number before anything can fail, so a rank whose call
-// returns an error (bad arguments, an allocation) is not one exchange behind its peers for good — its peers' kernels give
-// up on the exchange it never published (flag 2 after MOEINF_EP_PEER_TIMEOUT_MS), and a rank that IS out of step is
-// caught by the consumers themselves (a flag AHEAD of the exchange they wait for: flag 3, kdev.h ep_poll).  The device flag
-// is copied to a pinned word by the stream every ep_err_every exchanges and looked at on entry: a caller that never
-// calls moeinf_sync() still gets the error from one of its next forwards instead of silent garbage.
-static int ep_peer_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
-  g->ep_win.epoch += 1;  // collective discipline: every rank runs the same sequence of exchanges
-  if (g->ep_err_host) {
-    const int32_t f = *(volatile int32_t*)g->ep_err_host;
-    if (f == 2 || f == 3) {
-      *g->ep_err_host = 0;
-      return fail(MOEINF_ERR_STATE, f == 2 ? "peer-store exchange: a kernel gave up waiting for another rank's rows (MOEINF_EP_PEER_TIMEOUT_MS); the results of the last forwards are invalid"
-                                           : "peer-store exchange: another rank is AHEAD of this one (an earlier call failed here or there); the results of the last forwards are invalid");
-    }
-  }
-  const int rc = ep_peer_forward_body(g, layer, x_dev, tokens, batch_rows, gate_w_dev, out_dev, stream);
-  if (rc == MOEINF_OK && g->ep_err_host && g->ep_win.epoch % g->ep_err_every == 0)
-    HIPCHK(hipMemcpyAsync(g->ep_err_host, g->d_miss, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  return rc;
-}
-
-static int ep_peer_forward_body(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev, void* out_dev, void* stream) {
-  if (tokens > g->ep_win_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the exchange window", tokens, g->ep_win_cap_tokens);
-  if (ep_bcast_eligible(g, tokens)) return ep_peer_forward_bcast(g, layer, x_dev, gate_w_dev, out_dev, stream);
-  hipStream_t st = (hipStream_t)stream;
-  const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
-  moeinf_engine::EpProfRec pr;
-  const bool prof = g->ep_profiling;
-  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
-  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-  EpPeers pv;
-  ep_peer_view(g, &pv);
-  mark(0);
-  CHK(ep_route_pack_impl(g, layer, x_dev, tokens, batch_rows, gate_w_dev, nullptr, nullptr, cap, stream, &pv));
-  mark(1);
-  mark(2);  // (no dispatch collective: the rows are already on their way)
-  CHK(ep_expert_ffn_rows(g, layer, g->ep_win.recv_region(), g->ep_x_y, G * cap, st, &pv));
-  mark(3);
-  mark(4);
-  CHK(ep_combine_impl(g, x_dev, g->ep_win.ret_region(), out_dev, cap, stream, &pv));
-  mark(5);
-  if (prof) g->ep_prof_pending.push_back(pr);
-  return MOEINF_OK;
-}
-
-// One expert-parallel MoE layer in ONE host call (fixed-capacity form): router + send rows -> all-to-all -> owner FFN ->
-// all-to-all -> combine, every launch and both collectives enqueued on `stream` from here.
-extern "C" int moeinf_ep_moe_forward(moeinf_engine* g, int layer, const void* x_dev, int tokens, int batch_rows, const void* gate_w_dev,
-                                     void* out_dev, void* stream) {
-  if (!g || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  if (g->ep_win.attached && (g->ep_use_peer || !g->ep_comm)) return ep_peer_forward(g, layer, x_dev, tokens, batch_rows, gate_w_dev, out_dev, stream);
-  if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no transport: call moeinf_ep_peer_export + moeinf_ep_peer_attach, or moeinf_ep_comm_init, first");
-  if (tokens > g->ep_cap_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d > cap_tokens %d of the communicator's exchange buffers", tokens, g->ep_cap_tokens);
-  hipStream_t st = (hipStream_t)stream;
-  const RcclApi* api = RcclApi::get(nullptr);
-  const int cap = g->ep_x_cap_rows, G = g->cfg.ep_size;
-  moeinf_engine::EpProfRec pr;
-  const bool prof = g->ep_profiling;
-  auto mark = [&](int i) { if (prof) record_timing(pr.ev[i], st); };
-  if (prof) for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); }
-  mark(0);
-  CHK(moeinf_ep_route_pack(g, layer, x_dev, tokens, batch_rows, gate_w_dev, g->ep_x_send, nullptr, cap, stream));
-  mark(1);
-  std::string err = rccl_all_to_all(api, g->ep_comm, G, g->ep_x_send, g->ep_x_recv, (size_t)cap * ep_row_elems(g) * g->es, st);
-  if (!err.empty()) return fail(MOEINF_ERR_HIP, "dispatch all-to-all: %s", err.c_str());
-  mark(2);
-  CHK(moeinf_ep_expert_ffn(g, layer, g->ep_x_recv, g->ep_x_y, cap, stream));
-  mark(3);
-  err = rccl_all_to_all(api, g->ep_comm, G, g->ep_x_y, g->ep_x_ret, (size_t)cap * g->H * g->es, st);
-  if (!err.empty()) return fail(MOEINF_ERR_HIP, "combine all-to-all: %s", err.c_str());
-  mark(4);
-  CHK(moeinf_ep_combine(g, x_dev, g->ep_x_ret, out_dev, cap, stream));
-  mark(5);
-  if (prof) g->ep_prof_pending.push_back(pr);
-  return MOEINF_OK;
-}
-
-extern "C" int moeinf_ep_get_profile(moeinf_engine* g, moeinf_ep_profile* out) {
-  if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
-  if (g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
-  for (auto& r : g->ep_prof_pending) {
-    float ms = 0.f;
-    double* dst[5] = {&g->ep_prof.route_pack_ms, &g->ep_prof.a2a_dispatch_ms, &g->ep_prof.owner_ffn_ms, &g->ep_prof.a2a_combine_ms, &g->ep_prof.combine_ms};
-    for (int i = 0; i < 5; ++i) if (hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]) == hipSuccess) *dst[i] += ms;
-    for (int i = 0; i < 6; ++i) g->event_pool.push_back(r.ev[i]);
-    g->ep_prof.calls += 1;
-  }
-  g->ep_prof_pending.clear();
-  *out = g->ep_prof;
-  memset(&g->ep_prof, 0, sizeof g->ep_prof);
-  return MOEINF_OK;
-}

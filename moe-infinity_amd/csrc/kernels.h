@@ -1,5 +1,5 @@
 // kernels.h — launch wrappers of the gfx950 kernels (implemented in kernels.hip).
-// Host code (engine.cpp) sees only these plain-C++ declarations.
+// Host code (engine.cpp, engine_ep.cpp) sees only these plain-C++ declarations.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
