@@ -79,7 +79,9 @@ def test_deepseek_v2_lite_layer(t):
     gate = _gate(cfg.num_experts, cfg.hidden, torch.bfloat16, 4322, 0.02)
     x = acts(t, cfg.hidden, torch.bfloat16, 2025)
     expect_one_launch = t == 1 and os.environ.get("MOEINF_TEST_EXPECT_LAYER1") == "1"  # (test_one_launch_decode_layer_is_parity_green)
-    if expect_one_launch:
+    if expect_one_launch:  # the one-launch layer is a form of the SYNC-FREE path: every expert of the layer resident first
+        eng.prefetch(0, list(range(cfg.num_experts)))
+        eng.sync_copies()
         eng.set_profiling(True)
     for _ in range(2):
         out = eng.forward(0, x.to(DEV), gate.to(DEV))
