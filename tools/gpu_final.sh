@@ -14,7 +14,7 @@ grep -E "^(FAILED|ERROR)|passed|failed|pytest exit" "$OUT/pytest_gpu.log" | tail
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "bench exit $?"; tail -3 "$OUT/bench_default.err"
-LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1"
+LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1 --no-traffic"
 for wl in mixtral-8x7b deepseek-v2-lite; do
   tag=${wl//-/}; tag=${tag//./}
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/kt_$tag" -o m -- \

@@ -12,7 +12,7 @@ grep -E "^(FAILED|ERROR)|passed|failed|pytest exit" "$OUT/pytest_gpu.log" | tail
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 timeout 300 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "bench exit $?"; tail -2 "$OUT/bench_default.err"
-LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1"
+LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1 --no-traffic"
 (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/kt_mixtral8x7b" -o m -- \
     python "$R/bench.py" --workload mixtral-8x7b --steps 10 --warmup 2 $LEAN > "$R/$OUT/kt_bench_mixtral8x7b.json" 2> "$R/$OUT/kt_mixtral8x7b.err")
 python tools/rocprof_summary.py "$OUT/kt_mixtral8x7b/m_kernel_stats.csv" "$OUT/kernel_stats_mixtral8x7b.csv"

@@ -8,7 +8,7 @@ R=$(pwd)
 OUT=${1:-gpurun_out/profiles_run}
 mkdir -p "$OUT"
 python -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1
-LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1"
+LEAN="--no-cpu-baseline --no-other-configs --miss-heavy-frac 0 --windows 1 --no-traffic"
 for wl in mixtral-8x7b deepseek-v2-lite; do
   tag=${wl//-/}; tag=${tag//./}
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/kt_$tag" -o m -- \
