@@ -157,6 +157,11 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
       if (FILE* f = fopen(getenv("MOEINF_LAYER1_TRACE") ? getenv("MOEINF_LAYER1_TRACE") : "/dev/null", "w")) {
         std::vector<int32_t> tb((size_t)g->layer1_trace_blocks, 0);
         if (g->d_layer_tab) (void)hipMemcpy(tb.data(), g->d_layer_tab, tb.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        else  // the Switch form has no table: role = workgroup id (gate | meta | stage 1 | stage 2)
+          for (int b = 0; b < g->layer1_trace_blocks; ++b) {
+            const int n_rg = (g->F + 15) / 16;
+            tb[b] = b < g->E ? ((1 << 24) | b) : (b == g->E ? (3 << 24) : (b < g->E + 1 + n_rg ? ((4 << 24) | (b - g->E - 1)) : ((6 << 24) | (b - g->E - 1 - n_rg))));
+          }
         for (int b = 0; b < g->layer1_trace_blocks; ++b)  // "workgroup item role index t0 t1 t2 t3"
           if (tb[b]) fprintf(f, "%d %d %d %d %llu %llu %llu %llu\n", b / g->layer1_maxi, b % g->layer1_maxi, tb[b] >> 24, tb[b] & 0xffffff, tr[b * 4], tr[b * 4 + 1], tr[b * 4 + 2], tr[b * 4 + 3]);
         fclose(f);
@@ -178,7 +183,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_layer_ctr, g->d_layer_tab, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_layer_ctr, g->d_layer_tab, g->d_layer_part, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -1108,6 +1113,30 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
+    if (sr && sr->layer1_switch) {
+      LayerSync sy;
+      memset(&sy, 0, sizeof sy);
+      sy.ctr = g->d_layer_ctr; sy.launch = g->layer1_launches + 1; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
+      static const int l1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
+      sy.sleep = l1_sleep; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
+      static int ncu = 0;
+      if (!ncu) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
+      if (getenv("MOEINF_LAYER1_TRACE")) {
+        const int nb = g->E + 1 + (g->F + 15) / 16 + 4 * ((g->H + 15) / 16);
+        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; g->layer1_maxi = 1; }
+        sy.trace = g->d_layer_trace;
+      }
+      if (!g->d_layer_part) { if (hipMalloc((void**)&g->d_layer_part, (size_t)4 * g->H * sizeof(float)) != hipSuccess) { g->d_layer_part = nullptr; (void)hipGetLastError(); } }
+      sy.part = g->d_layer_part;
+      if (fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, st)) {
+        g->layer1_launches += 1;
+        if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
+        return MOEINF_OK;
+      }
+      (void)hipGetLastError();
+      g->last_layer1 = false;  // declined (fewer CUs than workgroups, ...): the three launches, starting with the gate the caller left out
+      HIPCHK(launch_gate_logits(*sr->ra, st));
+    }
     if (sr && sr->layer1) {
       if (!fuse || !sr->sh1 || !sr->sh2) return fail(MOEINF_ERR_STATE, "internal: the one-launch layer needs the fused combine and the hidden shared expert's stages");
       LayerSync sy;
@@ -1126,7 +1155,7 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
         if (hipMalloc((void**)&g->d_layer_tab, tab.size() * sizeof(int32_t)) != hipSuccess) { g->d_layer_tab = nullptr; (void)hipGetLastError(); return fail(MOEINF_ERR_OOM, "item table of the one-launch layer"); }
         HIPCHK(hipMemcpy(g->d_layer_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
       }
-      sy.tab = g->d_layer_tab; sy.maxi = g->layer1_maxi;
+      sy.tab = g->d_layer_tab; sy.maxi = g->layer1_maxi; sy.part = nullptr;
       if (getenv("MOEINF_LAYER1_TRACE")) {
         const int nb = g->layer1_nwg * g->layer1_maxi;
         if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
@@ -1284,13 +1313,17 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   static const bool layer1_env = getenv("MOEINF_LAYER1") ? atoi(getenv("MOEINF_LAYER1")) != 0 : false;
   const bool layer1 = layer1_env && selfroute && T == 1 && sr_gated && hide_shared && g->dt == DT_BF16 && !(flags & MOEINF_FWD_NO_COMBINE) &&
                       fuse_mode() != 0 && (getenv("MOEINF_FUSE_COMBINE") ? atoi(getenv("MOEINF_FUSE_COMBINE")) != 0 : true);
-  g->last_layer1 = layer1;
+  // Switch (top-1, no shared expert): the one-launch form is the DEFAULT — three launches of 3-10 us for 18.9 MB are pure fixed
+  // cost, and with hardly any traffic in flight a flag costs ~1 us (MOEINF_LAYER1_SWITCH=0: the three launches)
+  static const bool layer1s_env = getenv("MOEINF_LAYER1_SWITCH") ? atoi(getenv("MOEINF_LAYER1_SWITCH")) != 0 : true;
+  const bool layer1_switch = layer1s_env && selfroute && T == 1 && sr_switch && !sr_gated && !(flags & MOEINF_FWD_NO_COMBINE) && g->dt != DT_F16;
+  g->last_layer1 = layer1 || layer1_switch;
   FfnStage sh1, sh2;
   if (hide_shared) {
     hidden_shared_stages(g, layer, x_dev, sh1, sh2);
     ia.shared = 0;  // the index lists routed experts only
   }
-  if (layer1) {
+  if (layer1 || layer1_switch) {
     // nothing here: dispatch_experts launches the layer
   } else if (selfroute) {
     if (hide_shared) HIPCHK(launch_gate_shared1(ra, sh1, st));
@@ -1333,7 +1366,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK ||
                          (selfroute && sr_switch));  // (Switch: only the batch-1 stage 2 knows its combine)
   bool fused = false;
-  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1};
+  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1, layer1_switch};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        rows_estimate(T, K, E), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));

@@ -304,6 +304,7 @@ struct moeinf_engine {
   bool last_layer1 = false;         // ... and ran as ONE launch (layer_fused.hip)
   uint32_t* d_layer_ctr = nullptr;  // its counters (kernels.h LayerSync): only grow, zeroed at creation and after an error
   uint32_t layer1_launches = 0;
+  float* d_layer_part = nullptr;    // [4][H] partial sums of the Switch form's split stage 2
   int32_t* d_layer_tab = nullptr;   // item table of the persistent one-launch layer (built at the first launch)
   int layer1_nwg = 0, layer1_maxi = 0;
   bool layer1_scalar_poll = false;
@@ -358,6 +359,7 @@ struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn
   const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
   const FfnStage* sh1 = nullptr;  // layer1: its stage 1
   bool layer1 = false;  // the whole layer as ONE launch (launch_moe_layer1): the caller has NOT launched the gate
+  bool layer1_switch = false;  // ... its Switch form (launch_moe_layer1_switch); if that declines, dispatch_experts launches the gate itself
 };
 
 template <typename T>

@@ -249,6 +249,7 @@ struct LayerSync {
   int scalar_poll;            // 1: the counters are polled with scalar loads (they live in uncached memory); 0: agent-scope vector loads
   const int32_t* tab;         // item table [workgroups][maxi] (layer1_table), device memory
   int maxi;
+  float* part;                // Switch form: [4][H] fp32 partial sums of the split stage-2 reduction
 };
 }  // namespace moeinf
 #include <vector>
@@ -257,6 +258,9 @@ int layer1_table(int E, int K, int H, int F, int Fs, int elem_bytes, int gate_by
 int layer1_wgs_per_cu(int gate_dtype);
 hipError_t launch_moe_layer1(const RouteArgs& r, const IndexArgs& a, const FfnStage& sh1, const FfnStage& sh2, const FfnStage& s1, const FfnStage& s2,
                              const LayerSync& sy, int nwg, hipStream_t st);
+// the Switch form (top-1, plain experts, no shared expert): E + 1 + F/16 + 4 * H/16 workgroups of eight waves, all resident at once;
+// false: not handled (the caller runs the three launches)
+bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, hipStream_t st);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wait = nullptr);  // wait: poll these flags first (peer-store exchange)
 // out[i] = valid[i] ? idx[i] : -1

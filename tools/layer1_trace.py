@@ -2,7 +2,8 @@
 """Timeline of the one-launch decode layer (csrc/layer_fused.hip): runs a few DeepSeek-V2-Lite batch-1 forwards with
 MOEINF_LAYER1_TRACE set (the engine writes the per-workgroup timestamps of the LAST launch at destroy) and prints, per role,
 when its workgroups started / got past their waits / finished (microseconds after the first workgroup started).
-usage: layer1_trace.py [out.txt]   (extra MOEINF_* knobs are taken from the environment)"""
+usage: layer1_trace.py [--switch] [out.txt]   (--switch: Switch-base-8, the one-launch form that is its default; extra MOEINF_*
+knobs are taken from the environment; DeepSeek needs MOEINF_LAYER1=1)"""
 import os, statistics, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -10,7 +11,7 @@ import sys, torch
 sys.path.insert(0, %r)
 from moe_infinity_amd import MoEEngine, config as Cf
 from oracle.synth import acts
-cfg = Cf.deepseek_v2_lite(device_memory_ratio=0.5, max_tokens=1)
+cfg = (Cf.switch_base_8 if sys.argv[1] == "switch" else Cf.deepseek_v2_lite)(device_memory_ratio=0.5, max_tokens=1)
 cfg.num_layers = 2
 eng = MoEEngine(cfg)
 dev = torch.device("cuda:0")
@@ -18,12 +19,14 @@ off, siz, tot = eng.expert_layout(0)
 for l in range(2):
     for e in range(cfg.num_experts):
         eng.register_expert(l, e, None)
-        eng.expert_host_view(l, e).view(eng.dtype).copy_(torch.empty(tot // 2, dtype=eng.dtype, device=dev).normal_(0, 0.02))
-    _, sizs, _ = eng.expert_layout(1)
-    eng.register_shared(l, [torch.empty(s // 2, dtype=eng.dtype).normal_(0, 0.02) for s in sizs])
+        es = 4 if eng.dtype == torch.float32 else 2
+        eng.expert_host_view(l, e).view(eng.dtype).copy_(torch.empty(tot // es, dtype=eng.dtype, device=dev).normal_(0, 0.02))
+    if cfg.shared_inter:
+        _, sizs, _ = eng.expert_layout(1)
+        eng.register_shared(l, [torch.empty(s // 2, dtype=eng.dtype).normal_(0, 0.02) for s in sizs])
     eng.prefetch(l, list(range(cfg.num_experts)))
 eng.sync_copies()
-gates = [(torch.randn(cfg.num_experts, cfg.hidden, device=dev) * 0.02).to(eng.gate_dtype) for _ in range(2)]
+gates = [(torch.randn(cfg.num_experts, cfg.hidden, device=dev) * (0.5 if sys.argv[1] == "switch" else 0.02)).to(eng.gate_dtype) for _ in range(2)]
 x = acts(1, cfg.hidden, eng.dtype, 11).to(dev)
 out = torch.empty(1, cfg.hidden, dtype=eng.dtype, device=dev)
 for i in range(40):
@@ -35,7 +38,10 @@ eng.close()
 def main():
     path = tempfile.mktemp(suffix=".l1trace")
     env = dict(os.environ, MOEINF_LAYER1_TRACE=path)
-    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+    model = "switch" if "--switch" in sys.argv else "deepseek"
+    if "--switch" in sys.argv:
+        sys.argv.remove("--switch")
+    r = subprocess.run([sys.executable, "-c", CHILD, model], env=env, capture_output=True, text=True)
     if r.returncode or not os.path.exists(path):
         print("child failed:", r.stderr[-1500:]); return 1
     rows = [[int(v) for v in ln.split()] for ln in open(path)]  # workgroup item role index t0 t1 t2 t3
