@@ -142,8 +142,14 @@ def test_switch_base_8_layer_fp32(b, s):
     experts, _ = fill_layer_on_gpu(eng, "switch", 0, 4234)
     gate = _gate(cfg.num_experts, cfg.hidden, torch.float32, 4324, 0.5)
     x = acts(b * s, cfg.hidden, torch.float32, 2027).reshape(b, s, cfg.hidden)
+    if b * s == 1:  # batch-1 decode with every expert resident = the sync-free path = ONE launch per layer (round 5)
+        eng.prefetch(0, list(range(cfg.num_experts)))
+        eng.sync_copies()
+        eng.set_profiling(True)
     for _ in range(2):
         out = eng.forward(0, x.to(DEV), gate.to(DEV), batch_rows=b)
+    if b * s == 1 and os.environ.get("MOEINF_LAYER1_SWITCH", "1") != "0":
+        assert eng.profile()["fused_layers"] == 2, "Switch-base-8 batch-1 decode is expected to run as one launch per layer"
     ref = R.block_switch(x, gate, experts, expert_capacity=cfg.expert_capacity)
     r = _check_index(eng, ref)
     m = ref.router_mask.numpy()

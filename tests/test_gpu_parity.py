@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI, libmoeinf_hip.so) against the oracle and against the
 golden vectors produced by the reference's own Python blocks.  Needs an MI355X: -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -696,6 +698,44 @@ def test_batch1_decode_selfrouting_stage1(family, e, k, n_shared):
             outs.append(out.clone())
         assert torch.equal(outs[0], outs[1])
     assert eng.stats()["expert_misses"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32_switch_base_dtype", "bf16"])
+def test_batch1_switch_decode_is_one_launch_per_layer(dtype):
+    """Switch (top-1, plain ReLU experts) at batch 1 on the sync-free path: the whole layer is ONE launch
+    (csrc/layer_fused.hip moe_layer1_switch_kernel: gate | meta | self-routing stage 1 | stage 2 with its reduction split in
+    four and the combine in the tile's last arriver; round 5, default).  Against the oracle: top-1 index, router_prob, dispatch
+    index, expert rows (1 ulp), block output; a repeated forward is bit-identical; the profile says the one-launch form ran."""
+    h, f, e = 256, 384, 8
+    gate, experts, _ = make_weights("switch", h, f, e, 5100, dtype, gate_std=0.5)
+    eng = engine_for("switch", h, f, e, 1, dtype, max_tokens=4, expert_capacity=64)
+    register_all(eng, experts)
+    g = gate.to(DEV)
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    eng.set_profiling(True)
+    n = 0
+    for seed in range(6):
+        x = acts(1, h, dtype, 5200 + seed)
+        ref = R.block_switch(x[None], gate, experts, expert_capacity=64)
+        outs = []
+        for rep in range(2):
+            out = eng.forward(0, x.to(DEV), g, batch_rows=1)
+            n += 1
+            r = eng.routing()
+            m = ref.router_mask.numpy().reshape(1, e)
+            assert int(r["topk_idx"][0, 0]) == int(m.argmax(-1)[0]), "top-1 must be bit-exact"
+            _check_dispatch_index(r, ref)
+            rows = oracle_expert_rows(ref, e)
+            assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dtype, "expert FFN outputs (stage-2 reduction split in four)")
+            assert_block_close(out, ref, dtype, "switch batch-1 block output, one launch")
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1])
+    assert eng.stats()["expert_misses"] == 0
+    prof = eng.profile()
+    if os.environ.get("MOEINF_LAYER1_SWITCH", "1") != "0":
+        assert prof["fused_layers"] == n, (prof["fused_layers"], n)
     eng.close()
 
 
