@@ -157,11 +157,22 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
       if (FILE* f = fopen(getenv("MOEINF_LAYER1_TRACE") ? getenv("MOEINF_LAYER1_TRACE") : "/dev/null", "w")) {
         std::vector<int32_t> tb((size_t)g->layer1_trace_blocks, 0);
         if (g->d_layer_tab) (void)hipMemcpy(tb.data(), g->d_layer_tab, tb.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
-        else  // the Switch form has no table: role = workgroup id (gate | meta | stage 1 | stage 2)
+        else {  // no table: role = workgroup id (gate | shared stage 1 | meta | stage 1 | shared stage 2 (front) or stage 2 (Switch form))
+          const int n_rg = (g->F + 15) / 16, n_sh1 = g->has_shared ? (g->Fs + 15) / 16 : 0;
+          const bool sw = g->cfg.router_kind == MOEINF_ROUTER_SWITCH;
           for (int b = 0; b < g->layer1_trace_blocks; ++b) {
-            const int n_rg = (g->F + 15) / 16;
-            tb[b] = b < g->E ? ((1 << 24) | b) : (b == g->E ? (3 << 24) : (b < g->E + 1 + n_rg ? ((4 << 24) | (b - g->E - 1)) : ((6 << 24) | (b - g->E - 1 - n_rg))));
+            int c = b;
+            if (c < g->E) { tb[b] = (1 << 24) | c; continue; }
+            c -= g->E;
+            if (c < n_sh1) { tb[b] = (2 << 24) | c; continue; }
+            c -= n_sh1;
+            if (c == 0) { tb[b] = 3 << 24; continue; }
+            c -= 1;
+            if (c < g->K * n_rg) { tb[b] = (4 << 24) | c; continue; }
+            c -= g->K * n_rg;
+            tb[b] = ((sw ? 6 : 5) << 24) | c;
           }
+        }
         for (int b = 0; b < g->layer1_trace_blocks; ++b)  // "workgroup item role index t0 t1 t2 t3"
           if (tb[b]) fprintf(f, "%d %d %d %d %llu %llu %llu %llu\n", b / g->layer1_maxi, b % g->layer1_maxi, tb[b] >> 24, tb[b] & 0xffffff, tr[b * 4], tr[b * 4 + 1], tr[b * 4 + 2], tr[b * 4 + 3]);
         fclose(f);
@@ -1167,7 +1178,19 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
       return MOEINF_OK;
     }
-    if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
+    if (sr && sr->front1) {
+      LayerSync sy;
+      memset(&sy, 0, sizeof sy);
+      sy.ctr = g->d_layer_ctr; sy.launch = ++g->layer1_launches; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
+      static const int f1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
+      sy.sleep = f1_sleep; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
+      if (getenv("MOEINF_LAYER1_TRACE")) {
+        const int nb = g->E + (sr->sh1 ? (g->Fs + 15) / 16 : 0) + 1 + g->K * ((g->F + 15) / 16) + (sr->sh2 ? (g->H + 15) / 16 : 0);
+        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; g->layer1_maxi = 1; }
+        sy.trace = g->d_layer_trace;
+      }
+      HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
+    } else if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
     else if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
@@ -1318,13 +1341,20 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   static const bool layer1s_env = getenv("MOEINF_LAYER1_SWITCH") ? atoi(getenv("MOEINF_LAYER1_SWITCH")) != 0 : true;
   const bool layer1_switch = layer1s_env && selfroute && T == 1 && sr_switch && !sr_gated && !(flags & MOEINF_FWD_NO_COMBINE) && g->dt != DT_F16;
   g->last_layer1 = layer1 || layer1_switch;
+  // the gated families: the gate (and the hidden shared expert) can ride in FRONT of the self-routing stage 1, in the same
+  // launch (round 5, launch_moe_front1).  Measured A/B/A/B (profiles/r05_front1_gate_and_stage1_in_one_launch.txt): DeepSeek-V2-Lite
+  // 0.949-0.967 -> 0.937 ms/token (two launches per layer instead of three) = the default with a hidden shared expert; Mixtral
+  // 3.708-3.726 -> 3.723-3.728 (nothing: the hop costs what the gate launch cost) = off unless MOEINF_FRONT1=1; =0: never
+  static const int front1_env = getenv("MOEINF_FRONT1") ? atoi(getenv("MOEINF_FRONT1")) : -1;
+  const bool front1 = (front1_env < 0 ? hide_shared : front1_env != 0) && selfroute && !layer1 && T == 1 && sr_gated && g->dt != DT_F32 &&
+                      (hide_shared || !g->has_shared) && (ra.gate_dtype == ra.x_dtype || ra.gate_dtype == DT_F32);
   FfnStage sh1, sh2;
   if (hide_shared) {
     hidden_shared_stages(g, layer, x_dev, sh1, sh2);
     ia.shared = 0;  // the index lists routed experts only
   }
-  if (layer1 || layer1_switch) {
-    // nothing here: dispatch_experts launches the layer
+  if (layer1 || layer1_switch || front1) {
+    // nothing here: dispatch_experts launches the layer / the launch that carries the gate
   } else if (selfroute) {
     if (hide_shared) HIPCHK(launch_gate_shared1(ra, sh1, st));
     else HIPCHK(launch_gate_logits(ra, st));
@@ -1366,7 +1396,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK ||
                          (selfroute && sr_switch));  // (Switch: only the batch-1 stage 2 knows its combine)
   bool fused = false;
-  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1, layer1_switch};
+  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1, front1, layer1_switch};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        rows_estimate(T, K, E), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));

@@ -359,6 +359,7 @@ struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn
   const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
   const FfnStage* sh1 = nullptr;  // layer1: its stage 1
   bool layer1 = false;  // the whole layer as ONE launch (launch_moe_layer1): the caller has NOT launched the gate
+  bool front1 = false;  // gate + stage 1 (+ the hidden shared expert) as ONE launch (launch_moe_front1): the caller has NOT launched the gate
   bool layer1_switch = false;  // ... its Switch form (launch_moe_layer1_switch); if that declines, dispatch_experts launches the gate itself
 };
 

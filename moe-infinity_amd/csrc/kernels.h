@@ -258,6 +258,9 @@ int layer1_table(int E, int K, int H, int F, int Fs, int elem_bytes, int gate_by
 int layer1_wgs_per_cu(int gate_dtype);
 hipError_t launch_moe_layer1(const RouteArgs& r, const IndexArgs& a, const FfnStage& sh1, const FfnStage& sh2, const FfnStage& s1, const FfnStage& s2,
                              const LayerSync& sy, int nwg, hipStream_t st);
+// the FRONT of a batch-1 layer of the gated families in one launch: gate | (shared stage 1) | meta | self-routing stage 1 |
+// (shared stage 2); stage 2 + combine stay launch_ffn2_decode1.  sh1 / sh2: the hidden shared expert's stages or nullptr.
+hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnStage* sh1, const FfnStage* sh2, const FfnStage& s1, const LayerSync& sy, hipStream_t st);
 // the Switch form (top-1, plain experts, no shared expert): E + 1 + F/16 + 4 * H/16 workgroups of eight waves, all resident at once;
 // false: not handled (the caller runs the three launches)
 bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, hipStream_t st);

@@ -365,6 +365,117 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
 }
 
 // ------------------------------------------------------------------------------------------------
+// The FRONT of a batch-1 decode layer of the gated families in one launch (round 5): gate | (shared stage 1) | meta |
+// self-routing stage 1 | (shared stage 2) as workgroups of ONE grid — the gate launch and its boundary leave the layer
+// (Mixtral: two launches per layer; DeepSeek: two instead of three).  This is the part of the one-launch layer above that the
+// timelines showed to work: the GATE hand-over happens while nothing streams yet (flag seen 1 us after the last gate workgroup),
+// stage 1 starts 3 us into the launch instead of 8 us into the layer, and the shared expert's two stages overlap it as before.
+// What does NOT go into this launch is the stage-1 -> stage-2 hand-over (a chip-wide barrier under full load: a kernel boundary
+// is as cheap, section 4.5 of DESIGN.md): stage 2 + combine stay the launch they were (ffn2_decode1[_pair]).
+// Role = workgroup id (gate first): a workgroup only waits for smaller ids, the dispatcher hands them out in id order.
+// Item bodies = ffn1_selfroute_kernel's / gate_shared1_kernel's (ffn_rows_item<T, 2, 4, U, 1>, gate_body): bit-identical rows.
+template <typename T, typename GW, int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void moe_front1_kernel(RouteArgs r, IndexArgs a, FfnStage sh1, FfnStage sh2, FfnStage s1, LayerSync sy,
+                                                                                              int round_logits, int n_sh1, int n_sh2) {
+  constexpr int NW = 4;
+  __shared__ float red[NW][2][256];
+  __shared__ double redg[4][4];
+  __shared__ unsigned long long sh_w;
+  __shared__ int sh_flag;
+  static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
+  const int lane = threadIdx.x & 63;
+  const int K = r.K, E = r.E;
+  const int n_rg = (s1.R + 15) / 16;
+  int b = blockIdx.x;
+  const int tslot = (int)blockIdx.x * 4;
+  layer_trace(sy, tslot + 0);
+  if (b < E) {  // ---- gate
+    gate_body<T, GW, 4, true>(reinterpret_cast<const T*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, round_logits, redg, b, 0);
+    layer_arrive(sy, LC_GATE);
+    layer_trace(sy, tslot + 3);
+    return;
+  }
+  b -= E;
+  if (b < n_sh1) {  // ---- shared expert, stage 1 (h_shared is read by THIS launch's shared stage 2: write-through + counter)
+    const char* W = reinterpret_cast<const char*>(sh1.wptr[sh1.E]);
+    ffn_rows_item<T, 2, NW, U, 1, false, true>(sh1, b, W, true, 1, 0, red);
+    wait_stores_acked();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(layer_spread_word(sy, LC_SH1, b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    layer_trace(sy, tslot + 3);
+    return;
+  }
+  b -= n_sh1;
+  if (b == 0) {  // ---- meta (one wave): the generic router, the one-wave index, the decode records, the pinned mirror
+    if (threadIdx.x >= 64) return;
+    layer_wait(sy, LC_GATE, E);
+    layer_trace(sy, tslot + 1);
+    int* scratch = reinterpret_cast<int*>(&red[0][0][0]);
+    Routed o;
+    route_core<true>(r, 0, lane, o);
+    int my_sel, rank;
+    float my_w;
+    route_store(r, 0, lane, o, &my_sel, &my_w, &rank);
+    if (lane < K && s1.dec_w) {  // read by the NEXT launch (stage 2): plain stores
+      s1.dec_w[rank] = my_sel >= 0 ? s1.wptr[my_sel] : 0ull;
+      s1.dec_cw[rank] = my_w;
+    }
+    __threadfence_block();
+    index_small(a, scratch, scratch + IDX_MAXE);
+    layer_trace(sy, tslot + 3);
+    return;
+  }
+  b -= 1;
+  if (b < K * n_rg) {  // ---- routed stage 1 (h is read by the next launch: plain stores)
+    const int u = b / n_rg, rg = b - u * n_rg;
+    layer_wait(sy, LC_GATE, E);
+    layer_trace(sy, tslot + 1);
+    const char* W = layer_selfroute(r, s1, u, &sh_w, &sh_flag);
+    if (!sh_flag) return;
+    if (W == nullptr) {  // never on the sync-free path
+      if (threadIdx.x == 0 && rg == 0) atomicExch(s1.miss_flag, 1);
+      return;
+    }
+    ffn_rows_item<T, 2, NW, U, 1>(s1, rg, W, false, 1, u, red, 0);
+    layer_trace(sy, tslot + 3);
+    return;
+  }
+  b -= K * n_rg;
+  {  // ---- shared expert, stage 2 (y_shared is read by the next launch: plain stores; h_shared comes from this one)
+    const char* W = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
+    layer_wait_spread(sy, LC_SH1, n_sh1);
+    layer_trace(sy, tslot + 2);
+    ffn_rows_item<T, 1, NW, U, 1, true, false>(sh2, b, W, true, 1, 0, reinterpret_cast<float (*)[1][256]>(&red[0][0][0]));
+    layer_trace(sy, tslot + 3);
+    (void)n_sh2;
+  }
+}
+
+// bf16 / fp16 model with the gate in the model dtype or fp32; sh1 / sh2 = the hidden shared expert's stages or nullptr
+hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnStage* sh1, const FfnStage* sh2, const FfnStage& s1, const LayerSync& sy, hipStream_t st) {
+  const int n_rg = (s1.R + 15) / 16;
+  const int n_sh1 = sh1 ? (sh1->R_sh + 15) / 16 : 0, n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
+  const dim3 grid(r.E + n_sh1 + 1 + r.K * n_rg + n_sh2);
+  // (as launch_ffn1_selfroute: a multi-round grid streams best with FOUR workgroups per CU, capped through dynamic LDS, and
+  // four tiles per wave, matrix and batch; a grid that is resident all at once takes eight)
+  static const int lds_env = env_int("MOEINF_SR_LDS_KB", -1);
+  const size_t dyn = (size_t)(lds_env >= 0 ? lds_env : (grid.x > 4 * 256 ? 30 : 0)) * 1024;
+  static const int sr_u_env = env_int("MOEINF_SR_U", 0);
+  const int sr_u = sr_u_env ? sr_u_env : (grid.x > 4 * 256 ? 4 : 8);
+  const int rl = r.kind != 0 ? 0 : (r.x_dtype == DT_BF16 ? 1 : (r.x_dtype == DT_F16 ? 2 : 0));
+  const FfnStage& a1 = sh1 ? *sh1 : s1;
+  const FfnStage& a2 = sh2 ? *sh2 : s1;
+#define F1(TT, GW, UU) hipLaunchKernelGGL((moe_front1_kernel<TT, GW, UU>), grid, dim3(256), dyn, st, r, a, a1, a2, s1, sy, rl, n_sh1, n_sh2)
+#define F1U(TT, GW) do { if (sr_u == 8) F1(TT, GW, 8); else F1(TT, GW, 4); } while (0)
+  if (s1.dtype == DT_BF16) { if (r.gate_dtype == DT_BF16) F1U(uint16_t, uint16_t); else if (r.gate_dtype == DT_F32) F1U(uint16_t, float); else return hipErrorInvalidValue; }
+  else if (s1.dtype == DT_F16) { if (r.gate_dtype == DT_F16) F1U(half_t, half_t); else if (r.gate_dtype == DT_F32) F1U(half_t, float); else return hipErrorInvalidValue; }
+  else return hipErrorInvalidValue;
+#undef F1U
+#undef F1
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same idea for Switch (top-1, plain ReLU experts, no shared expert; Switch-base-8: 18.9 MB per layer in three launches of
 // 3-10 us = pure fixed cost) — and here it PAYS (0.32 -> 0.27 ms/token in its first form): with hardly any traffic in flight a
 // flag costs ~1 us.  ONE launch of E + 1 + F/16 + KS * H/16 workgroups of eight waves, every one resident at once (the launcher

@@ -2,7 +2,7 @@
 """Timeline of the one-launch decode layer (csrc/layer_fused.hip): runs a few DeepSeek-V2-Lite batch-1 forwards with
 MOEINF_LAYER1_TRACE set (the engine writes the per-workgroup timestamps of the LAST launch at destroy) and prints, per role,
 when its workgroups started / got past their waits / finished (microseconds after the first workgroup started).
-usage: layer1_trace.py [--switch] [out.txt]   (--switch: Switch-base-8, the one-launch form that is its default; extra MOEINF_*
+usage: layer1_trace.py [--switch | --mixtral] [out.txt]   (--switch: Switch-base-8, the one-launch form that is its default; extra MOEINF_*
 knobs are taken from the environment; DeepSeek needs MOEINF_LAYER1=1)"""
 import os, statistics, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ import sys, torch
 sys.path.insert(0, %r)
 from moe_infinity_amd import MoEEngine, config as Cf
 from oracle.synth import acts
-cfg = (Cf.switch_base_8 if sys.argv[1] == "switch" else Cf.deepseek_v2_lite)(device_memory_ratio=0.5, max_tokens=1)
+cfg = {"switch": Cf.switch_base_8, "mixtral": Cf.mixtral_8x7b, "deepseek": Cf.deepseek_v2_lite}[sys.argv[1]](device_memory_ratio=0.5, max_tokens=1)
 cfg.num_layers = 2
 eng = MoEEngine(cfg)
 dev = torch.device("cuda:0")
@@ -38,9 +38,11 @@ eng.close()
 def main():
     path = tempfile.mktemp(suffix=".l1trace")
     env = dict(os.environ, MOEINF_LAYER1_TRACE=path)
-    model = "switch" if "--switch" in sys.argv else "deepseek"
-    if "--switch" in sys.argv:
-        sys.argv.remove("--switch")
+    model = "deepseek"
+    for m in ("switch", "mixtral"):
+        if "--" + m in sys.argv:
+            model = m
+            sys.argv.remove("--" + m)
     r = subprocess.run([sys.executable, "-c", CHILD, model], env=env, capture_output=True, text=True)
     if r.returncode or not os.path.exists(path):
         print("child failed:", r.stderr[-1500:]); return 1
