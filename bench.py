@@ -444,6 +444,9 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
 
         kernels = {"ffn_stage1": kstat(p["ffn1_ms"], p["ffn1_launches"], p["ffn1_bytes"]),
                    "ffn_stage2": kstat(p["ffn2_ms"], p["ffn2_launches"], p["ffn2_bytes"])}
+        if p.get("fused_layers"):
+            # the whole layer ran as ONE launch (csrc/layer_fused.hip: Switch batch 1): its bytes and time are all under "ffn_stage1"
+            kernels["one_launch_per_layer"] = {"forwards": int(p["fused_layers"]), "note": "router, both FFN stages and the combine are ONE launch: every byte of the layer and the launch's whole time are reported as ffn_stage1"}
         if use_ep:
             kernels["note"] = f"rank 0's owner-side FFN over the rows it received (experts e % {world} == 0)"
         else:
@@ -955,8 +958,8 @@ def main():
                                            + f", decode batch {b}, device_memory_ratio={args.ratio}",
                                "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2),
                                "windows_ms": o["windows_ms"],
-                               "algorithmic_GB_per_step": None if not (k1 and k2) else round(step_bytes / 1e9, 3),
-                               "frac_of_hbm_peak_whole_step": None if not (k1 and k2) else round(step_bytes / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_GB_per_step": None if not (k1 and (k2 or o["kernels"].get("one_launch_per_layer"))) else round(step_bytes / 1e9, 3),
+                               "frac_of_hbm_peak_whole_step": None if not (k1 and (k2 or o["kernels"].get("one_launch_per_layer"))) else round(step_bytes / (o["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "ffn_stage1": k1, "ffn_stage2": k2, "route": o["kernels"].get("route(gate+topk+index)"),
                                "parity": o["parity"], "cpu_baseline": o["cpu"],
                                # BASELINE config 2 (DeepSeek-V2-Lite: "prefetch stream overlap"): cache = half of the expert bytes,

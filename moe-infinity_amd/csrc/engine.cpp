@@ -848,6 +848,11 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   }
   g->prof.forwards += 1;
   if (mirror[0] > 0) { g->prof.ffn1_launches += 1; g->prof.ffn2_launches += 1; }
+  if (local && g->last_front1 && !g->last_layer1) {
+    // the gate (and the hidden shared expert's first stage) ran inside the launch timed as "ffn1": their bytes belong there
+    g->prof.ffn1_bytes += g->prof.route_bytes - p0.route_bytes;
+    g->prof.route_bytes = p0.route_bytes;
+  }
   if (local && g->last_layer1) {
     // the one-launch layer: every byte of the forward moves inside the launch timed as "ffn1" (the other intervals are empty)
     g->prof.ffn1_bytes = p0.ffn1_bytes + (g->prof.ffn1_bytes - p0.ffn1_bytes) + (g->prof.ffn2_bytes - p0.ffn2_bytes) + (g->prof.route_bytes - p0.route_bytes) +
@@ -1346,6 +1351,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   // 0.949-0.967 -> 0.937 ms/token (two launches per layer instead of three) = the default with a hidden shared expert; Mixtral
   // 3.708-3.726 -> 3.723-3.728 (nothing: the hop costs what the gate launch cost) = off unless MOEINF_FRONT1=1; =0: never
   static const int front1_env = getenv("MOEINF_FRONT1") ? atoi(getenv("MOEINF_FRONT1")) : -1;
+  g->last_front1 = false;
   const bool front1 = (front1_env < 0 ? hide_shared : front1_env != 0) && selfroute && !layer1 && T == 1 && sr_gated && g->dt != DT_F32 &&
                       (hide_shared || !g->has_shared) && (ra.gate_dtype == ra.x_dtype || ra.gate_dtype == DT_F32);
   FfnStage sh1, sh2;
@@ -1353,6 +1359,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     hidden_shared_stages(g, layer, x_dev, sh1, sh2);
     ia.shared = 0;  // the index lists routed experts only
   }
+  g->last_front1 = front1;
   if (layer1 || layer1_switch || front1) {
     // nothing here: dispatch_experts launches the layer / the launch that carries the gate
   } else if (selfroute) {

@@ -301,6 +301,7 @@ struct moeinf_engine {
   // last forward
   bool last_hidden_shared = false;
   bool last_selfroute = false;      // the last forward used the self-routing FFN stage 1 (batch-1 decode)
+  bool last_front1 = false;         // ... or its front (gate, hidden shared expert, stage 1) as one launch (moe_front1_kernel)
   bool last_layer1 = false;         // ... and ran as ONE launch (layer_fused.hip)
   uint32_t* d_layer_ctr = nullptr;  // its counters (kernels.h LayerSync): only grow, zeroed at creation and after an error
   uint32_t layer1_launches = 0;
