@@ -277,7 +277,11 @@ hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st) {
 #undef GM
     return hipGetLastError();
   }
-#define GL(XT, WT) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb)
+  // one token (batch-1 decode, the gate launch in front of the self-routing stage 1): ONE cross-lane reduction per workgroup
+  // instead of four (the fp64 shuffles of the three absent tokens were most of the kernel: round 5, seen in the timelines of
+  // csrc/layer_fused.hip — gate done after 1.6 us instead of 2.6)
+#define GL(XT, WT) do { if (a.T == 1) hipLaunchKernelGGL((gate_logits_kernel<XT, WT, 1>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb); \
+                        else hipLaunchKernelGGL((gate_logits_kernel<XT, WT, TT>), grid, dim3(256), 0, st, (const XT*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb); } while (0)
   if (a.x_dtype == DT_F16) { if (a.gate_dtype == DT_F16) GL(half_t, half_t); else GL(half_t, float); }
   else if (a.x_dtype == DT_BF16 && a.gate_dtype == DT_BF16) GL(uint16_t, uint16_t);
   else if (a.x_dtype == DT_BF16) GL(uint16_t, float);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void moe_
                                                                                               int round_logits, int n_sh1, int n_sh2) {
   constexpr int NW = 4;
   __shared__ float red[NW][2][256];
-  __shared__ double redg[4][4];
+  __shared__ double redg[4][1];
   __shared__ unsigned long long sh_w;
   __shared__ int sh_flag;
   static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void moe_
   const int tslot = (int)blockIdx.x * 4;
   layer_trace(sy, tslot + 0);
   if (b < E) {  // ---- gate
-    gate_body<T, GW, 4, true>(reinterpret_cast<const T*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, round_logits, redg, b, 0);
+    gate_body<T, GW, 1, true>(reinterpret_cast<const T*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, round_logits, redg, b, 0);  // (one token: one reduction, not gate_logits_kernel's four)
     layer_arrive(sy, LC_GATE);
     layer_trace(sy, tslot + 3);
     return;
@@ -493,7 +493,7 @@ template <typename T, typename GW, int P2, int KS>
 __global__ __launch_bounds__(512) void moe_layer1_switch_kernel(RouteArgs r, IndexArgs a, FfnStage s1, FfnStage s2, LayerSync sy) {
   constexpr int NW = 8;
   __shared__ float red[NW][1][256];
-  __shared__ double redg[4][4];
+  __shared__ double redg[4][1];
   __shared__ unsigned long long sh_w;
   __shared__ int sh_flag;
   static_assert(sizeof(float) * NW * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void moe_layer1_switch_kernel(RouteArgs r, Ind
   layer_trace(sy, tslot + 0);
   if (b < E) {  // ---- gate: one logit per workgroup, four waves (the others leave: a finished wave does not count at a barrier)
     if (tid >= 256) return;
-    gate_body<T, GW, 4, true>(reinterpret_cast<const T*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, 0, redg, b, 0);
+    gate_body<T, GW, 1, true>(reinterpret_cast<const T*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, 0, redg, b, 0);
     layer_arrive(sy, LC_GATE);
     layer_trace(sy, tslot + 3);
     return;
