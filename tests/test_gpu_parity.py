@@ -586,7 +586,7 @@ def test_ep_two_ranks_variable_split_emulated_on_one_gpu():
         eng.close()
 
 
-@pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch")
+@pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch", "fsgpt")
                                         for d, t in ((torch.bfloat16, "bf16"), (torch.float32, "f32"), (torch.float16, "f16"))])
 def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     """R6 pinned to real reference code: tests/golden/ffn_ref_*.npz hold y = <module>.forward(x) computed by the
@@ -594,7 +594,8 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     (through expert_dispatcher's mask dispatch) must match within one ulp per rounding point."""
     z = load_golden(f"ffn_ref_{fam}_{tag}.npz")
     h, f, e, seed = [int(v) for v in z["meta"]]
-    gate, experts, _ = make_weights(fam, h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch") else {}))
+    # (fsgpt, expert type 3: NLLB-shaped tensors through the reference's FSGPTMoEDenseActDense, expert_module.cpp:113-129)
+    gate, experts, _ = make_weights("nllb" if fam == "fsgpt" else fam, h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}))
     np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
     eng = engine_for(fam, h, f, e, 1 if fam == "switch" else 2, dt, max_tokens=64)
     register_all(eng, experts)
@@ -605,7 +606,7 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
         y, counts, _ = eng.dispatch_mask(0, x.to(DEV), mask.to(DEV))
         assert int(counts[i]) == x.shape[0] and int(counts.sum()) == x.shape[0]
         assert_model_close(y, tt(z[f"y{i}"], torch.float32), dt, f"{fam} {tag} case {i} vs the reference module",
-                           ulps=2.0 if fam == "nllb" else 1.0)
+                           ulps=2.0 if fam in ("nllb", "fsgpt") else 1.0)
     eng.close()
 
 
