@@ -43,7 +43,7 @@ enum { MOEINF_DTYPE_BF16 = 0, MOEINF_DTYPE_F32 = 1, MOEINF_DTYPE_F16 = 2 };
 /* expert_type ids: core/parallel/expert_module.h:13-18, moe_infinity/common/constants.py:29-37 */
 enum {
   MOEINF_EXPERT_SWITCH = 0,       /* relu(x wi^T) wo^T                      expert_module.cpp:24-36   */
-  MOEINF_EXPERT_SWITCH_GATED = 1, /* gelu-gated, not in BASELINE configs -> MOEINF_ERR_UNSUPPORTED   */
+  MOEINF_EXPERT_SWITCH_GATED = 1, /* (gelu(x wi_0^T) * (x wi_1^T)) wo^T          expert_module.cpp:46-59   */
   MOEINF_EXPERT_NLLB = 2,         /* relu(x fc1^T + b1) fc2^T + b2          expert_module.cpp:79-93   */
   MOEINF_EXPERT_FSGPT = 3,        /* same math as NLLB                      expert_module.cpp:113-129 */
   MOEINF_EXPERT_MIXTRAL = 4,      /* (silu(x w1^T) * (x w3^T)) w2^T         expert_module.cpp:147-175 */

@@ -94,8 +94,8 @@ static int validate(const moeinf_config* c) {
   if (c->gate_dtype != MOEINF_DTYPE_F32 && c->dtype != MOEINF_DTYPE_F32 && c->gate_dtype != c->dtype) return fail(MOEINF_ERR_UNSUPPORTED, "gate_dtype %d with dtype %d", c->gate_dtype, c->dtype);
   if (c->gate_dtype == MOEINF_DTYPE_F16 && c->dtype == MOEINF_DTYPE_F32) return fail(MOEINF_ERR_UNSUPPORTED, "an fp16 gate with fp32 activations is not built");
   switch (c->expert_type) {
-    case MOEINF_EXPERT_SWITCH: case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: case MOEINF_EXPERT_MIXTRAL: case MOEINF_EXPERT_DEEPSEEK: break;
-    default: return fail(MOEINF_ERR_UNSUPPORTED, "expert_type %d is not built (switch-gated/gelu is outside BASELINE's configs)", c->expert_type);
+    case MOEINF_EXPERT_SWITCH: case MOEINF_EXPERT_SWITCH_GATED: case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: case MOEINF_EXPERT_MIXTRAL: case MOEINF_EXPERT_DEEPSEEK: break;
+    default: return fail(MOEINF_ERR_UNSUPPORTED, "expert_type %d is not one of the reference's (expert_module.h:13-18)", c->expert_type);
   }
   const int ev = c->dtype == MOEINF_DTYPE_F32 ? 4 : 8;
   if (c->hidden <= 0 || c->inter <= 0 || c->hidden % ev || c->inter % ev) return fail(MOEINF_ERR_INVALID, "hidden/inter must be positive multiples of %d", ev);
@@ -518,7 +518,7 @@ static int retile_tensor(const moeinf_engine* g, const DevLayout& dl, int i, con
 static int copy_order(int expert_type, int order[4]) {
   switch (expert_type) {
     case MOEINF_EXPERT_MIXTRAL: order[0] = 0; order[1] = 2; order[2] = 1; return 2;   // w1 w3 | w2
-    case MOEINF_EXPERT_DEEPSEEK: order[0] = 0; order[1] = 1; order[2] = 2; return 2;  // gate up | down
+    case MOEINF_EXPERT_DEEPSEEK: case MOEINF_EXPERT_SWITCH_GATED: order[0] = 0; order[1] = 1; order[2] = 2; return 2;  // gate up | down
     case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: order[0] = 0; order[1] = 1; order[2] = 2; order[3] = 3; return 2;  // fc1.w fc1.b | fc2.w fc2.b
     default: order[0] = 0; order[1] = 1; return 1;                                     // wi | wo
   }
@@ -808,6 +808,7 @@ void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64
     s.ld_in = ld_x > 0 ? ld_x : g->H; s.row_map = g->d_slot_token; s.out = g->d_h; s.ld_out = g->ldh;
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[0]; s.off_b = b.off[2]; s.epi = EPI_GATED_SILU; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[0]; s.off_b = b.off[1]; s.off_a_sh = bs.off[0]; s.off_b_sh = bs.off[1]; s.epi = EPI_GATED_SILU; }
+    else if (et == MOEINF_EXPERT_SWITCH_GATED) { s.off_a = b.off[0]; s.off_b = b.off[1]; s.epi = EPI_GATED_GELU; }  // gelu(x wi_0^T) * (x wi_1^T)
     else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[0]; s.epi = EPI_RELU; }
     else { s.off_a = b.off[0]; s.off_bias = b.off[1]; s.epi = EPI_BIAS_RELU; }
   } else {
@@ -816,6 +817,7 @@ void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64
     if (g->ovr_out) { s.out = g->ovr_out; s.out_map = g->ovr_map; }
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[2]; s.off_a_sh = bs.off[2]; s.epi = EPI_NONE; }
+    else if (et == MOEINF_EXPERT_SWITCH_GATED) { s.off_a = b.off[2]; s.epi = EPI_NONE; }  // wo
     else if (et == MOEINF_EXPERT_SWITCH) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
     else { s.off_a = b.off[2]; s.off_bias = b.off[3]; s.epi = EPI_BIAS; }
   }
@@ -836,7 +838,7 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   if (hidden) g->prof.route_bytes += (sr2 ? 2 : 3) * Fs * H * es + (int64_t)T * ((sr2 ? 1 : 2) * Fs + (sr2 ? 1 : 2) * H) * es;
   if (sr2) g->prof.ffn1_bytes += Fs * H * es + (int64_t)T * (Fs + H) * es;
   const int et = g->cfg.expert_type;
-  const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK);
+  const bool gated = (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK || et == MOEINF_EXPERT_SWITCH_GATED);
   const bool bias = (et == MOEINF_EXPERT_NLLB || et == MOEINF_EXPERT_FSGPT);
   const int64_t b1 = U * ((gated ? 2 : 1) * F * H * es + (bias ? F * es : 0)) + (Tsh ? 2 * Fs * H * es : 0) + (rows + Tsh) * H * es + rows * F * es + Tsh * Fs * es;
   const int64_t b2 = U * (H * F * es + (bias ? H * es : 0)) + (Tsh ? H * Fs * es : 0) + rows * F * es + Tsh * Fs * es + (rows + Tsh) * H * es;

@@ -88,6 +88,7 @@ static BlobLayout make_layout(int expert_type, int64_t H, int64_t F, int64_t es)
   switch (expert_type) {
     case MOEINF_EXPERT_MIXTRAL:   // w1[F,H] w2[H,F] w3[F,H]
     case MOEINF_EXPERT_DEEPSEEK:  // gate[F,H] up[F,H] down[H,F]
+    case MOEINF_EXPERT_SWITCH_GATED:  // wi_0[F,H] wi_1[F,H] wo[H,F] (expert_module.cpp:46-52)
       add(F * H * es); add(F * H * es); add(F * H * es);
       break;
     case MOEINF_EXPERT_NLLB:
@@ -121,7 +122,7 @@ static DevLayout make_dev_layout(int expert_type, int64_t H, int64_t F, int dt, 
   };
   switch (expert_type) {
     case MOEINF_EXPERT_MIXTRAL: mat(F, H); mat(H, F); mat(F, H); break;
-    case MOEINF_EXPERT_DEEPSEEK: mat(F, H); mat(F, H); mat(H, F); break;
+    case MOEINF_EXPERT_DEEPSEEK: case MOEINF_EXPERT_SWITCH_GATED: mat(F, H); mat(F, H); mat(H, F); break;
     case MOEINF_EXPERT_NLLB: case MOEINF_EXPERT_FSGPT: mat(F, H); vec(F); mat(H, F); vec(H); break;
     case MOEINF_EXPERT_SWITCH: mat(F, H); mat(H, F); break;
     default: break;

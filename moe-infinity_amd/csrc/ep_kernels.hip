@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_ep_kernel(FfnStage s, EpOwnArgs o
 
 hipError_t launch_ffn_ep_stage(const FfnStage& s, const EpOwnArgs& o, hipStream_t st) {
   const dim3 grid((s.R + 15) / 16 + ((o.stage == 1 && o.mirror) ? 1 : 0), o.max_active);
-  const bool gated = (s.epi == EPI_GATED_SILU);
+  const bool gated = (s.epi == EPI_GATED_SILU || s.epi == EPI_GATED_GELU);
   const size_t kbytes = (size_t)s.K * dt_bytes(s.dtype);
   const bool nw8 = kbytes >= 16384;  // long reductions: 8 waves per workgroup (as launch_ffn_stage)
 #define EPK(TT, NM, NWV) hipLaunchKernelGGL((ffn_ep_kernel<TT, NM, NWV, 4>), grid, dim3(NWV * 64), 0, st, s, o)

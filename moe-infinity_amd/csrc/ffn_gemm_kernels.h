@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void ffn_gemm_hyb_kernel(FfnStage s) {
 
 template <typename T, int NMAT>
 bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st) {
+  if (NMAT == 2 && s.epi != EPI_GATED_SILU) return false;  // (the gelu gate: the row kernel, kernels.hip)
   static const int use_gemm = env_int("MOEINF_FFN_GEMM", 2);
   static const int force_nt = env_int("MOEINF_FFN_GEMM_NT", 0);
   // long prefills: the 256 x 256 / 32x32x16-MFMA kernel (ffn_gemm_big.hip).  Measured (profiles/r03_ffn_sweep_prefill_big_*.txt):

@@ -551,6 +551,10 @@ __device__ __forceinline__ void ffn_rows_item(const FfnStage& s, const int bx, c
             const float b = DT<T>::round(s1);
             const float sl = DT<T>::round(v / (1.0f + expf(-v)));
             v = DT<T>::round(sl * b);
+          } else if (s.epi == EPI_GATED_GELU) {
+            const float b = DT<T>::round(s1);
+            const float gl = DT<T>::round(0.5f * v * (1.0f + erff(v * 0.70710678118654752f)));
+            v = DT<T>::round(gl * b);
           } else {
             if (s.epi == EPI_BIAS || s.epi == EPI_BIAS_RELU)
               v = DT<T>::round(v + DT<T>::load(reinterpret_cast<const T*>(W + s.off_bias) + orow));

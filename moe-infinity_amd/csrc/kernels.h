@@ -53,7 +53,9 @@ enum {
   EPI_BIAS = 1,       // out = Tr(Tr(acc) + bias)           (NLLB fc2)
   EPI_RELU = 2,       // out = relu(Tr(acc))                (Switch wi)
   EPI_BIAS_RELU = 3,  // out = relu(Tr(Tr(acc) + bias))     (NLLB fc1)
-  EPI_GATED_SILU = 4  // out = Tr(Tr(silu(Tr(acc0))) * Tr(acc1))   (Mixtral w1/w3, DeepSeek gate/up)
+  EPI_GATED_SILU = 4, // out = Tr(Tr(silu(Tr(acc0))) * Tr(acc1))   (Mixtral w1/w3, DeepSeek gate/up)
+  EPI_GATED_GELU = 5  // out = Tr(Tr(gelu(Tr(acc0))) * Tr(acc1))   (gelu-gated Switch wi_0/wi_1, expert_module.cpp:54-59; erf form = torch::gelu's
+                      // default).  Round 5: runs the row kernel at every size (the tuned grouped GEMMs are built for the SiLU gate only).
 };
 
 struct CombineArgs {

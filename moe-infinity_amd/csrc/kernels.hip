@@ -125,7 +125,7 @@ hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_
   static const int env_nw = env_int("MOEINF_FFN_NW", 0), env_u = env_int("MOEINF_FFN_U", 0);
   const int rmax = s.R > s.R_sh ? s.R : s.R_sh;
   dim3 grid((rmax + 15) / 16, max_active);
-  const bool gated = (s.epi == EPI_GATED_SILU);
+  const bool gated = (s.epi == EPI_GATED_SILU || s.epi == EPI_GATED_GELU);
   // long reductions get 8 waves per block (more bytes in flight per CU), short ones 4
   const int kmax = s.K > s.K_sh ? s.K : s.K_sh;
   const size_t kbytes = (size_t)kmax * dt_bytes(s.dtype);

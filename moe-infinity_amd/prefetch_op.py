@@ -415,7 +415,7 @@ class prefetch_handle:
             pass
 
 
-_ROUTER_OF = {Cf.EXPERT_SWITCH: Cf.ROUTER_SWITCH, Cf.EXPERT_NLLB: Cf.ROUTER_NLLB, Cf.EXPERT_FSGPT: Cf.ROUTER_NLLB,
+_ROUTER_OF = {Cf.EXPERT_SWITCH: Cf.ROUTER_SWITCH, Cf.EXPERT_SWITCH_GATED: Cf.ROUTER_SWITCH, Cf.EXPERT_NLLB: Cf.ROUTER_NLLB, Cf.EXPERT_FSGPT: Cf.ROUTER_NLLB,
               Cf.EXPERT_MIXTRAL: Cf.ROUTER_MIXTRAL, Cf.EXPERT_DEEPSEEK: Cf.ROUTER_DEEPSEEK}
 
 

@@ -21,7 +21,7 @@ from oracle import build_ref, ref_lib  # noqa: E402
 from oracle.synth import acts, checksum, make_weights  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-ET = {"mixtral": 4, "deepseek": 5, "nllb": 2, "switch": 0, "fsgpt": 3}  # fsgpt (round 5): NLLB-shaped tensors, its own module (expert_module.cpp:113-129)
+ET = {"mixtral": 4, "deepseek": 5, "nllb": 2, "switch": 0, "fsgpt": 3, "switchgated": 1}  # fsgpt (round 5): NLLB-shaped tensors, its own module (expert_module.cpp:113-129)
 
 
 def to_np(t):
@@ -30,11 +30,11 @@ def to_np(t):
 
 def main():
     build_ref.build()
-    for fam in ("mixtral", "deepseek", "nllb", "switch", "fsgpt"):
+    for fam in ("mixtral", "deepseek", "nllb", "switch", "fsgpt", "switchgated"):  # switchgated (round 5): DeepSeek-shaped tensors (wi_0, wi_1, wo), gelu gate
         for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32"), (torch.float16, "f16")):  # f16: round 4 (dtype id 2)
             h, f, e, seed = 256, 352, 3, 4100 + ET[fam]
             kw = {"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}
-            gate, experts, _ = make_weights("nllb" if fam == "fsgpt" else fam, h, f, e, seed, dt, **kw)
+            gate, experts, _ = make_weights({"fsgpt": "nllb", "switchgated": "deepseek"}.get(fam, fam), h, f, e, seed, dt, **kw)
             out = {"meta": np.array([h, f, e, seed]), "wsum": checksum(gate, experts)}
             for i, t in enumerate((1, 5, 37)):
                 x = acts(t, h, dt, seed + 10 + i)

@@ -42,6 +42,7 @@ import torch.nn.functional as F
 # expert_type ids: core/parallel/expert_module.h:13-18
 SWITCH_DENSE_ACT_DENSE = 0
 SWITCH_DENSE_GATED_ACT_DENSE = 1
+SWITCH_GATED_DENSE_ACT_DENSE = SWITCH_DENSE_GATED_ACT_DENSE
 NLLB_DENSE_ACT_DENSE = 2
 FSGPT_DENSE_ACT_DENSE = 3
 MIXTRAL_DENSE_ACT_DENSE = 4
@@ -258,6 +259,9 @@ def expert_ffn(x: torch.Tensor, tensors: Sequence[torch.Tensor], expert_type: in
         if expert_type == FSGPT_DENSE_ACT_DENSE and x.dtype != fc1.dtype:
             x = x.to(fc1.dtype)
         return torch.matmul(torch.relu(torch.matmul(x, fc1.t()) + b1), fc2.t()) + b2
+    if expert_type == SWITCH_GATED_DENSE_ACT_DENSE:  # expert_module.cpp:54-59 (torch::gelu default = the erf form)
+        wi_0, wi_1, wo = tensors
+        return torch.matmul(F.gelu(torch.matmul(x, wi_0.t())) * torch.matmul(x, wi_1.t()), wo.t())
     if expert_type == SWITCH_DENSE_ACT_DENSE:
         wi, wo = tensors
         return torch.matmul(torch.relu(torch.matmul(x, wi.t().to(x.dtype))), wo.t().to(x.dtype))
@@ -331,14 +335,15 @@ def block_deepseek(x3d, wg, experts, top_k, shared=None, layer_id=0, **gate_kw) 
     return r
 
 
-def block_switch(x3d, wg, experts, expert_capacity=64, layer_id=0) -> BlockResult:
-    """moe_infinity/models/switch_transformers.py:74-113."""
+def block_switch(x3d, wg, experts, expert_capacity=64, layer_id=0, expert_type=SWITCH_DENSE_ACT_DENSE) -> BlockResult:
+    """moe_infinity/models/switch_transformers.py:74-113.  expert_type SWITCH_DENSE_GATED_ACT_DENSE: the same block over the
+    gelu-gated experts (T5-v1.1-style Switch checkpoints; moe_infinity/common/constants.py maps them to type 1)."""
     router_mask, router_probs, logits = route_switch(x3d, wg, expert_capacity)
     b, s, h = x3d.shape
     next_states = x3d.clone()
     x = x3d.reshape(-1, h)
     mask2d = router_mask.reshape(-1, router_mask.shape[-1])
-    res = dispatch_local(x, mask2d, layer_id, experts, SWITCH_DENSE_ACT_DENSE)
+    res = dispatch_local(x, mask2d, layer_id, experts, expert_type)
     r = BlockResult(out=None, router_mask=mask2d.bool(), logits=logits.reshape(-1, logits.shape[-1]))
     for output, _, e, _ in res:
         tok = router_mask[:, :, e].bool()

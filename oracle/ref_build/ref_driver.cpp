@@ -32,7 +32,7 @@ int ref_expert_ffn(int expert_type, int dtype, const void* x, int64_t T, int64_t
     std::vector<std::vector<int64_t>> shapes;
     switch (expert_type) {
       case MIXTRAL_MOE_DENSE_ACT_DENSE: shapes = {{F, H}, {H, F}, {F, H}}; break;
-      case DEEPSEEK_MOE_DENSE_ACT_DENSE: shapes = {{F, H}, {F, H}, {H, F}}; break;
+      case DEEPSEEK_MOE_DENSE_ACT_DENSE: case SWITCH_TRANSFORMERS_DENSE_GATED_ACT_DENSE: shapes = {{F, H}, {F, H}, {H, F}}; break;
       case NLLB_MOE_DENSE_ACT_DENSE: case FSGPT_MOE_DENSE_ACT_DENSE: shapes = {{F, H}, {F}, {H, F}, {H}}; break;
       case SWITCH_TRANSFORMERS_DENSE_ACT_DENSE: shapes = {{F, H}, {H, F}}; break;
       default: return 2;
@@ -54,6 +54,7 @@ int ref_expert_ffn(int expert_type, int dtype, const void* x, int64_t T, int64_t
       case DEEPSEEK_MOE_DENSE_ACT_DENSE: { DeepSeekMoEDenseActDense m(dtype); m.SetTensorsFromBlob(nullptr, ids, cpu); out = m.forward(xin); break; }
       case NLLB_MOE_DENSE_ACT_DENSE: { NllbMoeDenseActDense m(dtype); m.SetTensorsFromBlob(nullptr, ids, cpu); out = m.forward(xin); break; }
       case FSGPT_MOE_DENSE_ACT_DENSE: { FSGPTMoEDenseActDense m(dtype); m.SetTensorsFromBlob(nullptr, ids, cpu); out = m.forward(xin); break; }
+      case SWITCH_TRANSFORMERS_DENSE_GATED_ACT_DENSE: { SwitchTransformersDenseGatedActDense m(dtype); m.SetTensorsFromBlob(nullptr, ids, cpu); out = m.forward(xin); break; }
       default: { SwitchTransformersDenseActDense m(dtype); m.SetTensorsFromBlob(nullptr, ids, cpu); out = m.forward(xin); break; }
     }
     out = out.contiguous();

@@ -31,8 +31,10 @@ def engine_for(family, h, f, e, k, dtype, n_shared=0, max_tokens=64, **kw):
     from moe_infinity_amd import config as Cf
 
     dt = Cf.DTYPE_BF16 if dtype == torch.bfloat16 else (Cf.DTYPE_F16 if dtype == torch.float16 else Cf.DTYPE_F32)
-    et = {"mixtral": Cf.EXPERT_MIXTRAL, "deepseek": Cf.EXPERT_DEEPSEEK, "switch": Cf.EXPERT_SWITCH, "nllb": Cf.EXPERT_NLLB, "fsgpt": Cf.EXPERT_FSGPT}[family]
-    rk = {"mixtral": Cf.ROUTER_MIXTRAL, "deepseek": Cf.ROUTER_DEEPSEEK, "switch": Cf.ROUTER_SWITCH, "nllb": Cf.ROUTER_NLLB, "fsgpt": Cf.ROUTER_NLLB}[family]
+    et = {"mixtral": Cf.EXPERT_MIXTRAL, "deepseek": Cf.EXPERT_DEEPSEEK, "switch": Cf.EXPERT_SWITCH, "nllb": Cf.EXPERT_NLLB, "fsgpt": Cf.EXPERT_FSGPT,
+          "switchgated": Cf.EXPERT_SWITCH_GATED}[family]
+    rk = {"mixtral": Cf.ROUTER_MIXTRAL, "deepseek": Cf.ROUTER_DEEPSEEK, "switch": Cf.ROUTER_SWITCH, "nllb": Cf.ROUTER_NLLB, "fsgpt": Cf.ROUTER_NLLB,
+          "switchgated": Cf.ROUTER_SWITCH}[family]
     base = dict(num_layers=1, num_experts=e, expert_type=et, hidden=h, inter=f, top_k=k, router_kind=rk, dtype=dt,
                 shared_inter=f * n_shared, device_memory_ratio=0.5, max_tokens=max_tokens)
     base.update(kw)

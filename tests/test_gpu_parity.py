@@ -586,7 +586,7 @@ def test_ep_two_ranks_variable_split_emulated_on_one_gpu():
         eng.close()
 
 
-@pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch", "fsgpt")
+@pytest.mark.parametrize("fam,dt,tag", [(f, d, t) for f in ("mixtral", "deepseek", "nllb", "switch", "fsgpt", "switchgated")
                                         for d, t in ((torch.bfloat16, "bf16"), (torch.float32, "f32"), (torch.float16, "f16"))])
 def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     """R6 pinned to real reference code: tests/golden/ffn_ref_*.npz hold y = <module>.forward(x) computed by the
@@ -594,10 +594,11 @@ def test_expert_ffn_against_the_reference_modules_own_output(fam, dt, tag):
     (through expert_dispatcher's mask dispatch) must match within one ulp per rounding point."""
     z = load_golden(f"ffn_ref_{fam}_{tag}.npz")
     h, f, e, seed = [int(v) for v in z["meta"]]
-    # (fsgpt, expert type 3: NLLB-shaped tensors through the reference's FSGPTMoEDenseActDense, expert_module.cpp:113-129)
-    gate, experts, _ = make_weights("nllb" if fam == "fsgpt" else fam, h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}))
+    # (fsgpt, expert type 3: NLLB-shaped tensors through the reference's FSGPTMoEDenseActDense, expert_module.cpp:113-129;
+    # switchgated, expert type 1: (wi_0, wi_1, wo) through SwitchTransformersDenseGatedActDense, :46-59 — the gelu gate)
+    gate, experts, _ = make_weights({"fsgpt": "nllb", "switchgated": "deepseek"}.get(fam, fam), h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}))
     np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
-    eng = engine_for(fam, h, f, e, 1 if fam == "switch" else 2, dt, max_tokens=64)
+    eng = engine_for(fam, h, f, e, 1 if fam in ("switch", "switchgated") else 2, dt, max_tokens=64, **({"expert_capacity": 64} if fam == "switchgated" else {}))
     register_all(eng, experts)
     for i in range(3):
         x = tt(z[f"x{i}"], dt)
@@ -699,6 +700,32 @@ def test_batch1_decode_selfrouting_stage1(family, e, k, n_shared):
             outs.append(out.clone())
         assert torch.equal(outs[0], outs[1])
     assert eng.stats()["expert_misses"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,t", [(torch.float32, 1), (torch.float32, 40), (torch.bfloat16, 7), (torch.bfloat16, 300)],
+                         ids=["fp32_b1", "fp32_t40", "bf16_t7", "bf16_t300_many_rows_per_expert"])
+def test_switch_block_over_gelu_gated_experts(dtype, t):
+    """Expert type 1 (SwitchTransformersDenseGatedActDense, core/parallel/expert_module.cpp:46-59: (gelu(x wi_0^T) * (x wi_1^T)) wo^T)
+    under the Switch block (top-1 + capacity + router_prob scaling): routing, dispatch index, expert rows, block output against
+    the oracle.  Built in round 5; the gelu gate runs the row kernel at every size (300 tokens: 16-token tiles over the weights)."""
+    h, f, e = 256, 352, 8
+    gate, experts, _ = make_weights("deepseek", h, f, e, 5300, dtype)  # (wi_0, wi_1, wo) have DeepSeek's (gate, up, down) shapes
+    gate = (torch.randn(e, h, generator=torch.Generator().manual_seed(5301)) * 0.5).to(dtype)
+    eng = engine_for("switchgated", h, f, e, 1, dtype, max_tokens=t, expert_capacity=t)
+    register_all(eng, experts)
+    x = acts(t, h, dtype, 5302)
+    for _ in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV), batch_rows=1)
+    ref = R.block_switch(x[None], gate, experts, expert_capacity=t, expert_type=R.SWITCH_DENSE_GATED_ACT_DENSE)
+    r = eng.routing()
+    m = ref.router_mask.numpy()
+    want_idx = np.where(m.sum(-1) > 0, m.argmax(-1), -1)
+    assert np.array_equal(r["topk_idx"][:, 0], want_idx.astype(np.int32)), "top-1 must be bit-exact"
+    _check_dispatch_index(r, ref)
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, dtype, "gelu-gated expert FFN outputs")
+    assert_block_close(out, ref, dtype, f"Switch block over gelu-gated experts, {t} tokens")
     eng.close()
 
 

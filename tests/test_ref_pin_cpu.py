@@ -19,7 +19,8 @@ from oracle import offload_format_ref as F
 from oracle import ref_lib
 
 ET = {"mixtral": R.MIXTRAL_DENSE_ACT_DENSE, "deepseek": R.DEEPSEEK_DENSE_ACT_DENSE, "nllb": R.NLLB_DENSE_ACT_DENSE,
-      "switch": R.SWITCH_DENSE_ACT_DENSE, "fsgpt": R.FSGPT_DENSE_ACT_DENSE}  # fsgpt: NLLB-shaped tensors, its own reference module
+      "switch": R.SWITCH_DENSE_ACT_DENSE, "fsgpt": R.FSGPT_DENSE_ACT_DENSE,
+      "switchgated": R.SWITCH_DENSE_GATED_ACT_DENSE}  # fsgpt: NLLB-shaped tensors; switchgated: (wi_0, wi_1, wo) = DeepSeek-shaped; each its own reference module
 CASES = [(fam, dt, tag) for fam in ET for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32"))]
 
 
@@ -27,7 +28,7 @@ CASES = [(fam, dt, tag) for fam in ET for dt, tag in ((torch.bfloat16, "bf16"), 
 def test_oracle_ffn_reproduces_the_reference_modules_output(fam, dt, tag):
     z = load_golden(f"ffn_ref_{fam}_{tag}.npz")
     h, f, e, seed = [int(v) for v in z["meta"]]
-    gate, experts, _ = make_weights("nllb" if fam == "fsgpt" else fam, h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}))
+    gate, experts, _ = make_weights({"fsgpt": "nllb", "switchgated": "deepseek"}.get(fam, fam), h, f, e, seed, dt, **({"gate_std": 0.5} if fam in ("nllb", "switch", "fsgpt") else {}))
     np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
     for i in range(3):
         x = tt(z[f"x{i}"], dt)
@@ -59,7 +60,7 @@ def test_live_reference_ffn_equals_oracle_on_fresh_cases():
     for fam, dt, _ in CASES:
         for t in (1, 3, 64):
             h, f = 128 * int(torch.randint(1, 4, (1,), generator=g)), 32 * int(torch.randint(1, 9, (1,), generator=g))
-            _, experts, _ = make_weights("nllb" if fam == "fsgpt" else fam, h, f, 1, 500 + t, dt)
+            _, experts, _ = make_weights({"fsgpt": "nllb", "switchgated": "deepseek"}.get(fam, fam), h, f, 1, 500 + t, dt)
             x = acts(t, h, dt, 600 + t)
             assert torch.equal(ref_lib.expert_ffn(x, experts[0], ET[fam]), R.expert_ffn(x, experts[0], ET[fam])), (fam, dt, t, h, f)
 
