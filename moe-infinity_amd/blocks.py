@@ -104,6 +104,14 @@ class DeepseekMoEBlock(_MoeBlockBase):
 
     @staticmethod
     def engine_config(config, num_layers, **kw) -> Cf.EngineConfig:
+        # DeepSeek-V3's gate (sigmoid scores + e_score_correction_bias + top-2-sum group selection,
+        # moe_infinity/models/modeling_deepseek_v3/modeling_deepseek.py:443-483) is NOT one of the fused routers: refuse loudly
+        # instead of routing with V2's softmax rule.  Such a model runs through the dense-mask path (its own Python MoEGate +
+        # prefetch_op.expert_dispatcher / moeinf_dispatch_mask), which does not look at the gate at all.
+        if getattr(config, "scoring_func", "softmax") != "softmax" or getattr(config, "topk_method", "greedy") == "noaux_tc":
+            raise NotImplementedError("DeepSeek-V3 gate (scoring_func=%r, topk_method=%r) is not a fused router of this engine: keep the model's "
+                                      "Python MoEGate and dispatch through prefetch_op.expert_dispatcher (moeinf_dispatch_mask)"
+                                      % (getattr(config, "scoring_func", None), getattr(config, "topk_method", None)))
         grouped = getattr(config, "topk_method", "greedy") == "group_limited_greedy"
         return Cf.EngineConfig(num_layers=num_layers, num_experts=config.n_routed_experts, expert_type=Cf.EXPERT_DEEPSEEK,
                                hidden=config.hidden_size, inter=config.moe_intermediate_size,

@@ -185,3 +185,19 @@ def test_reference_expert_prefetcher_drives_the_adapter_unmodified():
 
     assert flat(ref_eng.calls) == flat(ours_eng.calls)
     assert flat(ref_eng.calls)[1] == [(2, 3), (1, 0), (1, 2), (2, 1)], "descending predicted share"
+
+
+def test_the_deepseek_v3_gate_is_refused_not_misrouted():
+    """modeling_deepseek_v3/modeling_deepseek.py:443-483 scores with a sigmoid plus a correction bias and picks groups by
+    their top-2 sum; the fused DeepSeek router implements V2's softmax rule only, so a V3 config must fail loudly."""
+    import types
+
+    from moe_infinity_amd.blocks import DeepseekMoEBlock
+    base = dict(hidden_size=64, moe_intermediate_size=32, n_routed_experts=8, num_experts_per_tok=2, n_shared_experts=1,
+                norm_topk_prob=False, routed_scaling_factor=1.0, n_group=None, topk_group=None)
+    ok = DeepseekMoEBlock.engine_config(types.SimpleNamespace(topk_method="greedy", **base), 1, max_tokens=4)
+    assert ok.router_kind == Cf.ROUTER_DEEPSEEK and ok.num_experts == 8
+    for bad in (dict(topk_method="noaux_tc", scoring_func="sigmoid"), dict(topk_method="greedy", scoring_func="sigmoid"),
+                dict(topk_method="noaux_tc")):
+        with pytest.raises(NotImplementedError, match="expert_dispatcher"):
+            DeepseekMoEBlock.engine_config(types.SimpleNamespace(**{**base, **bad}), 1, max_tokens=4)
