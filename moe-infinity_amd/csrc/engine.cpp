@@ -845,7 +845,7 @@ static void account_profile(moeinf_engine* g, const int32_t* mirror, int T, bool
   g->prof.ffn1_bytes += b1;
   g->prof.ffn2_bytes += b2;
   if (local) {
-    g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? 2 : 4) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
+    g->prof.route_bytes += (int64_t)E * H * (g->cfg.gate_dtype == MOEINF_DTYPE_F32 ? 4 : 2) + (int64_t)T * H * es + (int64_t)T * E * 4 * 2 + (int64_t)T * K * 12;
     g->prof.combine_bytes += (rows + Tsh) * H * es + (int64_t)T * H * es;
   }
   g->prof.forwards += 1;
@@ -1245,7 +1245,9 @@ void make_index_args(const moeinf_engine* g, int T, int batch_rows, int32_t* mir
 // decode-sized DeepSeek forwards: the shared expert (routing-independent, always resident) runs INSIDE the two router launches
 bool can_hide_shared(const moeinf_engine* g, int T) {
   static const bool hide_env = getenv("MOEINF_HIDE_SHARED") ? atoi(getenv("MOEINF_HIDE_SHARED")) != 0 : true;
-  return hide_env && g->has_shared && g->dt == DT_BF16 && T <= kHideSharedMaxTokens && T * g->K <= 64 && g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
+  // (fp16 since round 5: gate_shared1 / route_shared2 / moe_front1 on half_t; fp32 experts keep the shared expert behind the router)
+  // (the gate is in the model dtype or fp32: moeinf_create refuses the mixed pairs)
+  return hide_env && g->has_shared && (g->dt == DT_BF16 || g->dt == DT_F16) && T <= kHideSharedMaxTokens && T * g->K <= 64 && g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK;
 }
 void hidden_shared_stages(const moeinf_engine* g, int layer, const void* x_dev, FfnStage& sh1, FfnStage& sh2) {
   fill_stage(g, layer, 1, sh1, 0);

@@ -198,7 +198,11 @@ hipError_t launch_gate_shared1(const RouteArgs& a, const FfnStage& s, hipStream_
   static const int nw8 = env_int("MOEINF_SH1_NW", 8) == 8;  // round 4: 0.984 -> 0.968 ms/token (A/B/A in one run); 4 = the four-wave form
 #define GS1(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU>), grid, dim3(256), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
 #define GS8(WT, UU) hipLaunchKernelGGL((gate_shared1_kernel<uint16_t, WT, TT, uint16_t, UU, 8>), grid, dim3(512), 0, st, (const uint16_t*)a.x, (const WT*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s)
-  if (nw8) {
+  if (a.x_dtype == DT_F16) {  // fp16 model (round 5): the default eight-wave form only, gate fp16 or fp32
+    if (a.gate_dtype == DT_F16) hipLaunchKernelGGL((gate_shared1_kernel<half_t, half_t, TT, half_t, 8, 8>), grid, dim3(512), 0, st, (const half_t*)a.x, (const half_t*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s);
+    else if (a.gate_dtype == DT_F32) hipLaunchKernelGGL((gate_shared1_kernel<half_t, float, TT, half_t, 8, 8>), grid, dim3(512), 0, st, (const half_t*)a.x, (const float*)a.gate_w, a.logits, a.T, a.H, a.E, rb, n_gate, s);
+    else return hipErrorInvalidValue;
+  } else if (nw8) {
     if (a.gate_dtype == DT_BF16) GS8(uint16_t, 8); else GS8(float, 8);
   } else if (a.gate_dtype == DT_BF16) { if (u8) GS1(uint16_t, 8); else GS1(uint16_t, 4); }
   else { if (u8) GS1(float, 8); else GS1(float, 4); }
@@ -463,7 +467,8 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
   const dim3 grid(1 + (s.R_sh + 15) / 16);
   const EpFuse pk = pack ? *pack : no_pack();
 #define RS2(NWV, UU) hipLaunchKernelGGL((route_shared2_kernel<uint16_t, NWV, UU>), grid, dim3(NWV * 64), 0, st, r, a, s, pk)
-  if (nw == 16) { if (u == 8) RS2(16, 8); else RS2(16, 4); }
+  if (s.dtype == DT_F16) hipLaunchKernelGGL((route_shared2_kernel<half_t, 8, 4>), grid, dim3(512), 0, st, r, a, s, pk);  // fp16: the default form only
+  else if (nw == 16) { if (u == 8) RS2(16, 8); else RS2(16, 4); }
   else if (nw == 4) { if (u == 8) RS2(4, 8); else RS2(4, 4); }
   else { if (u == 8) RS2(8, 8); else RS2(8, 4); }
 #undef RS2

@@ -899,7 +899,7 @@ def _fp16_block(family, x, gate, experts, k, shared):
 
 
 @pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 16, 4, 2), ("nllb", 16, 2, 0), ("switch", 8, 1, 0)])
-@pytest.mark.parametrize("t", [1, 7, 40, 300], ids=["batch1_selfrouting_or_generic", "decode_batch", "many_rows_token_tiles", "compute_bound_gemm_on_the_f16_matrix_instruction"])
+@pytest.mark.parametrize("t", [1, 3, 7, 40, 300], ids=["batch1_selfrouting_or_generic", "small_decode_batch_selfrouting", "decode_batch", "many_rows_token_tiles", "compute_bound_gemm_on_the_f16_matrix_instruction"])
 def test_fp16_experts_all_families(family, e, k, n_shared, t):
     dt = torch.float16
     h, f = 512, 384
