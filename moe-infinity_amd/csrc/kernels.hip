@@ -738,9 +738,8 @@ __global__ __launch_bounds__(NW * 64) void ffn2_decode1_kernel(FfnStage s) {
 // (that tail costs 3.5 us per launch, tools/ffn_micro.hip).  H/16 = 256 workgroups for Mixtral = one per CU.
 // Summation order inside an expert (waves 0..NWE-1, tiles in ascending k inside a wave) and the combine order
 // (ascending expert id) are those of ffn2_decode1_kernel, so the two produce identical bits.  Requires K % 32 == 0.
-template <int NWE, int U>
+template <typename T, int NWE, int U>  // T: uint16_t = bf16, half_t = fp16 (round 5)
 __global__ __launch_bounds__(2 * NWE * 64) void ffn2_decode1_pair_kernel(FfnStage s) {
-  typedef uint16_t T;
   constexpr int EPT = 32, EPV = 8;
   __shared__ float red[2][NWE][16];
   __shared__ float yv[2][16];
@@ -878,15 +877,16 @@ __global__ __launch_bounds__(KX * NWE * 64) void ffn2_decode1_half_kernel(FfnSta
 
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   static const int pair_env = env_int("MOEINF_DEC1_PAIR", 1);  // 0: always the arrival-counter form; 4 / 8: waves per expert
-  if (pair_env && s2.dtype == DT_BF16 && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
+  if (pair_env && (s2.dtype == DT_BF16 || s2.dtype == DT_F16) && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
     const dim3 g1((s2.R + 15) / 16);
     // 4 waves per expert (8 per CU), batches of 4 tiles: 38.9 us per Mixtral launch; 8 waves per expert 40.5; the
     // arrival-counter form 41.9
     static const int pu = env_int("MOEINF_DEC1_PAIR_U", 4);
-    if (pair_env == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<8, 4>), g1, dim3(1024), 0, st, s2);
-    else if (pu == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 8>), g1, dim3(512), 0, st, s2);
-    else if (pu == 2) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 2>), g1, dim3(512), 0, st, s2);
-    else hipLaunchKernelGGL((ffn2_decode1_pair_kernel<4, 4>), g1, dim3(512), 0, st, s2);
+    if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<half_t, 4, 4>), g1, dim3(512), 0, st, s2);  // fp16: the default form only
+    else if (pair_env == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 8, 4>), g1, dim3(1024), 0, st, s2);
+    else if (pu == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 8>), g1, dim3(512), 0, st, s2);
+    else if (pu == 2) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 2>), g1, dim3(512), 0, st, s2);
+    else hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 4>), g1, dim3(512), 0, st, s2);
     return hipGetLastError();
   }
   // K = 3..8: eight columns per workgroup, every expert and the combine inside it (MOEINF_DEC1_HALF=0: arrival-counter form)
