@@ -251,9 +251,11 @@ def test_error_paths_do_not_abort():
     from moe_infinity_amd import config as Cf
     from moe_infinity_amd import MoEEngine
 
-    with pytest.raises(MoeInfError):
-        MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=Cf.EXPERT_SWITCH_GATED, hidden=256, inter=512,
-                                  top_k=1, router_kind=Cf.ROUTER_SWITCH))
+    with pytest.raises(MoeInfError):  # not one of expert_module.h:13-18 (every one of those is built since round 5)
+        MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=7, hidden=256, inter=512, top_k=1, router_kind=Cf.ROUTER_SWITCH))
+    with pytest.raises(MoeInfError):  # the fp8 expert dtype (id 3) is declared by the reference and not built here: refused, not mis-read
+        MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=Cf.EXPERT_MIXTRAL, hidden=256, inter=512, top_k=2,
+                                  router_kind=Cf.ROUTER_MIXTRAL, dtype=3))
     eng = engine_for("mixtral", 256, 512, 8, 2, torch.bfloat16, max_tokens=4)
     gate = torch.zeros(8, 256, dtype=torch.bfloat16, device=DEV)
     x = torch.zeros(2, 256, dtype=torch.bfloat16, device=DEV)
