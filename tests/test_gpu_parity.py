@@ -855,6 +855,29 @@ def test_short_last_pass_of_the_256x256_kernel(family, t):
     eng.close()
 
 
+@pytest.mark.parametrize("family", ["mixtral", "nllb"])
+@pytest.mark.parametrize("t", [257, 265, 288, 289, 300, 320, 321, 600], ids=lambda t: f"{t % 256 if t < 512 else t - 512}_tokens_in_the_last_pass")
+def test_short_last_pass_of_the_256x256_kernel_longer_reductions(family, t):
+    """The short last pass again at H = 512, F = 1024 (2 and 4 times the reduction length of the test above: eight and sixteen
+    stages of the three-deep short-pass ring) with 1, 9, 32, 33, 44, 64, 65 and 88 tokens in it.  (Written for the round-5
+    experiment that cut such passes along the weight rows into 2 / 4 workgroups — parity green, no consistent gain, removed:
+    DESIGN.md section 7.1 — and kept as coverage of the unsplit form.)"""
+    e, k = (1, 1) if family == "mixtral" else (2, 2)
+    h, f = 512, 1024
+    gate, experts, shared = make_weights(family, h, f, e, 2800 + t, torch.bfloat16, gate_std=0.5 if family == "nllb" else 0.02)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, max_tokens=t)
+    register_all(eng, experts, shared)
+    x = acts(t, h, torch.bfloat16, 2801 + t)
+    ref = R.block_mixtral(x[None], gate, experts, top_k=k) if family == "mixtral" else R.block_nllb(x[None], gate, experts)
+    assert all(int(v.shape[0]) == t for v in ref.expert_out.values())
+    for i in range(2):
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        rows = oracle_expert_rows(ref, e)
+        assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, f"expert rows, forward {i}", ulps=2.0 if family == "nllb" else 1.0)
+        assert_block_close(out, ref, torch.bfloat16, f"{family} {t}-token block, forward {i}")
+    eng.close()
+
+
 @pytest.mark.parametrize("family,t,h,f,e,k,n_shared", [
     ("mixtral", 1400, 256, 384, 4, 2, 0),     # 700 rows per expert: 3 token passes, F = 3 row blocks of 128
     ("deepseek", 2000, 256, 192, 8, 3, 2),    # routed 750 rows; shared expert 2000 rows x F_shared 384 (its own K and R)
