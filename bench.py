@@ -956,6 +956,7 @@ def main():
                 others.append({"workload": f"{o['label']} MoE layers: L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}"
                                            + (f" +shared F={o['cfg'].shared_inter}" if o["cfg"].shared_inter else "")
                                            + f", decode batch {b}, device_memory_ratio={args.ratio}",
+                               "dtype": "f32" if o["dt"] == torch.float32 else "bf16", "batch": b,
                                "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2),
                                "windows_ms": o["windows_ms"],
                                "algorithmic_GB_per_step": None if not (k1 and (k2 or o["kernels"].get("one_launch_per_layer"))) else round(step_bytes / 1e9, 3),
@@ -979,7 +980,7 @@ def main():
                     o = run_workload(args, wl, b, world, rank, local_rank, dev, False, False, dist, dtype_id=Cf.DTYPE_F16, sample=(2, 2))
                     pr = o["parity"] or {}
                     others.append({"workload": f"{o['label']} MoE layers with fp16 experts (dtype id 2): L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}, decode batch {b}",
-                                   "dtype": "fp16", "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2), "windows_ms": o["windows_ms"],
+                                   "dtype": "fp16", "batch": b, "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2), "windows_ms": o["windows_ms"],
                                    "north_star_tolerance": "within 1e-3 fp16",
                                    "mean_rel_err": pr.get("mean_rel_err"), "max_rel_err": pr.get("max_rel_err"),
                                    "mean_rel_err_within_1e-3": None if pr.get("mean_rel_err") is None else bool(pr["mean_rel_err"] <= 1e-3),
@@ -1034,8 +1035,19 @@ def main():
         for pr in [r["parity"]] + [o.get("parity") for o in others]:
             if pr is not None and not pr.get("ok", True):
                 parity_ok = False
+        # everything measured -> bench_details.json (+ stderr); the driver's stdout line is the compact form (< 8 KB,
+        # bench_line.py: round 5's 24 KB line could not be parsed by the driver)
+        import bench_line
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        written = bench_line.write_details(line, here)
+        print("[bench] details: " + json.dumps(line), file=sys.stderr)
+        log("full result object written to", ", ".join(written) or "(nowhere: not writable)")
+        short = bench_line.compact(line)
+        bench_line.check(short)
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        sys.stderr.flush()
+        os.write(real_stdout, (json.dumps(short) + "\n").encode())
     if use_ep:
         dist.destroy_process_group()
     if not parity_ok:

@@ -30,7 +30,17 @@ def _bench(extra_env, *flags, timeout=900):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-4000:])
-    return json.loads(lines[0]), time.time() - t0, r.stderr
+    # the driver's contract for the line itself (< 8 KB, required keys): round 5's 24 KB line could not be parsed
+    sys.path.insert(0, ROOT)
+    import bench_line
+
+    bench_line.check(lines[0])
+    line = json.loads(lines[0])
+    with open(os.path.join(ROOT, line["details"])) as f:  # everything else the run measured
+        details = json.load(f)
+    assert details["value"] == line["value"] and details["ms_per_step"] == line["ms_per_step"]
+    line["_details"] = details
+    return line, time.time() - t0, r.stderr
 
 
 def test_bench_spawns_its_own_two_ranks_and_they_exchange_over_peer_store():
@@ -39,8 +49,8 @@ def test_bench_spawns_its_own_two_ranks_and_they_exchange_over_peer_store():
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2, line
     assert line["config"]["parallelism"] == "ep2"
     assert line["parity"]["ok"] and line["parity"]["routing_bit_exact"], line["parity"]
-    tr = line["ep_transport"]
-    assert tr["chosen"] == "peer-store", (tr, err[-2000:])
+    assert line["ep_transport"]["chosen"] == "peer-store", (line["ep_transport"], err[-2000:])
+    tr = line["_details"]["ep_transport"]
     assert any("probation passed on every rank" in c for c in tr["candidates"]), tr
     assert line["value"] > 0 and line["ep_phases_us_per_layer"], line
 
@@ -50,8 +60,8 @@ def test_auto_transport_falls_back_in_bounded_time_when_a_peer_never_publishes()
     self-test's send half is skipped) — what a rank behind a dead xGMI link looks like to its peers.  Every rank must come
     out of the bootstrap with the SAME fallback transport, within seconds, and the line must still be parity-green."""
     line, dt, err = _bench({"MOEINF_EP_TEST_SILENT_RANK": "1"}, "--layers", "2", "--cpu-sample-layers", "2", "--cpu-sample-steps", "2", "--ep-transport", "auto")
-    tr = line["ep_transport"]
-    assert tr["chosen"] == "torch", tr  # (rccl: not on a gloo group / a shared GPU)
+    assert line["ep_transport"]["chosen"] == "torch", line["ep_transport"]
+    tr = line["_details"]["ep_transport"]  # (rccl: not on a gloo group / a shared GPU)
     notes = " | ".join(tr["candidates"])
     assert "peer-store: not available" in notes and "timeout" in notes, notes
     assert line["parity"]["ok"], line["parity"]
