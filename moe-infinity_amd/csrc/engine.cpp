@@ -149,7 +149,7 @@ extern "C" int moeinf_sync(moeinf_engine* g) { return sync_last(g); }
 
 extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (!g) return MOEINF_OK;
-  hipSetDevice(g->cfg.device_id);
+  DeviceScope on_dev_(g->cfg.device_id);
   hipDeviceSynchronize();
   if (g->d_layer_trace) {  // debugging aid: "block t0 t1 t2 t3" (100 MHz ticks) of the last one-launch layer
     std::vector<unsigned long long> tr((size_t)g->layer1_trace_blocks * 4);
@@ -223,7 +223,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(MOEINF_ERR_INVALID, "device_id %d but %d HIP devices visible", cfg->device_id, ndev);
-  HIPCHK(hipSetDevice(cfg->device_id));
+  DeviceScope on_dev_(cfg->device_id); HIPCHK(on_dev_.err);
   moeinf_engine* g = new moeinf_engine();
   g->cfg = *cfg;
   memset(&g->st, 0, sizeof g->st);
@@ -349,7 +349,7 @@ extern "C" int moeinf_register_expert(moeinf_engine* g, int layer, int expert, c
   CHK(check_le(g, layer, expert));
   if (!owns(g, expert)) return fail(MOEINF_ERR_INVALID, "expert %d is not owned by ep_rank %d of %d", expert, g->cfg.ep_rank, g->cfg.ep_size);
   if (blob && nbytes != g->lay.total) return fail(MOEINF_ERR_INVALID, "expert blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay.total);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   const int idx = node_index(g, layer, expert);
   Node& n = g->nodes[idx];
   if (n.host_pending) {  // a background disk read of the old payload is under way: let it finish into its block first
@@ -386,7 +386,7 @@ extern "C" int moeinf_register_shared(moeinf_engine* g, int layer, const void* b
   if (!g->has_shared) return fail(MOEINF_ERR_INVALID, "engine was created without a shared expert");
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   if (!blob || nbytes != g->lay_sh.total) return fail(MOEINF_ERR_INVALID, "shared blob is %lld bytes, layout needs %lld", (long long)nbytes, (long long)g->lay_sh.total);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   if (!g->shared_dev[layer]) HIPCHK(hipMalloc(&g->shared_dev[layer], (size_t)g->dlay_sh.total));
   // one-off, synchronous: tensor by tensor through the demand lane's first staging buffer
   HIPCHK(hipStreamSynchronize(g->demand.copy));
@@ -1295,7 +1295,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (!route_only && g->cfg.ep_size > 1) return fail(MOEINF_ERR_STATE, "engine is expert-parallel (ep_size %d): run ROUTE_ONLY here and moeinf_ep_pack / ep_expert_ffn / ep_combine around the all-to-alls", g->cfg.ep_size);
   if (!route_only && !(flags & MOEINF_FWD_NO_COMBINE) && !out_dev) return fail(MOEINF_ERR_INVALID, "out_dev is NULL");
   StallTrace strace(layer, tokens);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   strace.mark("set_device");
   hipStream_t st = (hipStream_t)stream;
   const int T = tokens, K = g->K, E = g->E;
@@ -1429,7 +1429,7 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail(MOEINF_ERR_INVALID, "mask_elem_bytes must be 1, 4 or 8");
   // a token may be routed to up to E experts in a mask; the workspace holds max_tokens*K rows
   if (tokens <= 0 || tokens > g->cfg.max_tokens) return fail(MOEINF_ERR_INVALID, "tokens %d not in 1..max_tokens(%d)", tokens, g->cfg.max_tokens);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   const int E = g->E;
   drain_mirrors(g, true);
@@ -1470,7 +1470,7 @@ extern "C" int moeinf_combine(moeinf_engine* g, const void* x_dev, const void* y
   const int kind = g->cfg.router_kind;
   if ((kind == MOEINF_ROUTER_SWITCH || kind == MOEINF_ROUTER_NLLB) && !x_dev) return fail(MOEINF_ERR_INVALID, "x_dev is needed for the Switch/NLLB passthrough rules");
   if (kind == MOEINF_ROUTER_SWITCH && !router_prob_dev) return fail(MOEINF_ERR_INVALID, "router_prob_dev is needed for the Switch block");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   drain_mirrors(g, true);
   const int T = tokens, K = g->K;
@@ -1496,7 +1496,7 @@ extern "C" int moeinf_combine(moeinf_engine* g, const void* x_dev, const void* y
 extern "C" int moeinf_copy_routing_dev(moeinf_engine* g, float* logits_dev, int32_t* topk_idx_dev, float* topk_w_dev, void* stream) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "no forward has run yet");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   const size_t T = (size_t)g->last_T;
   if (logits_dev) HIPCHK(hipMemcpyAsync(logits_dev, g->d_logits, T * g->E * 4, hipMemcpyDeviceToDevice, st));
@@ -1516,7 +1516,7 @@ extern "C" int moeinf_set_profiling(moeinf_engine* g, int enabled) {
 static int check_device_flag(moeinf_engine* g);
 extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   if (g->last_stream || g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
   CHK(check_device_flag(g));
   drain_mirrors(g, true);
@@ -1557,7 +1557,7 @@ static int check_device_flag(moeinf_engine* g) {
 static int sync_last(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "no forward has run yet");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   HIPCHK(hipStreamSynchronize(g->last_stream));
   return check_device_flag(g);
 }
@@ -1697,7 +1697,7 @@ extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* exper
   drain_mirrors(g, true);
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
   if (n < 0 || (n > 0 && !experts)) return fail(MOEINF_ERR_INVALID, "experts is NULL");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   for (int i = 0; i < n; ++i) {
     const int e = experts[i];
     if (e < 0 || e >= g->E) return fail(MOEINF_ERR_INVALID, "expert id %d out of range", e);
@@ -1740,7 +1740,7 @@ extern "C" int moeinf_is_resident(moeinf_engine* g, int layer, int expert, int32
 
 extern "C" int moeinf_sync_copies(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   g->draining = true;
   struct Undrain { moeinf_engine* g; ~Undrain() { g->draining = false; } } undrain{g};
   for (;;) {  // serve the whole pending queue, a window at a time
@@ -1816,7 +1816,7 @@ extern "C" int moeinf_set_cache_policy(moeinf_engine* g, int policy) {
 extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_bytes) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (device_memory_bytes < g->slot_bytes) return fail(MOEINF_ERR_OOM, "budget %lld bytes cannot hold one expert of %lld bytes", (long long)device_memory_bytes, (long long)g->slot_bytes);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   drain_mirrors(g, true);
   g->st.prefetch_cancelled += g->pq.clear_prefetch();
   HIPCHK(hipDeviceSynchronize());  // no kernel or copy may still touch a slot that is about to be freed
@@ -1875,7 +1875,7 @@ extern "C" int moeinf_set_cache_budget(moeinf_engine* g, int64_t device_memory_b
 extern "C" int moeinf_reserve_tokens(moeinf_engine* g, int max_tokens) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   if (max_tokens <= g->cfg.max_tokens) return MOEINF_OK;
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   drain_mirrors(g, true);
   HIPCHK(hipDeviceSynchronize());
   free_token_workspace(g);
@@ -1912,7 +1912,7 @@ extern "C" int moeinf_register_expert_from_store(moeinf_engine* g, int layer, in
     if (!m) return fail(MOEINF_ERR_INVALID, "tensor %u is not in the offload index", tensor_ids[i]);
     if ((int64_t)m->size != g->lay.size[i]) return fail(MOEINF_ERR_INVALID, "tensor %u is %llu bytes on disk, blob slot %d needs %lld", tensor_ids[i], (unsigned long long)m->size, i, (long long)g->lay.size[i]);
   }
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   const int idx = node_index(g, layer, expert);
   Node& nd = g->nodes[idx];
   set_node_store(nd, &st->s);  // counted: moeinf_store_close refuses while an engine may still re-read this expert

@@ -40,7 +40,7 @@ extern "C" int moeinf_ep_pack(moeinf_engine* g, const void* x_dev, void* send_de
   if (!g || !x_dev || !send_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack needs a preceding ROUTE_ONLY forward");
   if (cap_rows < ep_min_cap(g, g->last_T)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank) (worst case: every pair a rank can receive from these tokens)", cap_rows, ep_min_cap(g, g->last_T));
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   CHK(ep_alloc(g, cap_rows));
   return ep_pack_fixed(g, x_dev, send_dev, send_counts_dev, cap_rows, st);
@@ -91,7 +91,7 @@ static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, in
   if (batch_rows <= 0 || tokens % batch_rows) return fail(MOEINF_ERR_INVALID, "tokens %d not divisible by batch_rows %d", tokens, batch_rows);
   if (cap_rows < ep_min_cap(g, tokens)) return fail(MOEINF_ERR_INVALID, "cap_rows %d < %d = tokens * min(K, experts per rank)", cap_rows, ep_min_cap(g, tokens));
   if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   const int T = tokens, K = g->K, np = T * K;
   CHK(ep_alloc(g, cap_rows));
@@ -135,7 +135,7 @@ static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, in
 extern "C" int moeinf_ep_pack_compact(moeinf_engine* g, const void* x_dev, void* send_dev, int32_t* send_counts_dev, void* stream) {
   if (!g || !x_dev || !send_dev || !send_counts_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (g->last_layer < 0) return fail(MOEINF_ERR_STATE, "ep_pack_compact needs a preceding ROUTE_ONLY forward");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   const int np = g->last_T * g->K, ep = g->cfg.ep_size;
   CHK(ep_alloc(g, std::max(1, np)));
@@ -175,7 +175,7 @@ extern "C" int moeinf_ep_expert_ffn_rows(moeinf_engine* g, int layer, const void
 // kernel behind (y_dev = a local staging buffer there)
 static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev, void* y_dev, int nrows, hipStream_t st, const EpPeers* pv) {
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer out of range");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   const int E = g->E;
   if ((int64_t)nrows > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "ep rows %d exceed workspace (max_tokens*K = %d): create the engine with max_tokens >= ep_size*cap_rows/K", nrows, g->cfg.max_tokens * g->K);
   const int64_t ld = ep_row_elems(g);
@@ -272,7 +272,7 @@ extern "C" int moeinf_ep_combine(moeinf_engine* g, const void* x_dev, const void
 static int ep_combine_impl(moeinf_engine* g, const void* x_dev, const void* ret_dev, void* out_dev, int cap_rows, void* stream, const EpPeers* pv) {
   if (!g || !x_dev || !ret_dev || !out_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (!g->d_ep_pair_pos || cap_rows != g->ep_cap_rows) return fail(MOEINF_ERR_STATE, "ep_combine needs a preceding ep_pack with the same cap_rows (0 after ep_pack_compact)");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   if (g->has_shared && !g->last_hidden_shared) {
     // the shared expert (always resident, replicated on every rank) runs on this rank's own tokens; for decode-sized
@@ -345,7 +345,7 @@ extern "C" int moeinf_ep_comm_prepare(moeinf_engine* g, int cap_tokens) {
   if (g->ep_comm) return fail(MOEINF_ERR_STATE, "the engine already has a communicator");
   std::string err;
   if (!RcclApi::get(&err)) return fail(MOEINF_ERR_UNSUPPORTED, "%s", err.c_str());
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   // exchange buffers: cap_rows row slots per peer, both directions (send/recv rows carry the 16-byte id tail)
   const int cap_rows = ep_min_cap(g, cap_tokens);
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
@@ -383,7 +383,7 @@ extern "C" int moeinf_ep_comm_init(moeinf_engine* g, const void* unique_id, int 
 extern "C" int moeinf_ep_all_to_all(moeinf_engine* g, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream) {
   if (!g || !send_dev || !recv_dev || bytes_per_peer <= 0) return fail(MOEINF_ERR_INVALID, "bad all_to_all arguments");
   if (!g->ep_comm) return fail(MOEINF_ERR_STATE, "no communicator: call moeinf_ep_comm_init first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   const std::string err = rccl_all_to_all(RcclApi::get(nullptr), g->ep_comm, g->cfg.ep_size, send_dev, recv_dev, (size_t)bytes_per_peer, (hipStream_t)stream);
   if (!err.empty()) return fail(MOEINF_ERR_HIP, "%s", err.c_str());
   return MOEINF_OK;
@@ -405,7 +405,7 @@ extern "C" int moeinf_ep_peer_export(moeinf_engine* g, int cap_tokens, void* blo
     return MOEINF_OK;
   }
   if (g->cfg.ep_size > EP_MAX_PEERS) return fail(MOEINF_ERR_UNSUPPORTED, "peer-store exchange: ep_size %d > %d", g->cfg.ep_size, EP_MAX_PEERS);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   const int cap_rows = ep_min_cap(g, cap_tokens);
   const size_t n = (size_t)g->cfg.ep_size * cap_rows;
   if ((int64_t)n > (int64_t)g->cfg.max_tokens * g->K) return fail(MOEINF_ERR_INVALID, "the owner side needs room for ep_size*cap_rows = %zu rows: create the engine with max_tokens >= %zu", n, (n + g->K - 1) / g->K);
@@ -438,7 +438,7 @@ extern "C" int moeinf_ep_peer_attach(moeinf_engine* g, const void* blobs, int nb
   if (!g || !blobs) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (nbytes != g->cfg.ep_size * kEpPeerBlobBytes) return fail(MOEINF_ERR_INVALID, "blobs must be ep_size * %d bytes, in rank order", kEpPeerBlobBytes);
   if (!g->ep_win.base) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_export first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   std::vector<EpPeerBlob> bs(g->cfg.ep_size);
   for (int p = 0; p < g->cfg.ep_size; ++p) memcpy(&bs[p], (const char*)blobs + (size_t)p * kEpPeerBlobBytes, sizeof(EpPeerBlob));
   if (g->ep_win.attached) {  // again (see moeinf_ep_peer_export): the same peers, or an error
@@ -469,7 +469,7 @@ extern "C" int moeinf_ep_peer_set_timeout_ms(moeinf_engine* g, int ms) {
 
 extern "C" int moeinf_ep_peer_release(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   HIPCHK(hipDeviceSynchronize());  // no kernel of this rank still reads or writes a window
   g->ep_win.destroy();
   g->ep_win_cap_tokens = 0;
@@ -499,7 +499,7 @@ extern "C" int moeinf_ep_peer_selftest(moeinf_engine* g, void* stream, int32_t* 
   if (!g || !ok) return fail(MOEINF_ERR_INVALID, "NULL argument");
   *ok = 0;
   if (!g->ep_win.attached) return fail(MOEINF_ERR_STATE, "call moeinf_ep_peer_attach first");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   g->ep_win.epoch += 1;
   EpPeers pv;
@@ -556,7 +556,7 @@ static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev,
   if (!x_dev || !gate_w_dev) return fail(MOEINF_ERR_INVALID, "NULL argument");
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
   if (g->has_shared && !g->shared_dev[layer]) return fail(MOEINF_ERR_STATE, "shared expert of layer %d not registered", layer);
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   hipStream_t st = (hipStream_t)stream;
   const int cap = g->ep_win.cap_rows, G = g->cfg.ep_size;
   const int64_t ld = ep_row_elems(g);
@@ -714,7 +714,7 @@ extern "C" int moeinf_ep_moe_forward(moeinf_engine* g, int layer, const void* x_
 
 extern "C" int moeinf_ep_get_profile(moeinf_engine* g, moeinf_ep_profile* out) {
   if (!g || !out) return fail(MOEINF_ERR_INVALID, "NULL argument");
-  HIPCHK(hipSetDevice(g->cfg.device_id));
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
   if (g->last_layer >= 0) HIPCHK(hipStreamSynchronize(g->last_stream));
   for (auto& r : g->ep_prof_pending) {
     float ms = 0.f;

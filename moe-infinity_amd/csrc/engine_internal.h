@@ -60,6 +60,23 @@ static inline int fail(int code, const char* fmt, ...) {
     hipError_t e_ = (call);                                                                       \
     if (e_ != hipSuccess) return fail(MOEINF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+// Every C entry point works on its engine's device and leaves the calling thread's current device as it found it: a
+// prefetch_handle drives one engine per device from ONE Python thread, and torch's notion of the current device must
+// not move under it (device='cuda' allocations, torch.cuda.current_stream()).  hipGetDevice is a thread-local read.
+struct DeviceScope {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev);
+    else prev = -1;  // nothing to restore
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 #define CHK(call)              \
   do {                         \
     int r_ = (call);           \

@@ -419,6 +419,25 @@ _ROUTER_OF = {Cf.EXPERT_SWITCH: Cf.ROUTER_SWITCH, Cf.EXPERT_SWITCH_GATED: Cf.ROU
               Cf.EXPERT_MIXTRAL: Cf.ROUTER_MIXTRAL, Cf.EXPERT_DEEPSEEK: Cf.ROUTER_DEEPSEEK}
 
 
+def slot_for_gpu(devices: Sequence[int], gpu_id: int, home: Optional[int]) -> int:
+    """Which of the handle's engines serves an ``enqueue_expert(..., gpu_id)``.
+
+    The reference's dispatch_local names ``gpu_id = expert_id % torch.cuda.device_count()`` (expert_executor.py:49-54), a
+    CUDA ordinal of ONE process that drives every GPU.  This handle drives ``devices`` (configure(devices=[...]); a single
+    device under WORLD_SIZE > 1 or configure(device_id=...)):
+      * distinct devices: ``gpu_id`` is looked up as an ordinal (devices=[2, 3], gpu_id 3 -> engine 1);
+      * the same device listed several times (tests: several engines on the one GPU of the box): ``gpu_id`` is the
+        engine's index;
+      * anything else — a GPU the process can see but this handle does not drive — is the expert's HOME engine (where
+        register_expert dealt it, expert % len(devices), model_topology.cpp:533-536), never an error: the unmodified
+        dispatch_local must keep working when device_count() > len(devices)."""
+    devices = list(devices)
+    fallback = home if home is not None else (gpu_id % len(devices) if gpu_id >= 0 else 0)
+    if len(set(devices)) == len(devices):
+        return devices.index(gpu_id) if gpu_id in devices else fallback
+    return gpu_id if 0 <= gpu_id < len(devices) else fallback
+
+
 class expert_dispatcher:
     """expert_dispatcher(num_experts, num_layers, dtype, expert_type, num_threads)
     (py_archer_prefetch.cpp:84-92, core/parallel/expert_dispatcher.h:27-137).  ``num_threads`` sized the reference's
@@ -497,17 +516,16 @@ class expert_dispatcher:
 
     def enqueue_expert(self, layer_idx: int, expert_idx: int, gpu_id: int = 0, remote: bool = False):
         """EnqueueExpert -> Enqueue (expert_dispatcher.cpp:108-158): the expert runs on ``gpu_id`` unless it is resident on
-        another device already (:135-137).  ``remote`` has no effect in the reference either (it is only stored)."""
+        another device already (:135-137).  ``remote`` has no effect in the reference either (it is only stored).
+        ``gpu_id`` is the CUDA ordinal the reference's dispatch_local computes (expert_id % torch.cuda.device_count(),
+        expert_executor.py:49-54); a device this handle does not drive (one process per GPU on a box where the process
+        still sees all of them) means the expert's home engine: see slot_for_gpu()."""
         h = self.handle
         key = (int(layer_idx), int(expert_idx))
         if key not in h._expert_ids:
             raise RuntimeError(f"ExpertDispatcher::Enqueue: expert (layer {key[0]}, expert {key[1]}) was never registered")
-        gpu_id = int(gpu_id)
-        if gpu_id < 0 or gpu_id >= len(h.devices):
-            raise RuntimeError(f"enqueue_expert: gpu_id {gpu_id} out of range: this handle drives {len(h.devices)} expert device(s) "
-                               f"{h.devices} (prefetch_op.configure(devices=[...]); one process per GPU: ExpertParallelMoE, INTEGRATION.md section 6)")
-        slot = gpu_id
         home = h._slot_of.get(key)
+        slot = slot_for_gpu(h.devices, int(gpu_id), home)
         if home is not None and home != slot and h.engines[home] is not None and h.engines[home].is_resident(*key):
             slot = home  # "if (expert_node->node->device.is_cuda()) args.gpu_id = device.index()"
         if slot != home:

@@ -220,8 +220,18 @@ def test_dispatch_local_with_two_expert_devices_runs_every_expert_on_the_gpu_it_
         (out2, _, _, hit2), = disp.wait_expert()
         assert handle._slot_of[(0, e)] == 0 and hit2 == 0 and torch.equal(out2.cpu(), out.cpu())
         assert handle.engines[0].expert_counters()[0, e, 0] == 1
-        with pytest.raises(RuntimeError, match="gpu_id 2 out of range"):
-            disp.enqueue_expert(0, 0, 2, False)
+        # a gpu_id this handle does not drive (device_count() > len(devices): torchrun's default visibility) is the
+        # expert's home engine, not an error: the unmodified dispatch_local keeps working
+        home0 = handle._slot_of[(0, 0)]
+        m0 = torch.zeros(3, E, dtype=torch.bool, device=DEV)
+        m0[:, 0] = True
+        disp.set_inputs(hdn, m0)
+        disp.set_expected_queue(1)
+        disp.enqueue_expert(0, 0, 5, False)
+        (out3, _, idx3, _), = disp.wait_expert()
+        assert idx3 == 0 and handle._slot_of[(0, 0)] == home0
+        assert_model_close(out3.cpu(), R.expert_ffn(hdn.cpu(), lay["experts"][0], R.MIXTRAL_DENSE_ACT_DENSE), torch.bfloat16, "rows of an expert enqueued with a foreign gpu_id")
+        assert torch.cuda.current_device() == 0  # the C entry points leave the thread's device alone
     finally:
         handle.clean_up_resources()
         P.configure(devices=None)

@@ -201,3 +201,24 @@ def test_the_deepseek_v3_gate_is_refused_not_misrouted():
                 dict(topk_method="noaux_tc")):
         with pytest.raises(NotImplementedError, match="expert_dispatcher"):
             DeepseekMoEBlock.engine_config(types.SimpleNamespace(**{**base, **bad}), 1, max_tokens=4)
+
+
+def test_enqueue_expert_maps_a_cuda_ordinal_to_the_engine_that_serves_it():
+    """dispatch_local passes gpu_id = expert_id % torch.cuda.device_count() (expert_executor.py:49-54).  A handle that drives
+    fewer devices than the process can see must serve every such call from the expert's home engine, and devices=[2, 3]
+    must look gpu_id up as an ordinal, not use it as an index (prefetch_op.py:507)."""
+    from moe_infinity_amd.prefetch_op import slot_for_gpu
+
+    # one process per GPU on an 8-GPU box: the handle drives device 3 only, dispatch_local names e % 8
+    for e in range(16):
+        assert slot_for_gpu([3], e % 8, 0) == 0
+    # one process, two of four GPUs: ordinals 2 and 3 are engines 0 and 1; 0 and 1 are not driven -> home
+    assert slot_for_gpu([2, 3], 3, 0) == 1 and slot_for_gpu([2, 3], 2, 1) == 0
+    assert slot_for_gpu([2, 3], 0, 1) == 1 and slot_for_gpu([2, 3], 1, 0) == 0
+    # the reference's own form: every GPU driven, gpu_id == engine index == ordinal
+    for g in range(4):
+        assert slot_for_gpu([0, 1, 2, 3], g, (g + 1) % 4) == g
+    # several engines on one GPU (tests): gpu_id is the engine index; out of range -> home
+    assert slot_for_gpu([0, 0], 1, 0) == 1 and slot_for_gpu([0, 0], 0, 1) == 0 and slot_for_gpu([0, 0], 5, 1) == 1
+    # an expert that was never dealt a home (cannot happen after register_expert) still lands on a valid engine
+    assert slot_for_gpu([0, 1], 7, None) == 1 and slot_for_gpu([4], -1, None) == 0
