@@ -700,7 +700,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
 
         # attention stand-in (the MoE layers of a real model sit between attention blocks: profiles/r04_attention_block_time_*,
         # tools/attn_time.py): a bf16 matmul on the compute stream, repeated to the measured time
-        attn_us = 0.0 if main else args.offload_attn_us
+        attn_us = args.offload_attn_us if family == "deepseek" else 0.0  # (the measured attention time is DeepSeek-V2-Lite's)
         reps, one_us = 0, 0.0
         if attn_us > 0:
             ma = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
@@ -715,14 +715,46 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             one_us = (time.perf_counter() - t0) / 50 * 1e6
             reps = max(1, int(round(attn_us / one_us)))
 
-        def offload_leg(routing, policy, with_attn, speculate, nsteps_leg):
+        # speculation legs: a synthetic RESIDUAL stream.  The default inputs are independent per layer (seed 2024 + layer), so
+        # nothing a layer sees says anything about the next one; a transformer's hidden state changes little from one MoE layer
+        # to the next.  x_0 = the default rows of layer 0, x_{l+1} = rmsnorm(x_l + RES_EPS * n_l), n_l ~ N(0, 1) seeded:
+        # cos(x_l, x_{l+1}) = 1 / sqrt(1 + RES_EPS^2) = 0.894 at RES_EPS = 0.5.
+        RES_EPS = 0.5
+        xres = {}
+
+        def x_res(s, l):
+            key = (s % steps, l)
+            if key not in xres:
+                if l == 0:
+                    xres[key] = xs[warmup + (s % steps)][0].float()
+                else:
+                    gg = torch.Generator().manual_seed(777000 + 1000 * (s % steps) + l)
+                    x = x_res(s, l - 1) + RES_EPS * torch.randn(B, H, generator=gg).to(dev)
+                    xres[key] = x / x.pow(2).mean(-1, keepdim=True).sqrt()
+            return xres[key]
+
+        def offload_leg(routing, policy, with_attn, speculate, nsteps_leg, stream="independent", la_max=0):
             zipf = routing != "natural"
             gl = gates_z if zipf else gates
+            residual = stream == "residual"
+
+            def x_of(s, l):
+                if residual:
+                    x = x_res(s, l).to(dt)
+                    if zipf:
+                        x = x.clone()
+                        x[:, 0] = 4.0
+                    return x
+                return x_zipf(s, l) if zipf else xs[warmup + (s % steps)][l]
             eng.set_cache_policy(Cf.POLICY_LRU if policy == "lru" else Cf.POLICY_LFU_INCACHE)
             eng.set_cache_budget(slot)      # flush: one slot ...
             eng.set_cache_budget(budget)    # ... and back to the budget of this leg
             native, nseq = None, -1
-            if speculate:
+            if speculate == "lookahead":
+                # next-layer gate lookahead (moeinf_set_lookahead): layer l+1's gate over layer l's input rows, the predicted
+                # experts issued behind layer l's misses on the same copy stream
+                eng.set_lookahead(gl, max_experts=la_max or 2 * K)
+            elif speculate:
                 # the engine-side predictor (moeinf_set_predictor; reference: memory/expert_tracer.py + expert_predictor.py +
                 # expert_prefetcher.py): history = activation matrices of 8 earlier sequences under the same routing
                 from moe_infinity_amd.engine import FWD_ROUTE_ONLY, ExpertTracerNative
@@ -731,7 +763,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 for sq in range(8):
                     for s in range(8):
                         for l in range(L):
-                            eng.forward(l, x_zipf(sq * 8 + s, l) if zipf else xs[(sq * 8 + s) % nsteps][l], gl[l], batch_rows=batch_rows, flags=FWD_ROUTE_ONLY)
+                            eng.forward(l, x_of(sq * 8 + s, l) if (zipf or residual) else xs[(sq * 8 + s) % nsteps][l], gl[l], batch_rows=batch_rows, flags=FWD_ROUTE_ONLY)
                             for i in eng.routing()["topk_idx"].reshape(-1):
                                 if i >= 0:
                                     hist[sq, l, i] += 1
@@ -749,7 +781,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                         if with_attn:
                             for _ in range(reps):
                                 ma @ mb
-                        eng.forward(l, x_zipf(s, l) if zipf else xs[warmup + (s % steps)][l], gl[l], batch_rows=batch_rows, out=out)
+                        eng.forward(l, x_of(s, l), gl[l], batch_rows=batch_rows, out=out)
 
             steps_(0, 2)  # settle the cache
             eng.sync_copies()
@@ -762,14 +794,23 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             el = time.perf_counter() - t0
             eng.sync_copies()
             s_ = eng.stats()
-            if speculate:
+            if speculate == "lookahead":
+                eng.set_lookahead(None)
+            elif speculate:
                 eng.set_predictor(None)
                 native.finish_entry(nseq)
                 eng.set_prefetch_governor(0.0, 16)
             mis = s_["expert_misses"]
             link = s_["h2d_bytes"] / s_["h2d_busy_ms"] / 1e6 if s_["h2d_busy_ms"] > 0 else None
             attn_ms = L * reps * one_us / 1e3 if with_attn else 0.0
-            return {"routing": routing, "policy": policy, "speculation": "engine predictor, lookahead 2, min_share 0.05, governor 0.5" if speculate else "none (on-demand fetches only)",
+            spec_name = {False: "none (on-demand fetches only)", True: "engine predictor, lookahead 2, min_share 0.05, governor 0.5",
+                         "lookahead": f"next-layer gate lookahead, the {la_max or 2 * K} most confident predictions per layer, issued behind the layer's misses"}[speculate]
+            done = s_["prefetch_useful"] + s_.get("prefetch_wasted", 0)
+            return {"routing": routing, "policy": policy, "speculation": spec_name,
+                    "speculation_kind": {False: "none", True: "eam", "lookahead": f"gate-lookahead top{la_max or 2 * K}"}[speculate],
+                    "activations": f"residual stream x_(l+1) = rmsnorm(x_l + {RES_EPS} n_l), cos 0.894" if residual else "independent per layer (seed 2024 + layer)",
+                    "prefetch_precision": None if not s_["prefetch_issued"] else round(s_["prefetch_useful"] / max(1, s_["prefetch_issued"]), 4),
+                    "prefetch_wasted": s_.get("prefetch_wasted"), "prefetch_settled": done,
                     "attention_standin_us_per_layer": round(reps * one_us, 1) if with_attn else 0.0,
                     "steps": nsteps_leg, "ms_per_token": round(el * 1e3 / nsteps_leg / B, 3),
                     "moe_ms_per_token_without_the_standin": round(el * 1e3 / nsteps_leg / B - attn_ms / B, 3),
@@ -816,6 +857,12 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 lg = offload_leg("zipf1.2", "lfu_incache", True, speculate, zsteps)
                 lg.pop("_raw")
                 legs.append(lg)
+            # ... and on a residual stream, where the next layer IS predictable: on demand / history (EAM) / next-layer gate
+            for routing in ("natural", "zipf1.2"):
+                for speculate, la_max in ((False, 0), (True, 0), ("lookahead", 1), ("lookahead", 2), ("lookahead", K)):
+                    lg = offload_leg(routing, "lfu_incache", True, speculate, zsteps if routing != "natural" else msteps, stream="residual", la_max=la_max)
+                    lg.pop("_raw")
+                    legs.append(lg)
         miss["sub_legs"] = legs
         eng.set_cache_policy(Cf.POLICY_LRU if args.policy == "lru" else Cf.POLICY_LFU_INCACHE)
 

@@ -336,6 +336,19 @@ int moeinf_tracer_get_eam(moeinf_tracer* tr, int64_t seq_id, double* eam_out);
  * Python with a D2H read per layer, expert_tracer.py:94-125, and requests EVERY predicted expert).  tr == NULL or
  * seq_id < 0 detaches.  The tracer must outlive the attachment. */
 int moeinf_set_predictor(moeinf_engine* eng, moeinf_tracer* tr, int64_t seq_id, int lookahead_layers, float min_share, int max_experts);
+/* Next-layer gate lookahead (speculation from the activations instead of from history).  With the gate weights of every
+ * layer registered (borrowed device pointers, [E, H] each, cfg.gate_dtype; n_layers = cfg.num_layers), a decode-sized
+ * forward (tokens <= 8) of layer l that takes the decision path also applies layer l+1's gate to ITS OWN input rows — in
+ * a transformer the residual stream changes little from one layer to the next, so that top-k is a prediction of layer
+ * l+1's routing — and, once layer l's misses are on the link and its FFN is launched, issues the predicted experts that
+ * are not resident BEHIND those misses on the same copy stream (of the max_experts most confident predictions — largest
+ * gate weight first; the link idles for about one small expert per layer, so 1-2 is the useful range —; never
+ * evicting the protected set or the experts of the layer in flight).  The link then stays busy while layer l computes and
+ * layer l+1's attention runs, instead of idling until layer l+1 routes.  Counted as speculative copies (prefetch_issued /
+ * prefetch_useful / prefetch_wasted of moeinf_stats).  Results of the forward are unchanged.  gate_w_dev == NULL or
+ * n_layers == 0 turns it off.  The reference has no counterpart: its prefetcher predicts from the EAM history only
+ * (moe_infinity/memory/expert_prefetcher.py:28-59) and is dormant for these models (mixtral.py:69-85 commented out). */
+int moeinf_set_lookahead(moeinf_engine* eng, const void* const* gate_w_dev, int n_layers, int max_experts);
 
 /* ---- disk tier: the reference's offload directory (host only) ----------------
  * Reads and writes `<offload_path>/archer_index` + `archer_param_<n>` in the reference's own format

@@ -191,6 +191,11 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   for (auto p : g->arena_chunks) hipHostFree(p);
   for (auto& n : g->nodes) { if (n.ready) hipEventDestroy(n.ready); if (n.ready1) hipEventDestroy(n.ready1); }
   for (auto e : g->event_pool) hipEventDestroy(e);
+  if (g->busy_mark) hipEventDestroy(g->busy_mark);
+  if (g->d_la_f) hipFree(g->d_la_f);
+  if (g->d_la_i) hipFree(g->d_la_i);
+  if (g->h_la_idx) hipHostFree(g->h_la_idx);
+  if (g->h_la_w) hipHostFree(g->h_la_w);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
@@ -300,6 +305,17 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     TRYHIP(hipMalloc(&g->d_y_sh, (size_t)kHideSharedMaxTokens * g->H * g->es));
   }
   for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i], kAioAlignment)));
+  {
+    // whole-blob transfers for experts up to MOEINF_H2D_WHOLE_BLOB_MB (64; 0 = always tensor by tensor): DeepSeek-V2-Lite's
+    // 16.5 MiB expert was three 5.5 MiB copies with an event pair and a re-tile launch each: 46 GB/s against the 54.5 that
+    // Mixtral's 112 MiB pieces reach (round 5 offload leg)
+    const char* e = getenv("MOEINF_H2D_WHOLE_BLOB_MB");
+    const int64_t cap = (e ? atoll(e) : 64) << 20;
+    bool vec_ok = true;
+    for (int i = 0; i < g->dlay.n; ++i) if (g->dlay.K[i] == 0 && (g->dlay.size[i] % 16) != 0) vec_ok = false;
+    g->whole_blob = g->lay.total <= cap && vec_ok;
+    if (g->whole_blob) g->stage_bytes = std::max<int64_t>(g->stage_bytes, align_up(g->lay.total, kAioAlignment));
+  }
   for (CopyLane* ln : {&g->demand, &g->prefetch}) {
     for (auto& b : ln->ring) {
       TRYHIP(hipMalloc(&b.dev, (size_t)g->stage_bytes));
@@ -541,36 +557,59 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   if (start && stop) HIPCHK(hipEventRecord(start, ln.copy));
   int order[4];
   const int n1 = copy_order(g->cfg.expert_type, order);
+  // first write into the slot.  (a) kernels of forward #last_use_seq may still read the previous tenant (fence
+  // ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence);
+  // (b) the previous tenant's OWN transfer may still be in flight on another lane (a prefetched expert is
+  // evictable from the moment its copy is issued): write-after-write on the slot
+  auto order_first_write = [&]() -> int {
+    if (s.last_use_seq > 0) {
+      const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
+      hipEvent_t fe = g->fence_ev[fs % kFenceRing];
+      if (hipEventQuery(fe) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipStreamWaitEvent(ln.retile, fe, 0));
+      }
+    }
+    if (victim >= 0) {
+      Node& vn = g->nodes[victim];
+      if (!vn.ready_waited && vn.ready && hipEventQuery(vn.ready) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipStreamWaitEvent(ln.retile, vn.ready, 0));
+      }
+      vn.ready_waited = true; vn.waited1 = true;
+    }
+    return MOEINF_OK;
+  };
+  if (g->whole_blob) {
+    StageBuf& b = ln.ring[ln.next];
+    ln.next = (ln.next + 1) % kStageRing;
+    if (b.used) HIPCHK(hipStreamWaitEvent(ln.copy, b.freed, 0));  // its previous content has been re-tiled
+    HIPCHK(hipMemcpyAsync(b.dev, n.host, (size_t)g->lay.total, hipMemcpyHostToDevice, ln.copy));
+    HIPCHK(hipEventRecord(b.filled, ln.copy));
+    HIPCHK(hipStreamWaitEvent(ln.retile, b.filled, 0));
+    CHK(order_first_write());
+    RetileBlob rb;
+    memset(&rb, 0, sizeof rb);
+    rb.src = b.dev; rb.dst = s.dev; rb.n = g->lay.n;
+    for (int i = 0; i < g->lay.n; ++i) {
+      rb.src_off[i] = g->lay.off[i]; rb.dst_off[i] = g->dlay.off[i];
+      rb.K[i] = g->dlay.K[i];
+      rb.R[i] = g->dlay.K[i] > 0 ? g->dlay.R[i] : (int)(g->dlay.size[i] / 16);
+    }
+    HIPCHK(launch_retile_blob(rb, g->dt, ln.retile));
+    HIPCHK(hipEventRecord(b.freed, ln.retile));
+    b.used = true;
+    HIPCHK(hipEventRecord(n.ready1, ln.retile));
+  } else
   for (int k = 0; k < g->lay.n; ++k) {
     const int i = order[k];
     StageBuf& b = ln.ring[ln.next];
-    ln.next ^= 1;
+    ln.next = (ln.next + 1) % kStageRing;
     if (b.used) HIPCHK(hipStreamWaitEvent(ln.copy, b.freed, 0));  // its previous content has been re-tiled
     HIPCHK(hipMemcpyAsync(b.dev, (const char*)n.host + g->lay.off[i], (size_t)g->lay.size[i], hipMemcpyHostToDevice, ln.copy));
     HIPCHK(hipEventRecord(b.filled, ln.copy));
     HIPCHK(hipStreamWaitEvent(ln.retile, b.filled, 0));
-    if (k == 0) {
-      // first write into the slot.  (a) kernels of forward #last_use_seq may still read the previous tenant (fence
-      // ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence);
-      if (s.last_use_seq > 0) {
-        const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
-        hipEvent_t fe = g->fence_ev[fs % kFenceRing];
-        if (hipEventQuery(fe) != hipSuccess) {
-          (void)hipGetLastError();
-          HIPCHK(hipStreamWaitEvent(ln.retile, fe, 0));
-        }
-      }
-      // (b) the previous tenant's OWN transfer may still be in flight on the other lane (a prefetched expert is
-      // evictable from the moment its copy is issued): write-after-write on the slot
-      if (victim >= 0) {
-        Node& vn = g->nodes[victim];
-        if (!vn.ready_waited && vn.ready && hipEventQuery(vn.ready) != hipSuccess) {
-          (void)hipGetLastError();
-          HIPCHK(hipStreamWaitEvent(ln.retile, vn.ready, 0));
-        }
-        vn.ready_waited = true; vn.waited1 = true;
-      }
-    }
+    if (k == 0) CHK(order_first_write());
     CHK(retile_tensor(g, g->dlay, i, b.dev, s.dev, ln.retile));
     HIPCHK(hipEventRecord(b.freed, ln.retile));
     b.used = true;
@@ -596,14 +635,26 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
 
 static void settle_copy_timers(moeinf_engine* g, bool wait) {
   size_t keep = 0;
+  // link-busy time = the UNION of the lanes' copy intervals (the demand lane and the speculative lane run side by side: a
+  // plain sum would count the shared link twice).  Intervals settle in issue order; `busy_mark` is the stop event of the
+  // interval that ends latest so far — an interval only adds what it extends beyond that mark.
   for (size_t i = 0; i < g->copy_timers.size(); ++i) {
     auto pr = g->copy_timers[i];
     if (wait) hipEventSynchronize(pr.second);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-      g->st.h2d_busy_ms += ms;
+      float add = ms, gap = 0.f, ext = 0.f;
+      bool new_mark = true;
+      if (g->busy_mark && hipEventElapsedTime(&gap, g->busy_mark, pr.first) == hipSuccess && gap < 0.f) {  // starts inside the accounted time
+        if (hipEventElapsedTime(&ext, g->busy_mark, pr.second) == hipSuccess && ext > 0.f) add = ext;
+        else { add = 0.f; new_mark = false; }
+      } else (void)hipGetLastError();
+      g->st.h2d_busy_ms += add;
       g->event_pool.push_back(pr.first);
-      g->event_pool.push_back(pr.second);
+      if (new_mark) {
+        if (g->busy_mark) g->event_pool.push_back(g->busy_mark);
+        g->busy_mark = pr.second;
+      } else g->event_pool.push_back(pr.second);
     } else {
       (void)hipGetLastError();
       g->copy_timers[keep++] = pr;
@@ -1018,6 +1069,8 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
       g->st.expert_misses += 1;
       // a queued speculative transfer of this expert is overtaken by the demand (StartExec, task_scheduler.cpp:158-168)
       g->st.prefetch_cancelled += g->pq.remove_node(idx);
+      // (one demand lane: a layer's misses dealt over TWO concurrent copy streams measured slower — DeepSeek-V2-Lite offload
+      // leg 27.9 -> 32.9 ms/token, 52.6 -> 44.2 GB/s, profiles/r06_offload_whole_blob_ab.txt: the streams share one link)
       rc = issue_copy(g, idx, g->demand, true);
       if (rc != MOEINF_OK) break;
       g->demand_inflight.push_back(idx);
@@ -1053,6 +1106,36 @@ static int wait_late(moeinf_engine* g, int layer, hipStream_t st, std::vector<in
   if (w0 && w1) { record_timing(w1, st); g->wait_timers.push_back({w0, w1}); }
   late.clear();
   return MOEINF_OK;
+}
+
+// The predicted experts of layer + 1 (moeinf_set_lookahead; g->la_list, best first) go onto the DEMAND lane behind this
+// layer's misses: one link, first in first out — the misses keep their full bandwidth, the predictions take the link when it
+// would idle (this layer's FFN, the next layer's attention and routing).  This layer's active experts stay pinned
+// meanwhile: their forward's fence is not recorded yet, so their slots must not be chosen as victims.
+static int lookahead_issue(moeinf_engine* g, int layer) {
+  const int E1 = g->E + 1;
+  const int na = g->h_mirror[0];
+  const int32_t* active = g->h_mirror + 1 + E1;
+  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = true; }
+  int rc = MOEINF_OK;
+  for (int idx : g->la_list) {
+    Node& nd = g->nodes[idx];
+    if (nd.slot >= 0) continue;
+    if (!nd.host) continue;  // on the disk tier only: left to the speculative queue's background read (moeinf_prefetch)
+    g->st.prefetch_cancelled += g->pq.remove_node(idx);
+    g->pol[idx].pinned = true;
+    rc = issue_copy(g, idx, g->demand, false);
+    g->pol[idx].pinned = false;
+    if (rc == MOEINF_ERR_OOM) { g->st.prefetch_dropped += 1; rc = MOEINF_OK; continue; }  // nothing evictable: dropped, as a queued prefetch would be
+    if (rc != MOEINF_OK) break;
+    nd.prefetched = true;
+    nd.prefetch_cnt += 1;
+    g->st.prefetch_issued += 1;
+    g->demand_inflight.push_back(idx);
+  }
+  for (int i = 0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
+  g->la_list.clear();
+  return rc;
 }
 
 // Launch both FFN stages for the active list in h_mirror.  If the layer needs more experts than
@@ -1093,6 +1176,7 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
     CHK(wait_late(g, layer, st, late));  // stage 2 reads the down projections: wait for the rest of each transfer
     HIPCHK(launch_ffn_stage(s2, b - a, max_rows, st));
+    if (a == 0 && b == na && !g->la_list.empty()) CHK(lookahead_issue(g, layer));
     a = b;
     if (a < na) {
       g->seq += 1;
@@ -1218,6 +1302,27 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
     // the host holds this layer's routing right now: predict and request the next layers' experts BEFORE serving this
     // layer's misses, so the speculative queue is ordered and the copies start as soon as the link is free
     if (g->pred_tracer && !g->ovr_out) CHK(predictor_observe(g, layer, g->h_mirror, /*prefetch=*/true));
+    g->la_list.clear();
+    if (g->la_armed_T > 0) {  // the lookahead route of this forward has landed with the routing mirror (same stream, same wait)
+      // the la_max most confident predictions (largest gate weight over the tokens), of which the non-resident ones are issued
+      std::vector<std::pair<float, int>> cand;
+      for (int i = 0; i < g->la_armed_T * g->K; ++i) {
+        const int e = g->h_la_idx[i];
+        if (e < 0 || e >= E || !owns(g, e)) continue;
+        const int idx = node_index(g, layer + 1, e);
+        bool dup = false;
+        for (auto& c : cand) if (c.second == idx) { c.first = std::max(c.first, g->h_la_w[i]); dup = true; }
+        if (!dup) cand.push_back({g->h_la_w[i], idx});
+      }
+      std::stable_sort(cand.begin(), cand.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+      static const bool la_dry = getenv("MOEINF_LA_DRY") && atoi(getenv("MOEINF_LA_DRY")) != 0;  // (measurement: the route runs, nothing is issued)
+      for (size_t i = 0; i < cand.size() && (int)i < g->la_max && !la_dry; ++i) {
+        const Node& n = g->nodes[cand[i].second];
+        if (n.slot >= 0 || (!n.host && !n.store)) continue;  // resident / in flight already, or never registered
+        g->la_list.push_back(cand[i].second);
+      }
+      g->la_armed_T = 0;
+    }
     CHK(run_experts(g, layer, x_in, st, prof ? pr->ev[2] : nullptr, prof ? pr->ev[3] : nullptr, prof ? pr->ev[4] : nullptr, ld_x, fuse, fused, exp_rows));
   }
   return MOEINF_OK;
@@ -1383,6 +1488,20 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
       if (ia.capacity <= 0 && (int64_t)T * K > wide_pairs) HIPCHK(launch_dispatch_index_wide(ia, g->d_chunk, st));
       else HIPCHK(launch_dispatch_index(ia, st));
     }
+  }
+  // next-layer gate lookahead: the decision path waits for this layer's routing anyway — layer l+1's gate over the same
+  // rows rides in front of that wait (two small launches; the top-k lands in pinned memory)
+  g->la_armed_T = 0;
+  if (!route_only && !mp.fast && !g->la_gates.empty() && T <= kLaTokens && layer + 1 < g->L && !g->ovr_out &&
+      g->resident_per_layer[layer + 1] < g->owned_experts) {
+    RouteArgs la = ra;
+    la.gate_w = g->la_gates[layer + 1];
+    la.logits = g->d_la_f; la.router_prob = g->d_la_f + (size_t)kLaTokens * g->E;
+    la.topk_idx = g->h_la_idx; la.topk_w = g->h_la_w;
+    la.pair_valid = g->d_la_i; la.pair_order = g->d_la_i + (size_t)kLaTokens * g->K;
+    HIPCHK(launch_gate_logits(la, st));
+    HIPCHK(launch_route_topk(la, st));
+    g->la_armed_T = T;
   }
   g->last_T = T; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
@@ -1710,6 +1829,24 @@ extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* exper
     g->st.prefetch_cancelled += g->pq.enqueue(idx, layer, priority_from_score(scores, i));
   }
   return pump_prefetch(g);
+}
+
+extern "C" int moeinf_set_lookahead(moeinf_engine* g, const void* const* gate_w_dev, int n_layers, int max_experts) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (!gate_w_dev || n_layers == 0) { g->la_gates.clear(); g->la_armed_T = 0; g->la_list.clear(); return MOEINF_OK; }
+  if (n_layers != g->L) return fail(MOEINF_ERR_INVALID, "moeinf_set_lookahead: %d gate pointers for %d layers", n_layers, g->L);
+  if (max_experts <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_set_lookahead: max_experts must be positive");
+  for (int l = 0; l < n_layers; ++l) if (!gate_w_dev[l]) return fail(MOEINF_ERR_INVALID, "moeinf_set_lookahead: gate of layer %d is NULL", l);
+  DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);
+  if (!g->d_la_f) {
+    HIPCHK(hipMalloc((void**)&g->d_la_f, (size_t)kLaTokens * (g->E + 1) * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&g->d_la_i, (size_t)2 * kLaTokens * g->K * sizeof(int32_t)));
+    HIPCHK(hipHostMalloc((void**)&g->h_la_idx, (size_t)kLaTokens * g->K * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&g->h_la_w, (size_t)kLaTokens * g->K * sizeof(float), hipHostMallocDefault));
+  }
+  g->la_gates.assign(gate_w_dev, gate_w_dev + n_layers);
+  g->la_max = max_experts;
+  return MOEINF_OK;
 }
 
 extern "C" int moeinf_protect(moeinf_engine* g, const int32_t* layers, const int32_t* experts, int n) {

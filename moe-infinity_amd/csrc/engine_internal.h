@@ -188,12 +188,14 @@ struct StageBuf {
   hipEvent_t filled = nullptr, freed = nullptr;
   bool used = false;
 };
+constexpr int kStageRing = 4;  // staging buffers per lane: the link never waits for a re-tile launch two copies back
 struct CopyLane {
   hipStream_t copy = nullptr, retile = nullptr;
-  StageBuf ring[2];
+  StageBuf ring[kStageRing];
   int next = 0;
 };
 
+constexpr int kLaTokens = 8;  // the lookahead route runs for decode-sized forwards only
 struct moeinf_engine {
   moeinf_config cfg;
   int64_t es = 2;  // element size
@@ -202,6 +204,20 @@ struct moeinf_engine {
   DevLayout dlay, dlay_sh;  // HBM slot (tiled)
   CopyLane demand, prefetch;  // on-demand misses (high priority) / speculative copies (low priority)
   int64_t stage_bytes = 0;
+  // Small experts travel as ONE hipMemcpyAsync of the whole contiguous host blob (as the reference copies it,
+  // model_topology.cpp:102-119) into a staging buffer sized for an expert, re-tiled by one launch; big ones (Mixtral: 336 MiB)
+  // tensor by tensor, so FFN stage 1 can start while the down projection is still on the link.
+  bool whole_blob = false;
+  // next-layer gate lookahead (moeinf_set_lookahead)
+  std::vector<const void*> la_gates;   // [L] borrowed device pointers; empty: off
+  int la_max = 0;
+  float* d_la_f = nullptr;             // logits [kLaTokens * E] + router_prob [kLaTokens]
+  int32_t* d_la_i = nullptr;           // pair_valid + pair_order [2 * kLaTokens * K]
+  int32_t* h_la_idx = nullptr;         // pinned, written by the route kernel itself: top-k ids [kLaTokens * K]
+  float* h_la_w = nullptr;             // ... and weights
+  int la_armed_T = 0;                  // > 0: the running forward launched a lookahead route over this many tokens
+  std::vector<int> la_list;            // node indices predicted for the next layer, best first
+  hipEvent_t busy_mark = nullptr;  // stop event of the latest-ending copy interval accounted so far (union of the lanes' busy time)
   int64_t slot_bytes = 0;
   int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
   bool has_shared = false;

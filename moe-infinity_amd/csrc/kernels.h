@@ -169,6 +169,16 @@ inline Ring2Form ring2_form(int elem_bytes, bool f16, int nmat, int K, int K_sh,
 hipError_t launch_ffn_stage(const FfnStage& s, int max_active, int max_rows_per_expert, hipStream_t st);
 // row-major [R,K] -> MFMA A-operand tiles (see kernels.hip); dst needs tiled_bytes(R,K) bytes
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st);
+// all tensors of one staged blob in one launch: tensor t = (src + src_off[t]) row-major [R, K] -> (dst + dst_off[t]) tiled;
+// K == 0: a vector of R 16-byte pieces, copied as is
+struct RetileBlob {
+  const void* src;
+  void* dst;
+  int n;
+  int64_t src_off[4], dst_off[4];
+  int R[4], K[4];
+};
+hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st);
 inline int64_t tiled_bytes(int64_t R, int64_t K, int dtype) { const int64_t ept = dtype == DT_F32 ? 16 : 32; return ((R + 15) / 16) * ((K + ept - 1) / ept) * 1024; }
 
 struct RouteArgs {

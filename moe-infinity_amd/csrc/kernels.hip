@@ -14,6 +14,8 @@
 // are reproduced (Tr() below) so results match its CPU path to accumulation-order noise.
 #include "kdev.h"
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include <string.h>
@@ -43,6 +45,49 @@ __global__ __launch_bounds__(256) void retile_kernel(const T* __restrict__ src, 
   u32x4 v = {0u, 0u, 0u, 0u};
   if (row < R && k < K) v = ld16(src + (size_t)row * K + k);  // K % EPV == 0
   *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = v;
+}
+// Every tensor of ONE staged expert blob in one launch (small experts travel host -> HBM as a whole blob, one
+// hipMemcpyAsync; engine.cpp issue_copy): blockIdx.z = tensor, a matrix is re-tiled as above, a bias vector (K == 0) is
+// copied as 16-byte pieces.
+template <typename T>
+__global__ __launch_bounds__(256) void retile_blob_kernel(RetileBlob b) {
+  constexpr int EPV = DT<T>::EPV;
+  constexpr int EPT = 4 * EPV;
+  const int t = blockIdx.z;
+  const char* src = reinterpret_cast<const char*>(b.src) + b.src_off[t];
+  char* dst = reinterpret_cast<char*>(b.dst) + b.dst_off[t];
+  const int R = b.R[t], K = b.K[t];
+  if (K == 0) {  // not a matrix: R = bytes / 16 (sizes are multiples of 16: checked by the launcher)
+    const int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (i < R) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+    return;
+  }
+  const int KB = (K + EPT - 1) / EPT;
+  const int lane = threadIdx.x & 63;
+  const int kb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rg = blockIdx.y;
+  if (kb >= KB || rg * 16 >= R) return;
+  const int row = rg * 16 + (lane & 15);
+  const int k = kb * EPT + (lane >> 4) * EPV;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < R && k < K) v = ld16(reinterpret_cast<const T*>(src) + (size_t)row * K + k);
+  *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = v;
+}
+hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st) {
+  const int ept = dtype == DT_F32 ? 16 : 32;
+  unsigned gx = 1, gy = 1;
+  for (int t = 0; t < b.n; ++t) {
+    if (b.K[t] > 0) { gx = std::max(gx, (unsigned)(((b.K[t] + ept - 1) / ept + 3) / 4)); gy = std::max(gy, (unsigned)((b.R[t] + 15) / 16)); }
+  }
+  for (int t = 0; t < b.n; ++t)
+    if (b.K[t] == 0) {  // a vector's pieces are spread over the (gx, gy) plane the matrices set
+      const int64_t blocks = ((int64_t)b.R[t] + 255) / 256;
+      while ((int64_t)gx * gy < blocks) gy += 1;
+    }
+  const dim3 grid(gx, gy, b.n);
+  if (dtype != DT_F32) hipLaunchKernelGGL(retile_blob_kernel<uint16_t>, grid, dim3(256), 0, st, b);
+  else hipLaunchKernelGGL(retile_blob_kernel<float>, grid, dim3(256), 0, st, b);
+  return hipGetLastError();
 }
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st) {
   const int ept = dtype == DT_F32 ? 16 : 32;

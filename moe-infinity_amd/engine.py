@@ -300,6 +300,24 @@ class MoEEngine:
         check(self.lib.moeinf_set_predictor(self._h, tracer._h if tracer is not None else None, int(seq_id), int(lookahead_layers),
                                             float(min_share), int(max_experts)))
 
+    def set_lookahead(self, gates: Optional[Sequence[torch.Tensor]], max_experts: int = 0):
+        """next-layer gate lookahead (moeinf_set_lookahead): ``gates`` = every layer's gate weight [E, H] on this engine's
+        device, in layer order (borrowed: keep them alive); None turns it off.  ``max_experts``: predictions issued per
+        forward (default: top_k x 2)."""
+        if gates is None:
+            self._lookahead_gates = None
+            check(self.lib.moeinf_set_lookahead(self._h, None, 0, 0))
+            return
+        gates = list(gates)
+        if len(gates) != self.cfg.num_layers:
+            raise ValueError(f"set_lookahead: {len(gates)} gates for {self.cfg.num_layers} layers")
+        for g in gates:
+            if g.device != self.device or not g.is_contiguous() or tuple(g.shape) != (self.cfg.num_experts, self.cfg.hidden):
+                raise ValueError("set_lookahead: every gate must be a contiguous [num_experts, hidden] tensor on the engine's device")
+        arr = (C.c_void_p * len(gates))(*[g.data_ptr() for g in gates])
+        self._lookahead_gates = gates  # borrowed by the engine
+        check(self.lib.moeinf_set_lookahead(self._h, arr, len(gates), int(max_experts) or 2 * self.cfg.top_k))
+
     def expert_counters(self) -> np.ndarray:
         """[L, E, 7] = visit, hit, miss, prefetch, incache_visit_count, resident, unused_count (get_hit_rate analogue)."""
         a = np.empty((self.cfg.num_layers, self.cfg.num_experts, 7), np.int64)

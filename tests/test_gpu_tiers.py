@@ -286,3 +286,63 @@ def test_dense_mask_with_more_than_k_experts_per_token_is_rejected_without_overr
     y, counts, hit = eng.dispatch_mask(0, x, ok)  # the engine is still healthy
     assert int(counts.sum()) == 2 * t and y.shape[0] == 2 * t
     eng.close()
+
+
+def test_next_layer_gate_lookahead_issues_the_next_layers_experts_and_changes_no_result():
+    """moeinf_set_lookahead: on a residual stream (x_{l+1} = rmsnorm(x_l + 0.3 n)) layer l+1's gate over layer l's rows
+    predicts layer l+1's routing; the predicted experts are copied behind layer l's misses, so layer l+1 finds them
+    resident (or in flight).  Outputs are bit-identical to the same engine without the lookahead, every layer checked
+    against the oracle; a wrong prediction only costs link time."""
+    h, f, e, k, t, L = 512, 1024, 16, 2, 1, 6  # 3 MiB experts: whole-blob copies
+    ws = [make_weights("mixtral", h, f, e, 2500 + l, torch.bfloat16) for l in range(L)]
+    gates = [w[0].to(DEV) for w in ws]
+
+    def stream(step):
+        g = torch.Generator().manual_seed(2600 + step)
+        x = acts(t, h, torch.float32, 2650 + step)
+        xs = [x]
+        for _ in range(L - 1):
+            x = x + 0.3 * torch.randn(t, h, generator=g)
+            x = x / x.pow(2).mean(-1, keepdim=True).sqrt()
+            xs.append(x)
+        return [v.to(torch.bfloat16) for v in xs]
+
+    def run(lookahead):
+        eng = _mixtral_engine(L, e, h, f, k, 24, t)  # 24 slots for 96 experts
+        for l in range(L):
+            register_all(eng, ws[l][1], layer=l)
+        if lookahead:
+            eng.set_lookahead(gates, max_experts=2 * k)
+        outs = []
+        for step in range(12):
+            xs = stream(step)
+            for l in range(L):
+                out = eng.forward(l, xs[l].to(DEV), gates[l])
+                outs.append(out.cpu())
+                if step == 11:
+                    assert_block_close(out, R.block_mixtral(xs[l][None], ws[l][0], ws[l][1], top_k=k), torch.bfloat16, f"layer {l}, lookahead={lookahead}")
+        eng.sync_copies()
+        st = eng.stats()
+        if lookahead:
+            eng.set_lookahead(None)
+            before = eng.stats()["prefetch_issued"]
+            for l in range(L):
+                eng.forward(l, stream(99)[l].to(DEV), gates[l])
+            assert eng.stats()["prefetch_issued"] == before, "switched off: nothing is issued any more"
+        eng.close()
+        return outs, st
+
+    plain, st0 = run(False)
+    ahead, st1 = run(True)
+    assert st0["prefetch_issued"] == 0
+    assert all(torch.equal(a, b) for a, b in zip(plain, ahead)), "the lookahead must not change any output"
+    assert st1["prefetch_issued"] > 0 and st1["prefetch_useful"] > 0, st1
+    # a prediction from a 0.96-cosine neighbour is mostly right: most speculative copies were dispatched before eviction
+    assert st1["prefetch_useful"] >= 0.5 * st1["prefetch_issued"], st1
+    assert st1["expert_misses"] < st0["expert_misses"], (st0["expert_misses"], st1["expert_misses"])
+    with pytest.raises(Exception):
+        e2 = _mixtral_engine(L, e, h, f, k, 24, t)
+        try:
+            e2.set_lookahead(gates[:2])
+        finally:
+            e2.close()
