@@ -263,8 +263,9 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             # verdicts follow on every rank, after EVERY probation forward — so one failing rank ends the probation of this
             # candidate for everybody at the next all-reduce instead of leaving the others in a collective it never enters.
             t_prob = time.time()
+            prev_timeout = None
             if cand == "peer-store":  # on probation a peer that never publishes costs seconds per poll, not MOEINF_EP_PEER_TIMEOUT_MS
-                eng.ep_peer_set_timeout_ms(3000)
+                prev_timeout = eng.ep_peer_set_timeout_ms(3000)
             passed, why = True, ""
             for it in range(2):  # the first pass takes the decision path, the second the sync-free one
                 for l in range(min(2, L)):
@@ -294,8 +295,8 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                         break
                 if not passed:
                     break
-            if cand == "peer-store":
-                eng.ep_peer_set_timeout_ms(int(os.environ.get("MOEINF_EP_PEER_TIMEOUT_MS", "10000")))
+            if prev_timeout:
+                eng.ep_peer_set_timeout_ms(prev_timeout)
             if passed:
                 ep_notes.append(f"{cand}: self-test passed and probation passed on every rank (bit-identical to the torch.distributed transport" + ("; shared expert: to the last bit of the model dtype" if cfg.shared_inter else "") + f") in {time.time() - t_prob:.1f}s")
                 break
@@ -415,6 +416,46 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
             ep.profile = False
         except Exception as ex:
             log(f"EP phase-timer leg failed on rank {rank}: {ex!r}")
+
+    # ---- N > 1: the same K steps over EVERY transport that works here, not only the one `auto` chose (north_star names the RCCL
+    # all-to-all; the default prefers the direct peer-store exchange): one window each, same barrier / max-over-ranks bracket.
+    # Every rank runs the same sequence of collectives: the constructors' verdicts are all-reduced inside ExpertParallelMoE.
+    by_transport = None
+    if ep is not None and world > 1:
+        by_transport = {ep.transport: round(ms_per_step, 4)}
+        chosen_ep, chosen_name = ep, ep.transport
+
+        def time_transport(ep_alt):
+            nonlocal ep
+            ep = ep_alt
+            try:
+                fence()
+                run_steps(0, warmup)
+                fence()
+                t0_ = time.perf_counter()
+                run_steps(warmup, steps)
+                fence()
+                el = time.perf_counter() - t0_
+                tt = torch.tensor([el], dtype=torch.float64, device=comm_dev(dist, dev))
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return round(float(tt.item()) * 1e3 / steps, 4)
+            finally:
+                ep = chosen_ep
+
+        try:
+            if chosen_name == "peer-store":  # RCCL from inside the engine (needs an RCCL process group: not when ranks share a GPU)
+                ep_r = ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport="rccl", uniform_tokens=True)
+                if ep_r.transport == "rccl":
+                    by_transport["rccl"] = time_transport(ep_r)
+                else:
+                    ep_notes.append(f"rccl (timing only): not available ({ep_r.native_note})")
+                eng.ep_select_transport("peer-store")
+            if chosen_name != "torch":
+                by_transport["torch"] = time_transport(ep_plain if ep_plain is not None else
+                                                       ExpertParallelMoE(HipEpOps(eng), H, K, B, dt, dev, num_experts=E, transport="torch"))
+        except Exception as ex:  # noqa: BLE001
+            log(f"per-transport timing failed on rank {rank}: {ex!r}")
+        log(f"ms per step by transport: {by_transport} (chosen: {chosen_name})")
 
     # ---- same K steps again with per-kernel HIP events on the launch stream (roofline leg)
     # Expert-parallel runs: every rank repeats the steps (the collectives need all of them); the events bracket the
@@ -871,7 +912,7 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
            "prefill_ms": prefill_ms, "prefill_passes": prefill_passes, "prefill_kernels": prefill_kernels, "prompt": prompt, "roof": roof, "kernels": kernels, "cpu": cpu, "parity": parity, "miss": miss,
            "warm": warm, "st": st, "ep_phases": ep_phases, "selfroute": selfroute,
            "ep_transport": None if ep is None else {
-               "chosen": ep.transport,
+               "chosen": ep.transport, "world": world, "ms_per_step_by_transport": by_transport,
                "what": {"peer-store": "rows stored straight into the owners' / home ranks' windows by the router and FFN kernels, flag words instead of a collective; one host call per layer (moeinf_ep_moe_forward)",
                         "rccl": "RCCL send/recv group called from inside the engine; one host call per layer (moeinf_ep_moe_forward)",
                         "torch": "torch.distributed all_to_all_single, five host calls per layer"}[ep.transport],
@@ -934,6 +975,8 @@ def main():
     ap.add_argument("--offload-attn-us", type=float, default=270.1, help="that leg's attention stand-in per layer (profiles/r04_attention_block_time_stock_pytorch.jsonl: DeepSeek-V2-Lite batch 1, context 2048)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
     ap.add_argument("--no-fp16-legs", action="store_true", help="skip the fp16-expert legs of other_configs")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the path through prefetch_op.expert_dispatcher as the reference's dispatch_local drives it, timed beside the fused path)")
+    ap.add_argument("--dropin-layers", type=int, default=8, help="full-size MoE layers of the drop-in leg (its offload directory holds every expert of them: 8 Mixtral layers = 21 GiB)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic pass (two rocprofv3 --pmc child runs, ~1 min): roofline.traffic then comes from profiles/ (static)")
     args = ap.parse_args()
 
@@ -1037,6 +1080,26 @@ def main():
                     log(f"fp16 leg {wl} failed: {ex!r}")
                     others.append({"workload": wl + " fp16", "error": repr(ex)})
 
+    # ---- the DROP-IN path, timed (VERDICT r5 "missing" 2): prefetch_op.expert_dispatcher driven exactly as the reference's
+    # dispatch_local drives its pybind object (set_inputs, set_expected_queue, enqueue_expert x U, wait_expert, the blocks' Python
+    # router and combine around it), beside the fused path on the same engine and weights: tools/dropin_time.py
+    dropin = None
+    if rank == 0 and world == 1 and not use_ep and default_main and not args.no_dropin:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("_dropin_time", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "dropin_time.py"))
+        dmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(dmod)
+        dropin = {}
+        for wl in ("mixtral-8x7b", "deepseek-v2-lite"):
+            try:
+                t0 = time.time()
+                dropin[wl] = dmod.measure(wl, layers=args.dropin_layers, steps=10, warmup=2, log=log)
+                log(f"drop-in leg {wl}: {dropin[wl]['ms_per_token']} ms/token, {dropin[wl]['over_fused']} x the fused path ({time.time() - t0:.0f}s)")
+            except Exception as ex:  # noqa: BLE001
+                log(f"drop-in leg {wl} failed: {ex!r}")
+                dropin[wl] = {"error": repr(ex)}
+
     parity_ok = True
     if rank == 0:
         cfg, st, warm = r["cfg"], r["st"], r["warm"]
@@ -1075,6 +1138,7 @@ def main():
             "cache": {k: st[k] for k in ("expert_hits", "expert_misses", "evictions", "h2d_bytes", "slots_total", "slots_used", "slot_bytes", "host_arena_bytes")},
             "parity": r["parity"],
             "miss_heavy": r["miss"],
+            "dropin": dropin,
             "ep_phases_us_per_layer": r["ep_phases"],
             "ep_transport": r["ep_transport"],
             "other_configs": others or None,

@@ -85,11 +85,17 @@ def _miss(m):
     subs = m.get("sub_legs")
     if isinstance(subs, list) and subs:
         out["sub_legs"] = len(subs)
-        best = [s for s in subs if isinstance(s, dict) and s.get("prefetch_issued")]
-        if best:  # the speculating sub-leg, beside the on-demand headline of this object
-            b = min(best, key=lambda s: s.get("ms_per_token", 1e30))
-            out["speculating"] = _pick(b, ("routing", "policy", "ms_per_token", "hit_rate", "overlap", "prefetch_issued",
-                                           "prefetch_useful", "h2d_GBps", "speculation_kind"))
+        # speculation on the residual stream (where the next layer is predictable): on demand | EAM history | next-layer gate
+        res = [s for s in subs if isinstance(s, dict) and str(s.get("activations", "")).startswith("residual")]
+        if res:
+            out["residual_stream"] = [{"routing": s.get("routing"), "kind": s.get("speculation_kind"), "ms_per_token": s.get("ms_per_token"),
+                                       "hit_rate": s.get("hit_rate"), "overlap": s.get("overlap"), "precision": s.get("prefetch_precision")} for s in res]
+        else:
+            best = [s for s in subs if isinstance(s, dict) and s.get("prefetch_issued")]
+            if best:  # the speculating sub-leg, beside the on-demand headline of this object
+                b = min(best, key=lambda s: s.get("ms_per_token", 1e30))
+                out["speculating"] = _pick(b, ("routing", "policy", "ms_per_token", "hit_rate", "overlap", "prefetch_issued",
+                                               "prefetch_useful", "h2d_GBps", "speculation_kind"))
     return out
 
 
@@ -147,8 +153,11 @@ def compact(full):
         line["prefetch_stream"] = _pick(ps, ("GiB", "GBps", "frac_of_pcie5_x16_63GBps", "frac_of_hbm_peak"))
     if isinstance(full.get("miss_heavy"), dict):
         line["miss_heavy"] = _miss(full["miss_heavy"])
-    if isinstance(full.get("dropin"), dict):
-        line["dropin"] = _pick(full["dropin"], ("ms_per_token", "host_us_per_call", "over_fused", "calls_per_token", "parity_ok"))
+    if isinstance(full.get("dropin"), dict):  # {workload: tools/dropin_time.measure()}
+        line["dropin"] = {_workload_short(k): (_pick(v, ("ms_per_token", "fused_ms_per_token", "over_fused", "host_us_per_call", "calls_per_token",
+                                                          "boundary_us_per_layer", "reference_python_us_per_layer", "parity_ok"))
+                                               if "error" not in v else {"error": _short(v["error"], 100)})
+                          for k, v in full["dropin"].items() if isinstance(v, dict)}
     if isinstance(full.get("prefill_4096"), dict):
         line["prefill_4096"] = _pick(full["prefill_4096"], ("tokens", "ms_all_layers", "gated_PFLOPs", "down_PFLOPs", "frac_of_mfma_peak"))
     ep = full.get("ep_transport")

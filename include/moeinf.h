@@ -140,14 +140,6 @@ int moeinf_abi_version(void);
 /* the row estimate moeinf_moe_forward passes to the FFN launchers when every expert of the layer is resident (sync-free path) */
 int moeinf_rows_estimate(int tokens, int top_k, int num_experts);
 int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5);
-/* The item table of the one-launch batch-1 decode layer (csrc/layer_fused.hip: a persistent grid of num_cus * wgs_per_cu
- * workgroups, each walking its own list of work items; replaces one layer's router + dispatch_local + expert GEMMs + combine,
- * moe_infinity/models/deepseek.py:55-136): pure host logic, exported so that tests can check it without a GPU.
- * out[workgroup * (*list_len) + j] = role << 24 | index, 0 = end of the list; roles 1 gate (index: expert), 2 shared stage 1
- * (16-row group), 3 meta, 4 routed stage 1 (slot * ceil(F/16) + row group), 5 shared stage 2 (16-column tile), 6 routed stage 2
- * (slot * ceil(H/16) + column tile).  cap: int32 entries `out` holds (MOEINF_ERR_INVALID if too small). */
-int moeinf_layer1_table(int num_experts, int top_k, int hidden, int inter, int shared_inter, int elem_bytes, int gate_elem_bytes,
-                        int num_cus, int wgs_per_cu, int32_t* out, int64_t cap, int32_t* list_len);
 
 /* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------
  * (core/prefetch/archer_prefetch_handle.cpp:18-64,73-81) */
@@ -205,6 +197,12 @@ int moeinf_moe_forward(moeinf_engine* eng, int layer, const void* x_dev, int tok
  * already resident when dispatched (wait_expert's 4th tuple field), 0 if fetched on demand, -1 if idle. */
 int moeinf_dispatch_mask(moeinf_engine* eng, int layer, const void* x_dev, int tokens, const void* router_mask_dev,
                          int mask_elem_bytes, void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream);
+/* ... the same with only the mask columns of `expert_ids` taken (the others count as all-false): what
+ * expert_dispatcher.wait_expert() needs when the experts enqueued on THIS device are a subset of the mask's columns
+ * (core/parallel/expert_dispatcher.cpp:121-158 queues experts one by one), without building a second mask on the host side.
+ * expert_ids == NULL: every column (= moeinf_dispatch_mask). */
+int moeinf_dispatch_mask_subset(moeinf_engine* eng, int layer, const void* x_dev, int tokens, const void* router_mask_dev, int mask_elem_bytes,
+                                void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream, const int32_t* expert_ids, int n_ids);
 
 /* The combine loop of the reference's blocks on its own (mixtral.py:96-101 `final_hidden_states[token_indices] +=
  * output * routing_weights_mask[...]`, deepseek.py:123-131, switch_transformers.py:99-109 incl. the `router_probs *`
@@ -522,6 +520,8 @@ int moeinf_ep_peer_release(moeinf_engine* eng);
  * by moeinf_ep_peer_export; a host layer shortens it while a transport is on probation (bench.py: 3 000) so that a peer that
  * never publishes costs seconds, and restores it afterwards.  Takes effect with the next exchange; ms > 0. */
 int moeinf_ep_peer_set_timeout_ms(moeinf_engine* eng, int ms);
+/* ... and what it is now (a host layer that shortens it for a probation restores THIS, not the environment's default). */
+int moeinf_ep_peer_get_timeout_ms(moeinf_engine* eng, int* ms);
 /* out[0] = transport moeinf_ep_moe_forward will take (MOEINF_EP_TRANSPORT_*); out[1] = 1 if another rank shares this GPU
  * (then a one-wave wait kernel runs in front of the consumers instead of polls inside them); out[2] = 1: polls inside the
  * consumer kernels; out[3] = exchanges so far */

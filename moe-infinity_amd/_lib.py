@@ -80,7 +80,6 @@ PROTOTYPES = {
     "moeinf_abi_version": (C.c_int, []),
     "moeinf_ffn_ring2_form": (C.c_int, [C.c_int] * 8 + [_I32P]),
     "moeinf_set_cache_policy": (C.c_int, [_P, C.c_int]),
-    "moeinf_layer1_table": (C.c_int, [C.c_int] * 9 + [_I32P, C.c_int64, _I32P]),
     "moeinf_rows_estimate": (C.c_int, [C.c_int] * 3),
     "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "moeinf_destroy": (C.c_int, [_P]),
@@ -90,6 +89,7 @@ PROTOTYPES = {
     "moeinf_register_shared": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "moeinf_moe_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_uint32]),
     "moeinf_dispatch_mask": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _I32P, _I32P, _P]),
+    "moeinf_dispatch_mask_subset": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _I32P, _I32P, _P, _I32P, C.c_int]),
     "moeinf_copy_routing_dev": (C.c_int, [_P, _P, _P, _P, _P]),
     "moeinf_get_routing": (C.c_int, [_P, _I32P, _F32P, _I32P, _I32P, _I32P, _I32P]),
     "moeinf_get_expert_outputs": (C.c_int, [_P, _P, C.c_int64]),
@@ -166,6 +166,7 @@ PROTOTYPES = {
     "moeinf_ep_peer_selftest": (C.c_int, [_P, _P, _I32P]),
     "moeinf_ep_peer_release": (C.c_int, [_P]),
     "moeinf_ep_peer_set_timeout_ms": (C.c_int, [_P, C.c_int]),
+    "moeinf_ep_peer_get_timeout_ms": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "moeinf_ep_transport": (C.c_int, [_P, _I32P]),
     "moeinf_ep_select_transport": (C.c_int, [_P, C.c_int]),
     "moeinf_ep_set_uniform_tokens": (C.c_int, [_P, C.c_int]),

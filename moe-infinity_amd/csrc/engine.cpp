@@ -64,16 +64,6 @@ extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
 // at most T.  Picks the FORM of the FFN kernels only; an expert with more rows takes more passes.
 static inline int rows_estimate(int T, int K, int E) { return (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1); }
 extern "C" int moeinf_rows_estimate(int tokens, int top_k, int num_experts) { return rows_estimate(tokens, top_k, num_experts); }
-extern "C" int moeinf_layer1_table(int num_experts, int top_k, int hidden, int inter, int shared_inter, int elem_bytes, int gate_elem_bytes,
-                                   int num_cus, int wgs_per_cu, int32_t* out, int64_t cap, int32_t* list_len) {
-  if (!out || !list_len || num_experts <= 0 || top_k <= 0 || hidden <= 0 || inter <= 0 || shared_inter < 0 || num_cus <= 0 || wgs_per_cu <= 0)
-    return fail(MOEINF_ERR_INVALID, "moeinf_layer1_table: bad arguments");
-  std::vector<int32_t> tab;
-  *list_len = layer1_table(num_experts, top_k, hidden, inter, shared_inter, elem_bytes, gate_elem_bytes, num_cus, wgs_per_cu, tab);
-  if ((int64_t)tab.size() > cap) return fail(MOEINF_ERR_INVALID, "moeinf_layer1_table: out holds %lld entries, the table has %zu", (long long)cap, tab.size());
-  memcpy(out, tab.data(), tab.size() * sizeof(int32_t));
-  return MOEINF_OK;
-}
 
 extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5) {
   if (!out5 || (nmat != 1 && nmat != 2) || K <= 0 || R <= 0 || active <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_ffn_ring2_form: bad arguments");
@@ -143,6 +133,7 @@ static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
 }
 
 static int sync_last(moeinf_engine* g);
+static int check_device_flag(moeinf_engine* g);
 // wait for the stream of the last forward and report the kernels' error flag (no resident blob for an active expert; a
 // peer-store exchange that gave up waiting for another rank)
 extern "C" int moeinf_sync(moeinf_engine* g) { return sync_last(g); }
@@ -156,8 +147,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
     if (hipMemcpy(tr.data(), g->d_layer_trace, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
       if (FILE* f = fopen(getenv("MOEINF_LAYER1_TRACE") ? getenv("MOEINF_LAYER1_TRACE") : "/dev/null", "w")) {
         std::vector<int32_t> tb((size_t)g->layer1_trace_blocks, 0);
-        if (g->d_layer_tab) (void)hipMemcpy(tb.data(), g->d_layer_tab, tb.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
-        else {  // no table: role = workgroup id (gate | shared stage 1 | meta | stage 1 | shared stage 2 (front) or stage 2 (Switch form))
+        {  // role = workgroup id (gate | shared stage 1 | meta | stage 1 | shared stage 2 (front) or stage 2 (Switch form))
           const int n_rg = (g->F + 15) / 16, n_sh1 = g->has_shared ? (g->Fs + 15) / 16 : 0;
           const bool sw = g->cfg.router_kind == MOEINF_ROUTER_SWITCH;
           for (int b = 0; b < g->layer1_trace_blocks; ++b) {
@@ -174,7 +164,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
           }
         }
         for (int b = 0; b < g->layer1_trace_blocks; ++b)  // "workgroup item role index t0 t1 t2 t3"
-          if (tb[b]) fprintf(f, "%d %d %d %d %llu %llu %llu %llu\n", b / g->layer1_maxi, b % g->layer1_maxi, tb[b] >> 24, tb[b] & 0xffffff, tr[b * 4], tr[b * 4 + 1], tr[b * 4 + 2], tr[b * 4 + 3]);
+          if (tb[b]) fprintf(f, "%d %d %d %d %llu %llu %llu %llu\n", b, 0, tb[b] >> 24, tb[b] & 0xffffff, tr[b * 4], tr[b * 4 + 1], tr[b * 4 + 2], tr[b * 4 + 3]);
         fclose(f);
       }
     hipFree(g->d_layer_trace);
@@ -196,10 +186,11 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (g->d_la_i) hipFree(g->d_la_i);
   if (g->h_la_idx) hipHostFree(g->h_la_idx);
   if (g->h_la_w) hipHostFree(g->h_la_w);
+  if (g->h_keep) hipHostFree(g->h_keep);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
-                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_layer_ctr, g->d_layer_tab, g->d_layer_part, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
+                  g->d_arrive, g->d_ep_rec, g->d_miss, g->d_dec_w, g->d_dec_cw, g->d_layer_ctr, g->d_layer_part, g->d_h_sh, g->d_y_sh, g->d_ep_key, g->d_ep_counts, g->d_ep_offsets, g->d_ep_active,
                   g->d_ep_nactive, g->d_ep_pair_slot, g->d_ep_slot_token, g->d_ep_slot_pair, g->d_ep_pair_pos};
   for (void* b : bufs) if (b) hipFree(b);
   if (g->mirror_slab) hipHostFree(g->mirror_slab);
@@ -331,6 +322,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     for (int i = 0; i < kFenceRing; ++i) g->mirror_pool.push_back(g->mirror_slab + per * i);
   }
   TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
+  *g->h_miss = 0;
   prealloc_slots(g);
   if (g->slots.empty() && g->slab_exhausted) { fail(MOEINF_ERR_OOM, "no device memory for a single expert slot of %lld bytes", (long long)g->slot_bytes); return bail(MOEINF_ERR_OOM); }
   *out = g;
@@ -1160,7 +1152,13 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     int64_t used = 0;
     while (b < na && (active[b] >= E || used < cap)) { if (active[b] < E) ++used; ++b; }
     std::vector<int> late;
+    const int64_t misses_before = g->st.expert_misses;
     CHK(ensure_resident(g, layer, st, late, a, b));
+    // lookahead copies are issued while the host has nothing better to do: with misses of THIS layer on the link the FFN launches
+    // below wait for them anyway (the host calls hide behind the copies); without, the FFN goes first
+    const bool la_now = a == 0 && b == na && !g->la_list.empty();
+    const bool la_early = la_now && g->st.expert_misses > misses_before;
+    if (la_early) CHK(lookahead_issue(g, layer));
     CHK(flush_pokes(g, st));
     s1.active = g->d_active + a; s2.active = g->d_active + a;
     s1.n_active_host = b - a; s2.n_active_host = b - a;
@@ -1176,7 +1174,7 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     if (ev_mid && b == na) HIPCHK(hipEventRecord(ev_mid, st));
     CHK(wait_late(g, layer, st, late));  // stage 2 reads the down projections: wait for the rest of each transfer
     HIPCHK(launch_ffn_stage(s2, b - a, max_rows, st));
-    if (a == 0 && b == na && !g->la_list.empty()) CHK(lookahead_issue(g, layer));
+    if (la_now && !la_early) CHK(lookahead_issue(g, layer));
     a = b;
     if (a < na) {
       g->seq += 1;
@@ -1201,6 +1199,9 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
   const int E = g->E, E1 = E + 1;
   if (fused) *fused = false;
   if (mp.fast) {
+    // a workgroup of an earlier fused launch gave up a wait (flag 4): its kernel also wrote the pinned word, so the forward path
+    // sees it without a device round trip — the error surfaces HERE, not only at the next moeinf_sync (as ep_err_host does for the exchange)
+    if (g->h_miss && *(volatile int32_t*)g->h_miss == 4) { *g->h_miss = 0; CHK(check_device_flag(g)); }
     moeinf_engine::PendingMirror pm;
     pm.buf = mp.target; pm.seq = g->seq + 1; pm.layer = layer; pm.T = T; pm.prof = prof; pm.local = !g->ovr_out;
     g->pend.push_back(pm);
@@ -1218,19 +1219,20 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
     if (sr && sr->layer1_switch) {
       LayerSync sy;
       memset(&sy, 0, sizeof sy);
-      sy.ctr = g->d_layer_ctr; sy.launch = g->layer1_launches + 1; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
+      sy.ctr = g->d_layer_ctr; sy.launch = g->layer1_launches + 1; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss; sy.err_host = g->h_miss;
       static const int l1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
       sy.sleep = l1_sleep; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
-      static int ncu = 0;
-      if (!ncu) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
+      if (!g->num_cus) (void)hipDeviceGetAttribute(&g->num_cus, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);  // per engine: engines of one process may sit on different devices
+      if (g->layer1_switch_wgs_per_cu < 0) g->layer1_switch_wgs_per_cu = layer1_switch_wgs_per_cu(sr->ra->x_dtype, sr->ra->gate_dtype);  // asked once: registers + LDS of the instantiation
+      const int ncu = g->num_cus;
       if (getenv("MOEINF_LAYER1_TRACE")) {
         const int nb = g->E + 1 + (g->F + 15) / 16 + 4 * ((g->H + 15) / 16);
-        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; g->layer1_maxi = 1; }
+        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
         sy.trace = g->d_layer_trace;
       }
       if (!g->d_layer_part) { if (hipMalloc((void**)&g->d_layer_part, (size_t)4 * g->H * sizeof(float)) != hipSuccess) { g->d_layer_part = nullptr; (void)hipGetLastError(); } }
       sy.part = g->d_layer_part;
-      if (fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, st)) {
+      if (fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, g->layer1_switch_wgs_per_cu, st)) {
         g->layer1_launches += 1;
         if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
         return MOEINF_OK;
@@ -1239,48 +1241,19 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       g->last_layer1 = false;  // declined (fewer CUs than workgroups, ...): the three launches, starting with the gate the caller left out
       HIPCHK(launch_gate_logits(*sr->ra, st));
     }
-    if (sr && sr->layer1) {
-      if (!fuse || !sr->sh1 || !sr->sh2) return fail(MOEINF_ERR_STATE, "internal: the one-launch layer needs the fused combine and the hidden shared expert's stages");
-      LayerSync sy;
-      sy.ctr = g->d_layer_ctr; sy.launch = ++g->layer1_launches; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
-      static const int l1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
-      sy.sleep = l1_sleep; sy.trace = nullptr; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
-      if (!g->d_layer_tab) {  // first one-launch layer of this engine: size the persistent grid to the chip, build the item table
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
-        int wpc = layer1_wgs_per_cu(sr->ra->gate_dtype);
-        if (const char* e = getenv("MOEINF_LAYER1_WPC")) wpc = std::min(wpc, std::max(1, atoi(e)));
-        if (ncu <= 0 || wpc <= 0) return fail(MOEINF_ERR_HIP, "occupancy query of the one-launch layer failed");
-        std::vector<int32_t> tab;
-        g->layer1_maxi = layer1_table(g->E, g->K, g->H, g->F, g->Fs, g->es, sr->ra->gate_dtype == DT_F32 ? 4 : 2, ncu, wpc, tab);
-        g->layer1_nwg = ncu * wpc;
-        if (hipMalloc((void**)&g->d_layer_tab, tab.size() * sizeof(int32_t)) != hipSuccess) { g->d_layer_tab = nullptr; (void)hipGetLastError(); return fail(MOEINF_ERR_OOM, "item table of the one-launch layer"); }
-        HIPCHK(hipMemcpy(g->d_layer_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      }
-      sy.tab = g->d_layer_tab; sy.maxi = g->layer1_maxi; sy.part = nullptr;
-      if (getenv("MOEINF_LAYER1_TRACE")) {
-        const int nb = g->layer1_nwg * g->layer1_maxi;
-        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
-        sy.trace = g->d_layer_trace;
-      }
-      FfnStage sh2c = *sr->sh2;
-      sh2c.fuse_combine = 1;  // (its y_shared rows are combined by another workgroup of the same launch)
-      HIPCHK(launch_moe_layer1(*sr->ra, *sr->ia, *sr->sh1, sh2c, s1, s2, sy, g->layer1_nwg, st));
-      if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
-      return MOEINF_OK;
-    }
     if (sr && sr->front1) {
       LayerSync sy;
       memset(&sy, 0, sizeof sy);
-      sy.ctr = g->d_layer_ctr; sy.launch = ++g->layer1_launches; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss;
+      sy.ctr = g->d_layer_ctr; sy.launch = g->layer1_launches + 1; sy.timeout_ticks = g->layer1_timeout_ticks; sy.err = g->d_miss; sy.err_host = g->h_miss;
       static const int f1_sleep = getenv("MOEINF_LAYER1_SLEEP") ? std::max(1, atoi(getenv("MOEINF_LAYER1_SLEEP"))) : 2;
       sy.sleep = f1_sleep; sy.scalar_poll = g->layer1_scalar_poll ? 1 : 0;
       if (getenv("MOEINF_LAYER1_TRACE")) {
         const int nb = g->E + (sr->sh1 ? (g->Fs + 15) / 16 : 0) + 1 + g->K * ((g->F + 15) / 16) + (sr->sh2 ? (g->H + 15) / 16 : 0);
-        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; g->layer1_maxi = 1; }
+        if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
         sy.trace = g->d_layer_trace;
       }
       HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
+      g->layer1_launches += 1;  // only a launch that went out moves the grow-only counters' target (a failed one must not leave them out of step)
     } else if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
     else if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
@@ -1444,24 +1417,20 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   const bool selfroute = selfroute_env && !route_only && mp.fast && K <= 8 && E <= 64 && !g->ovr_out &&
                          ((T == 1 && (sr_gated || sr_switch)) || sr_multi);
   g->last_selfroute = selfroute;
-  // ... and with a hidden shared expert (DeepSeek) the whole layer CAN be one launch: gate, shared expert, self-routing stage 1,
-  // stage 2 and the combine as work items of one persistent grid (layer_fused.hip).  OPT-IN (MOEINF_LAYER1=1): measured in round 5
-  // it does not beat the three launches (DeepSeek-V2-Lite 1.09 vs 0.958 ms/token; DESIGN.md section 4.5 has the timelines and why).
-  static const bool layer1_env = getenv("MOEINF_LAYER1") ? atoi(getenv("MOEINF_LAYER1")) != 0 : false;
-  const bool layer1 = layer1_env && selfroute && T == 1 && sr_gated && hide_shared && g->dt == DT_BF16 && !(flags & MOEINF_FWD_NO_COMBINE) &&
-                      fuse_mode() != 0 && (getenv("MOEINF_FUSE_COMBINE") ? atoi(getenv("MOEINF_FUSE_COMBINE")) != 0 : true);
+  // (the whole DeepSeek layer as ONE persistent launch was built in round 5, measured slower — 1.09 vs 0.958 ms/token — and
+  // removed in round 6: DESIGN.md section 4.5.1 keeps the analysis)
   // Switch (top-1, no shared expert): the one-launch form is the DEFAULT — three launches of 3-10 us for 18.9 MB are pure fixed
   // cost, and with hardly any traffic in flight a flag costs ~1 us (MOEINF_LAYER1_SWITCH=0: the three launches)
   static const bool layer1s_env = getenv("MOEINF_LAYER1_SWITCH") ? atoi(getenv("MOEINF_LAYER1_SWITCH")) != 0 : true;
   const bool layer1_switch = layer1s_env && selfroute && T == 1 && sr_switch && !sr_gated && !(flags & MOEINF_FWD_NO_COMBINE) && g->dt != DT_F16;
-  g->last_layer1 = layer1 || layer1_switch;
+  g->last_layer1 = layer1_switch;
   // the gated families: the gate (and the hidden shared expert) can ride in FRONT of the self-routing stage 1, in the same
   // launch (round 5, launch_moe_front1).  Measured A/B/A/B (profiles/r05_front1_gate_and_stage1_in_one_launch.txt): DeepSeek-V2-Lite
   // 0.949-0.967 -> 0.937 ms/token (two launches per layer instead of three) = the default with a hidden shared expert; Mixtral
   // 3.708-3.726 -> 3.723-3.728 (nothing: the hop costs what the gate launch cost) = off unless MOEINF_FRONT1=1; =0: never
   static const int front1_env = getenv("MOEINF_FRONT1") ? atoi(getenv("MOEINF_FRONT1")) : -1;
   g->last_front1 = false;
-  const bool front1 = (front1_env < 0 ? hide_shared : front1_env != 0) && selfroute && !layer1 && T == 1 && sr_gated && g->dt != DT_F32 &&
+  const bool front1 = (front1_env < 0 ? hide_shared : front1_env != 0) && selfroute && T == 1 && sr_gated && g->dt != DT_F32 &&
                       (hide_shared || !g->has_shared) && (ra.gate_dtype == ra.x_dtype || ra.gate_dtype == DT_F32);
   FfnStage sh1, sh2;
   if (hide_shared) {
@@ -1469,7 +1438,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
     ia.shared = 0;  // the index lists routed experts only
   }
   g->last_front1 = front1;
-  if (layer1 || layer1_switch || front1) {
+  if (layer1_switch || front1) {
     // nothing here: dispatch_experts launches the layer / the launch that carries the gate
   } else if (selfroute) {
     if (hide_shared) HIPCHK(launch_gate_shared1(ra, sh1, st));
@@ -1526,7 +1495,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
                         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK ||
                          (selfroute && sr_switch));  // (Switch: only the batch-1 stage 2 knows its combine)
   bool fused = false;
-  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, layer1, front1, layer1_switch};
+  SelfRoute sr{&ra, &ia, hide_shared ? &sh2 : nullptr, hide_shared ? &sh1 : nullptr, front1, layer1_switch};
   CHK(dispatch_experts(g, layer, x_dev, 0, T, std::min(E, T * K) + ((g->has_shared && !hide_shared) ? 1 : 0),
                        rows_estimate(T, K, E), st, prof, prof ? &pr : nullptr,
                        mp, can_fuse ? &ca : nullptr, &fused, selfroute ? &sr : nullptr));
@@ -1542,7 +1511,13 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
 
 extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_dev, int tokens, const void* mask_dev, int mask_elem_bytes,
                                     void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream) {
+  return moeinf_dispatch_mask_subset(g, layer, x_dev, tokens, mask_dev, mask_elem_bytes, y_dev, counts_host, hit_host, stream, nullptr, 0);
+}
+
+extern "C" int moeinf_dispatch_mask_subset(moeinf_engine* g, int layer, const void* x_dev, int tokens, const void* mask_dev, int mask_elem_bytes,
+                                           void* y_dev, int32_t* counts_host, int32_t* hit_host, void* stream, const int32_t* expert_ids, int n_ids) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (n_ids < 0 || (n_ids > 0 && !expert_ids)) return fail(MOEINF_ERR_INVALID, "expert_ids is NULL");
   if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
   if (!x_dev || !mask_dev || !y_dev) return fail(MOEINF_ERR_INVALID, "x_dev/router_mask_dev/y_dev is NULL");
   if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail(MOEINF_ERR_INVALID, "mask_elem_bytes must be 1, 4 or 8");
@@ -1559,7 +1534,17 @@ extern "C" int moeinf_dispatch_mask(moeinf_engine* g, int layer, const void* x_d
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = g->h_mirror;
   ia.slot_cap = g->cfg.max_tokens * g->K;  // rows the workspace holds: the kernel never writes past them
   drop_stale_prefetches(g, layer);
-  HIPCHK(launch_mask_index(mask_dev, mask_elem_bytes, tokens, E, ia, st));
+  const uint8_t* keep = nullptr;
+  if (expert_ids) {  // only the enqueued experts run (expert_dispatcher.wait_expert: the queue of THIS device): a pinned byte per expert
+    if (!g->h_keep) HIPCHK(hipHostMalloc((void**)&g->h_keep, (size_t)E, hipHostMallocDefault));
+    memset(g->h_keep, 0, (size_t)E);
+    for (int i = 0; i < n_ids; ++i) {
+      if (expert_ids[i] < 0 || expert_ids[i] >= E) return fail(MOEINF_ERR_INVALID, "expert id %d out of range", expert_ids[i]);
+      g->h_keep[expert_ids[i]] = 1;
+    }
+    keep = g->h_keep;  // read by the kernel below, which this call waits for before it returns
+  }
+  HIPCHK(launch_mask_index(mask_dev, mask_elem_bytes, tokens, E, ia, st, keep));
   HIPCHK(hipEventRecord(g->route_ev, st));
   HIPCHK(hipEventSynchronize(g->route_ev));
   int64_t rows = 0;
@@ -1662,6 +1647,7 @@ static int check_device_flag(moeinf_engine* g) {
   if (f == 0) return MOEINF_OK;
   HIPCHK(hipMemset(g->d_miss, 0, sizeof f));
   if (g->ep_err_host) *g->ep_err_host = 0;
+  if (g->h_miss) *g->h_miss = 0;
   if (f == 4) {  // the counters of the one-launch layer may be out of step now: start them again
     HIPCHK(hipMemset(g->d_layer_ctr, 0, LAYER1_CTRS * LAYER1_CTR_STRIDE * sizeof(uint32_t)));
     HIPCHK(hipMemset(g->d_arrive, 0, (size_t)((g->H + 15) / 16) * sizeof(int32_t)));

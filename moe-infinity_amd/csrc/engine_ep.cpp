@@ -467,6 +467,12 @@ extern "C" int moeinf_ep_peer_set_timeout_ms(moeinf_engine* g, int ms) {
   return MOEINF_OK;
 }
 
+extern "C" int moeinf_ep_peer_get_timeout_ms(moeinf_engine* g, int* ms) {
+  if (!g || !ms) return fail(MOEINF_ERR_INVALID, "engine or ms is NULL");
+  *ms = (int)(g->ep_peer_timeout_ticks / 100000);
+  return MOEINF_OK;
+}
+
 extern "C" int moeinf_ep_peer_release(moeinf_engine* g) {
   if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
   DeviceScope on_dev_(g->cfg.device_id); HIPCHK(on_dev_.err);

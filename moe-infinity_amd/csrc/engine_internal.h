@@ -217,6 +217,9 @@ struct moeinf_engine {
   float* h_la_w = nullptr;             // ... and weights
   int la_armed_T = 0;                  // > 0: the running forward launched a lookahead route over this many tokens
   std::vector<int> la_list;            // node indices predicted for the next layer, best first
+  int num_cus = 0;                     // of THIS engine's device
+  int layer1_switch_wgs_per_cu = -1;   // occupancy of the one-launch Switch kernel (asked once per engine)
+  uint8_t* h_keep = nullptr;           // moeinf_dispatch_mask_subset: pinned byte per expert
   hipEvent_t busy_mark = nullptr;  // stop event of the latest-ending copy interval accounted so far (union of the lanes' busy time)
   int64_t slot_bytes = 0;
   int L = 0, E = 0, K = 0, H = 0, F = 0, Fs = 0;
@@ -340,8 +343,6 @@ struct moeinf_engine {
   uint32_t* d_layer_ctr = nullptr;  // its counters (kernels.h LayerSync): only grow, zeroed at creation and after an error
   uint32_t layer1_launches = 0;
   float* d_layer_part = nullptr;    // [4][H] partial sums of the Switch form's split stage 2
-  int32_t* d_layer_tab = nullptr;   // item table of the persistent one-launch layer (built at the first launch)
-  int layer1_nwg = 0, layer1_maxi = 0;
   bool layer1_scalar_poll = false;
   unsigned long long* d_layer_trace = nullptr;  // MOEINF_LAYER1_TRACE=<file>: per-workgroup timestamps of the last one-launch layer, written out at destroy
   int layer1_trace_blocks = 0;
@@ -392,8 +393,7 @@ struct SelfRoute {  // batch-1 decode: FFN stage 1 routes for itself (launch_ffn
   const RouteArgs* ra;
   const IndexArgs* ia;
   const FfnStage* sh2;  // hidden shared expert's stage 2, or nullptr
-  const FfnStage* sh1 = nullptr;  // layer1: its stage 1
-  bool layer1 = false;  // the whole layer as ONE launch (launch_moe_layer1): the caller has NOT launched the gate
+  const FfnStage* sh1 = nullptr;  // front1: the hidden shared expert's stage 1
   bool front1 = false;  // gate + stage 1 (+ the hidden shared expert) as ONE launch (launch_moe_front1): the caller has NOT launched the gate
   bool layer1_switch = false;  // ... its Switch form (launch_moe_layer1_switch); if that declines, dispatch_experts launches the gate itself
 };

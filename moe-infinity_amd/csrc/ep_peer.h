@@ -186,6 +186,9 @@ struct EpPeerWindow {
     if (base) (void)hipFree(base);
     if (done) (void)hipFree(done);
     base = nullptr; done = nullptr; attached = false; bytes = 0;
+    // a released window starts over: ranks that fell out of step (one of them failed before it took its exchange number)
+    // must meet again at exchange 0 after the next export / attach, not at their old, different epochs
+    epoch = 0; shared_anywhere = false; poll_agreed = true; bcast_agreed = true;
   }
 };
 

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
         }
       }
     } else
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
       // Ping-pong: the two waves of a SIMD (wave w and w + 4, i.e. the row halves wm = 0 / 1) alternate between a LOAD
       // slot (fragment reads of one 16-deep k-step + two DMAs, retired before the slot ends) and a COMPUTE slot (its
       // eight MFMAs), one s_barrier per slot; the wm = 1 half runs one slot behind, so on every SIMD one wave's MFMAs run
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
       // issued, its C3 is slot 8: vmcnt(2); the weights of stage s+1 are older and retire first).  The buffers the DMAs of
       // stage s overwrite were last read in stage s-1's L3 of wm = 1 (slot 7), retired by that slot's lgkmcnt(0), two
       // barriers before the first DMA issue of stage s (slot 1).
-      static_assert(MODE != 2 || RING3, "ping-pong uses the 3-deep weight ring");
+      static_assert(MODE < 2 || RING3, "ping-pong uses the 3-deep weight ring");
       issue_a(0, 0); issue_b(0, 0); issue_a(min(1, KS - 1), 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -275,11 +275,21 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
           // LOAD slot j: the fragments of k-step j+1 are requested one slot ahead (they land under the MFMAs of step j), so
           // only L0 waits out an LDS round trip; L3 requests nothing — the next stage is not known to have landed yet
           big_read_frags<NMAT, RT, RGB, j>(af, bf, a_addr, b_base);
+          if constexpr (MODE == 3) {
+            // MODE 3 (round 6): the stage's eight DMAs ride in the LOAD slots, two behind each k-step's fragment reads (their
+            // issue — address processing for 64 lanes each — then overlaps the reads' LDS round trip and the partner wave's bare
+            // MFMAs, instead of stalling this wave between its own MFMAs while the matrix pipe drains).  Same buffers, same
+            // hazards: a LOAD slot of stage s starts after the barrier that ended the last read of stage s-1.
+            __builtin_amdgcn_sched_barrier(0);
+            issue_next(j * 2);
+            issue_next(j * 2 + 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           // wm = 1 has issued d0..d5 of this stage by now (its C3 is slot 8): all but d4, d5 — i.e. its share of stage s+1's
           // activations and, older, of stage s+1's weights — must have landed before the barrier that ends slot 7
-          if (j == 3 && wm == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          // (MODE 3: d0..d7 are issued by now: all but the newest four)
+          if (j == 3 && wm == 1) { if constexpr (MODE == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
                 // the stage's eight DMAs ride in the COMPUTE slots, one behind every fourth MFMA (32 matrix-pipe cycles
                 // each cover the issue): in the LOAD slot they would lengthen the slot the matrix pipe waits for
                 const int idx = (m * RT + rt) * 2 + tt;
-                if ((idx & 3) == 3) {
+                if (MODE == 2 && (idx & 3) == 3) {
                   __builtin_amdgcn_sched_barrier(0);
                   issue_next(j * 2 + (idx >> 2));
                   __builtin_amdgcn_sched_barrier(0);
@@ -526,7 +536,8 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
     return true;
   }
   if (ring3) {
-    if (mode == 2) { if (nmat == 2) BIGGO(2, true, 2); else BIGGO(1, true, 2); }
+    if (mode == 3) { if (nmat == 2) BIGGO(2, true, 3); else BIGGO(1, true, 3); }
+    else if (mode == 2) { if (nmat == 2) BIGGO(2, true, 2); else BIGGO(1, true, 2); }
     else { if (nmat == 2) BIGGO(2, true, 1); else BIGGO(1, true, 1); }
   } else {
     if (nmat == 2) BIGGO(2, false, 1); else BIGGO(1, false, 1);

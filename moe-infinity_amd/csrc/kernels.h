@@ -224,7 +224,8 @@ hipError_t launch_dispatch_index(const IndexArgs& a, hipStream_t st);
 // Not for a.capacity > 0 (Switch per-row capacity is a sequential pass).
 hipError_t launch_dispatch_index_wide(const IndexArgs& a, int32_t* chunk_scratch, hipStream_t st);
 // dispatch index from a dense router_mask[T,E] (element size 1, 4 or 8 bytes, non-zero = routed)
-hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st);
+// keep: nullptr, or E bytes (device-visible): columns with keep[e] == 0 are treated as all-false
+hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st, const uint8_t* keep = nullptr);
 // fused route_topk + dispatch_index in one single-workgroup launch (use for T <= 64)
 hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_t st, const EpFuse* pack = nullptr);
 // Decode-sized DeepSeek forwards (bf16, T*K <= 64): the shared expert's FFN rides along with the router.
@@ -256,26 +257,20 @@ struct LayerSync {
   uint32_t launch;
   int64_t timeout_ticks;  // bound of every wait, wall_clock64 ticks (100 MHz); on expiry *err = 4 and the workgroup goes on
   int32_t* err;
-  unsigned long long* trace;  // debugging (MOEINF_LAYER1_TRACE=<file>): [workgroup][maxi][4] wall-clock ticks (start, first wait over, second wait over, end); else nullptr
+  int32_t* err_host;          // pinned, device-visible copy of the flag (nullptr: none): the host reads it on the forward path
+  unsigned long long* trace;  // debugging (MOEINF_LAYER1_TRACE=<file>): [workgroup][4] wall-clock ticks (start, first wait over, second wait over, end); else nullptr
   int sleep;                  // s_sleep(2) repetitions between two polls
   int scalar_poll;            // 1: the counters are polled with scalar loads (they live in uncached memory); 0: agent-scope vector loads
-  const int32_t* tab;         // item table [workgroups][maxi] (layer1_table), device memory
-  int maxi;
   float* part;                // Switch form: [4][H] fp32 partial sums of the split stage-2 reduction
 };
-}  // namespace moeinf
-#include <vector>
-namespace moeinf {
-int layer1_table(int E, int K, int H, int F, int Fs, int elem_bytes, int gate_bytes, int ncu, int wpc, std::vector<int32_t>& tab);
-int layer1_wgs_per_cu(int gate_dtype);
-hipError_t launch_moe_layer1(const RouteArgs& r, const IndexArgs& a, const FfnStage& sh1, const FfnStage& sh2, const FfnStage& s1, const FfnStage& s2,
-                             const LayerSync& sy, int nwg, hipStream_t st);
 // the FRONT of a batch-1 layer of the gated families in one launch: gate | (shared stage 1) | meta | self-routing stage 1 |
 // (shared stage 2); stage 2 + combine stay launch_ffn2_decode1.  sh1 / sh2: the hidden shared expert's stages or nullptr.
 hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnStage* sh1, const FfnStage* sh2, const FfnStage& s1, const LayerSync& sy, hipStream_t st);
 // the Switch form (top-1, plain experts, no shared expert): E + 1 + F/16 + 4 * H/16 workgroups of eight waves, all resident at once;
 // false: not handled (the caller runs the three launches)
-bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, hipStream_t st);
+bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, int wgs_per_cu, hipStream_t st);
+// workgroups of that kernel one CU holds at a time (hipOccupancyMaxActiveBlocksPerMultiprocessor of the instantiation; 0: unknown)
+int layer1_switch_wgs_per_cu(int x_dtype, int gate_dtype);
 
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st, const EpWait* wait = nullptr);  // wait: poll these flags first (peer-store exchange)
 // out[i] = valid[i] ? idx[i] : -1

@@ -999,7 +999,7 @@ hipError_t launch_route_index(const RouteArgs& r, const IndexArgs& a, hipStream_
 // (= the boolean-mask gather order of expert_dispatcher.cpp:274-284).
 // ------------------------------------------------------------------------------------------------
 template <typename MT>
-__global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __restrict__ mask, int T, int E, IndexArgs a) {
+__global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __restrict__ mask, int T, int E, IndexArgs a, const uint8_t* __restrict__ keep) {
   __shared__ int cnt[IDX_MAXE];
   __shared__ int offs[IDX_MAXE + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __res
     int c = 0;
     for (int t0 = 0; t0 < T; t0 += 64) {
       const int t = t0 + lane;
-      const bool on = t < T && mask[(size_t)t * E + e] != (MT)0;
+      const bool on = t < T && (!keep || keep[e]) && mask[(size_t)t * E + e] != (MT)0;
       c += __popcll(__ballot(on));
     }
     if (lane == 0) cnt[e] = c;
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __res
     int base = offs[e];
     for (int t0 = 0; t0 < T; t0 += 64) {
       const int t = t0 + lane;
-      const bool on = t < T && mask[(size_t)t * E + e] != (MT)0;
+      const bool on = t < T && (!keep || keep[e]) && mask[(size_t)t * E + e] != (MT)0;
       const uint64_t b = __ballot(on);
       if (on) {
         const int slot = base + __popcll(b & lanes_below(lane));
@@ -1055,10 +1055,10 @@ __global__ __launch_bounds__(IDX_THREADS) void mask_index_kernel(const MT* __res
     }
   }
 }
-hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st) {
-  if (mask_elem_bytes == 1) hipLaunchKernelGGL(mask_index_kernel<uint8_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const uint8_t*)mask, T, E, a);
-  else if (mask_elem_bytes == 4) hipLaunchKernelGGL(mask_index_kernel<int32_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int32_t*)mask, T, E, a);
-  else hipLaunchKernelGGL(mask_index_kernel<int64_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int64_t*)mask, T, E, a);
+hipError_t launch_mask_index(const void* mask, int mask_elem_bytes, int T, int E, const IndexArgs& a, hipStream_t st, const uint8_t* keep) {
+  if (mask_elem_bytes == 1) hipLaunchKernelGGL(mask_index_kernel<uint8_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const uint8_t*)mask, T, E, a, keep);
+  else if (mask_elem_bytes == 4) hipLaunchKernelGGL(mask_index_kernel<int32_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int32_t*)mask, T, E, a, keep);
+  else hipLaunchKernelGGL(mask_index_kernel<int64_t>, dim3(1), dim3(IDX_THREADS), 0, st, (const int64_t*)mask, T, E, a, keep);
   return hipGetLastError();
 }
 

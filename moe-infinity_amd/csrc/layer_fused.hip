@@ -1,39 +1,24 @@
-// layer_fused.hip — a whole batch-1 decode MoE layer of a gated family with a hidden shared expert (DeepSeek-V2-Lite) in ONE
-// launch.  OPT-IN (MOEINF_LAYER1=1): built and measured in round 5, parity-green, and NOT faster than the three launches it
-// would replace — 1.09 ms/token against 0.958 (timelines, what the time goes to, what would change it).
+// layer_fused.hip — counters instead of kernel boundaries, where that pays (round 5):
+//   * moe_front1_kernel: the FRONT of a batch-1 decode layer of the gated families in one launch — gate | (shared expert stage 1)
+//     | meta (router, index, records, mirror) | self-routing stage 1 | (shared expert stage 2); DeepSeek-V2-Lite 0.958 -> 0.928
+//     ms/token (two launches per layer instead of three);
+//   * moe_layer1_switch_kernel: a whole Switch layer (top-1, plain experts) in ONE launch, 0.285 -> 0.204 ms/token.
+// Role = workgroup id; a workgroup only waits for smaller ids and the dispatcher hands workgroups out in id order, so no wait can
+// be circular.  Every wait is bounded by the wall clock (MOEINF_LAYER1_TIMEOUT_MS): on expiry the device error flag reads 4 and the
+// workgroup goes on — a wrong result that the next forward / sync point reports, never a hung GPU.  The counters only grow: launch
+// number n (per engine) waits for n * (arrivals per launch), compared with a signed difference.  They live in UNCACHED memory, one
+// 4 KB page each, and are polled on the SCALAR path (s_load glc): a vector load waits behind every weight tile its CU has requested.
+// Data that crosses workgroups inside the launch is written with write-through stores that are drained before the arrival, and read
+// with agent-scope loads after the wait.
 //
-// Why it was built: the layer moves 139 MB (22 us at the rate this chip streams), but as three dependent launches (gate +
-// shared stage 1 | self-routing stage 1 + shared stage 2 | stage 2 + combine) it takes 33 us of kernels + 4 us of gaps
-// (profiles/r04_rocprof_kernel_stats_deepseekv2lite.csv: 4.7 / 3.6 / 3.7 TB/s).  Here the SAME work items (ffn_rows_item,
-// gate_body, route_core / route_set_lean / index_small of kdev.h — same tiles, same summation order, same rounding points)
-// are items of one PERSISTENT grid (as many workgroups as the chip holds at once; every workgroup walks its own short list
-// from a host-built table, balanced by bytes per CU), and what used to be a kernel boundary is a counter in device memory:
+// What is NOT here any more (round 6): the whole DeepSeek layer as one persistent launch (moe_layer1_kernel, its item table and
+// the stage-2 pre-load helpers).  Built and measured in round 5: parity-green and slower than the two launches it would replace
+// (1.09-1.20 vs 0.928 ms/token; profiles/r05_layer1_vs_three_launches_*.txt, timelines profiles/r05_layer1_timeline_*.txt; DESIGN.md
+// section 4.5.1 keeps the analysis) — the stage-1 -> stage-2 hand-over is a chip-wide barrier under full load, and a kernel
+// boundary is as cheap.  Deleted rather than shipped as 350 lines of opt-in code.
 //
-//   role (list order)          items (DeepSeek-V2-Lite)        waits for            arrives at
-//   1 gate                     E            = 64               —                    GATE
-//   2 shared stage 1           Fs/16        = 176              —                    SH1
-//   3 meta (router, index,     1                               GATE                 META
-//           records, mirror)
-//   4 routed stage 1           K * F/16     = 528              GATE                 H[u]      (routes for itself, u = item / (F/16))
-//   5 shared stage 2           H/16         = 128              SH1 (, META)         tile_done[column tile]
-//   6 routed stage 2           K * H/16     = 768              GATE, H[u], META     tile_done[column tile] -> the LAST arriver combines
-// Stage 2 requests its WEIGHT tiles before it waits for h (ffn2_pre_load: they do not depend on the activations; routed
-// items learn their expert from the logits like stage 1 does; a workgroup that holds two stage-2 items requests both).
-//
-// No deadlock: a list is in ascending role order and an item only waits for items of LOWER roles, which are never behind a
-// wait for a higher one in anybody's list; the grid is sized to what the chip holds (hipOccupancyMaxActiveBlocksPerMultiprocessor
-// x CUs), so every workgroup is resident.  Every wait is bounded by the wall clock (MOEINF_LAYER1_TIMEOUT_MS): on expiry the
-// device error flag reads 4 and the workgroup goes on — a wrong result that the next sync point reports, never a hung GPU.
-// The counters only grow: launch number n (per engine, 1, 2, ...) waits for n * (arrivals per launch); compared with a signed
-// difference, so the wrap of the 32-bit word is harmless.  They live in UNCACHED memory, one 4 KB page each, and are polled
-// on the SCALAR path (s_load glc): a vector load waits behind every weight tile its CU has requested — the first version
-// (one workgroup per item, vector polls) saw a flag 5 us after it was set, and its ~1000 pollers slowed the weight stream
-// itself (launch span 43 us; poll interval x128: 38 us; this form: 34 us; profiles/r05_layer1_timeline_*.txt).
-// Data that crosses workgroups inside the launch (gate logits, h, h_shared, the combine weights, y, y_shared) is written with
-// write-through stores that are drained (s_waitcnt) before the arrival, and read with agent-scope loads after the wait.
-//
-// What this replaces in the reference: one layer's Python router + dispatch_local + per-expert ATen GEMMs + combine loop
-// (moe_infinity/models/deepseek.py:55-136, core/parallel/expert_module.cpp:193-204), like the three launches it competes with.
+// Replaces in the reference: one layer's Python router + dispatch_local + per-expert ATen GEMMs + combine loop
+// (moe_infinity/models/deepseek.py:55-136, switch_transformers.py:74-113, core/parallel/expert_module.cpp:24-36,193-204).
 #include "kdev.h"
 
 #include <algorithm>
@@ -56,7 +41,7 @@ __device__ __forceinline__ void layer_wait(const LayerSync& sy, const int which,
       if (sy.scalar_poll) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(c) : "memory");
       else v = ld_coherent(c);
       if ((int32_t)(v - target) >= 0) break;
-      if (wall_clock64() - t0 > sy.timeout_ticks) { atomicExch(sy.err, 4); break; }
+      if (wall_clock64() - t0 > sy.timeout_ticks) { atomicExch(sy.err, 4); if (sy.err_host) __hip_atomic_store(sy.err_host, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
       for (int i = 0; i < sy.sleep; ++i) __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -93,7 +78,7 @@ __device__ __forceinline__ void layer_wait_spread(const LayerSync& sy, const int
 #pragma unroll
       for (int j = 0; j < LAYER1_SPREAD; ++j) ok = ok && (int32_t)(v[j] - sy.launch * (uint32_t)((total + LAYER1_SPREAD - 1 - j) / LAYER1_SPREAD)) >= 0;
       if (ok) break;
-      if (wall_clock64() - t0 > sy.timeout_ticks) { atomicExch(sy.err, 4); break; }
+      if (wall_clock64() - t0 > sy.timeout_ticks) { atomicExch(sy.err, 4); if (sy.err_host) __hip_atomic_store(sy.err_host, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
       for (int i = 0; i < sy.sleep; ++i) __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -105,96 +90,6 @@ __device__ __forceinline__ void layer_arrive(const LayerSync& sy, const int whic
   wait_stores_acked();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(sy.ctr + which * LAYER1_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// the tail of a stage-2 work item: arrive at the column tile's counter; the last of its K (+1 with a shared expert) arrivers
-// combines the tile's 16 columns (ascending expert id, the reference's rounding points: combine_apply)
-template <typename T>
-__device__ __forceinline__ void layer_tile_done(const FfnStage& s2, const LayerSync& sy, const int tile, const int arrivals, int* is_last) {
-  const int tid = threadIdx.x;
-  wait_stores_acked();
-  __syncthreads();
-  if (tid == 0) *is_last = __hip_atomic_fetch_add(&s2.tile_done[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrivals - 1;
-  __syncthreads();
-  if (*is_last) {
-    if (tid < 4) {
-      CombineMeta m;
-      const int K = s2.comb.K;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) { m.slot[kk] = min(kk, K - 1); m.w[kk] = ld_coherent(&s2.dec_cw[min(kk, K - 1)]); }
-      combine_apply<T, true>(s2.comb, 0, tile * 16 + tid * 4, m);
-    }
-    if (tid == 0) s2.tile_done[tile] = 0;
-  }
-  __syncthreads();  // (*is_last lives in LDS the next item writes)
-}
-
-// Stage 2 of ONE token with the weights fetched BEFORE the activations exist.  The work item of ffn_rows_item<T, 1, 4, U, 1>
-// (16 output columns: k-tiles wave, wave + 4, ... of one row group, multiplied in ascending order, partial sums added over the
-// waves in ascending order, one rounding to the model dtype — the same bits), split in two: `ffn2_pre_load` issues the first P
-// weight tiles of every wave (they do not depend on the activations: P * 4 KB per workgroup in flight while the stage that
-// produces h is still streaming), `ffn2_pre_finish` runs after the wait: the activation fragments of those tiles in ONE batch of
-// agent-scope loads, the multiplies, then the remaining tiles in batches of U like ffn_rows_item.  K % (4 * EPV) == 0.
-template <typename T, int P>
-struct Pre2 {
-  u32x4 w[P];
-  const char* a0;
-  int KB;
-};
-template <typename T, int P, int NW = 4>
-__device__ __forceinline__ void ffn2_pre_load(Pre2<T, P>& p, const FfnStage& s, const int bx, const char* W, const bool sh) {
-  constexpr int EPT = 4 * DT<T>::EPV;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  p.KB = (sh ? s.K_sh : s.K) / EPT;
-  p.a0 = W + (sh ? s.off_a_sh : s.off_a) + (size_t)bx * p.KB * 1024 + lane * 16;
-#pragma unroll
-  for (int i = 0; i < P; ++i)
-    if (W && wave + i * NW < p.KB) p.w[i] = ld16_nt(p.a0 + (size_t)(wave + i * NW) * 1024);
-}
-// prob != nullptr (Switch, top-1): the item also writes the block's output, out = Tr(prob * Tr(acc)) (switch_transformers.py:99-109)
-template <typename T, int P, int U, int NW = 4>
-__device__ __forceinline__ void ffn2_pre_finish(Pre2<T, P>& p, const FfnStage& s, const int bx, const bool sh, const bool live, const int row,
-                                                float (*red)[256], const float* prob = nullptr, T* out_row = nullptr) {
-  constexpr int EPV = DT<T>::EPV, EPT = 4 * EPV;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int R = sh ? s.R_sh : s.R;
-  const T* xr = reinterpret_cast<const T*>(s.in) + (int64_t)row * s.ld_in + (lane >> 4) * EPV;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    u32x4 xv[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-      if (wave + i * NW < p.KB) xv[i] = ld16_coherent(xr + (size_t)(wave + i * NW) * EPT);
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-      if (wave + i * NW < p.KB) mma16<T>(acc, p.w[i], xv[i]);
-    for (int kb = wave + P * NW; kb < p.KB; kb += U * NW) {
-      u32x4 av[U], bv[U];
-#pragma unroll
-      for (int i = 0; i < U; ++i)
-        if (kb + i * NW < p.KB) { av[i] = ld16_nt(p.a0 + (size_t)(kb + i * NW) * 1024); bv[i] = ld16_coherent(xr + (size_t)(kb + i * NW) * EPT); }
-#pragma unroll
-      for (int i = 0; i < U; ++i)
-        if (kb + i * NW < p.KB) mma16<T>(acc, av[i], bv[i]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = acc[j];
-  __syncthreads();
-  if (tid < 256) {
-    const int i = tid;  // 256 threads = the 256 sums of the tile
-    float s0 = 0.f;  // (exactly ffn_rows_item's chain, signed zeros included)
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) s0 += red[ww][i];
-    const int l = i >> 2, j = i & 3;
-    const int orow = bx * 16 + (l >> 4) * 4 + j;
-    if (live && (l & 15) == 0 && orow < R) {
-      const float v = DT<T>::round(s0);
-      DT<T>::store_coherent(reinterpret_cast<T*>(s.out) + (size_t)row * s.ld_out + orow, v);
-      if (prob) DT<T>::store(out_row + orow, DT<T>::round(ld_coherent(prob) * v));
-    }
-  }
-  __syncthreads();
 }
 
 // The blob pointer of the u-th chosen expert (ascending id) of the one token, derived by THIS workgroup from the gate logits
@@ -219,149 +114,6 @@ __device__ __forceinline__ const char* layer_selfroute(const RouteArgs& r, const
   }
   __syncthreads();
   return reinterpret_cast<const char*>(*sh_w);
-}
-
-enum { LR_END = 0, LR_GATE = 1, LR_SH1 = 2, LR_META = 3, LR_R1 = 4, LR_SH2 = 5, LR_R2 = 6 };  // roles of the item table
-
-// WPE: workgroups per CU the register budget is cut for (a workgroup = one wave per SIMD): 3 -> 168 registers, 2 -> 256
-template <typename T, typename GW, int U1, int U2, int PRE, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(WPE, WPE))) void moe_layer1_kernel(RouteArgs r, IndexArgs a, FfnStage sh1, FfnStage sh2, FfnStage s1, FfnStage s2,
-                                                                                              LayerSync sy, int round_logits) {
-  constexpr int NW = 4;
-  // PRE: weight tiles per wave requested ahead of the activations (DeepSeek-V2-Lite, 11: all of a routed stage-2 item, half of the shared one)
-  __shared__ float red[NW][2][256];
-  __shared__ double redg[4][4];
-  __shared__ unsigned long long sh_w;
-  __shared__ int sh_flag;
-  static_assert(sizeof(float) * NW * 2 * 256 >= sizeof(int) * (2 * IDX_MAXE + 1), "index scratch aliases the reduction buffer");
-  const int lane = threadIdx.x & 63;
-  const int K = r.K, E = r.E;
-  const int n_gate = E, n_sh1 = (sh1.R_sh + 15) / 16, n_rg = (s1.R + 15) / 16, n_col = (s2.R + 15) / 16;
-  const bool has_sh = sh1.R_sh > 0;
-
-  // PERSISTENT: every workgroup walks its own short list of work items (host-built table, balanced by bytes per CU, roles in
-  // ascending order inside a list).  A workgroup only waits for items of LOWER roles, and those are never behind a wait for a
-  // higher one in anybody's list; with every workgroup resident (the launcher sizes the grid to what the chip holds) no wait
-  // can be circular.
-  // (one loop per role, in role order, instead of one loop over a switch: the register allocation of a role's body then
-  // does not meet the others' at a common join — 124 registers instead of 400)
-  const int32_t* tab = sy.tab + (size_t)blockIdx.x * sy.maxi;
-  int j = 0;
-#define ITEM_IS(ROLE) (j < sy.maxi && (tab[j] >> 24) == (ROLE))
-#define ITEM_BEGIN const int b = tab[j] & 0xffffff; const int tslot = ((int)blockIdx.x * sy.maxi + j) * 4; layer_trace(sy, tslot + 0);
-#define ITEM_END layer_trace(sy, tslot + 3); ++j;
-  while (ITEM_IS(LR_GATE)) {  // ---- gate: one logit per item (fp64 accumulation: the routing does not depend on the summation order)
-    ITEM_BEGIN
-    gate_body<uint16_t, GW, 4, true>(reinterpret_cast<const uint16_t*>(r.x), reinterpret_cast<const GW*>(r.gate_w), r.logits, 1, r.H, E, round_logits, redg, b, 0);
-    layer_arrive(sy, LC_GATE);
-    ITEM_END
-  }
-  while (ITEM_IS(LR_SH1)) {  // ---- shared expert, stage 1: 16 rows of its gate / up projections, needs nothing but x
-    ITEM_BEGIN
-    const char* W = reinterpret_cast<const char*>(sh1.wptr[sh1.E]);
-    ffn_rows_item<T, 2, NW, U1, 1, false, true>(sh1, b, W, true, 1, 0, red);
-    layer_arrive(sy, LC_SH1);
-    ITEM_END
-  }
-  while (ITEM_IS(LR_META)) {  // ---- meta: the generic router, the one-wave dispatch index, the decode records, the pinned routing mirror
-    ITEM_BEGIN
-    (void)b;
-    layer_wait(sy, LC_GATE, n_gate);
-    layer_trace(sy, tslot + 1);
-    if (threadIdx.x < 64) {
-      int* scratch = reinterpret_cast<int*>(&red[0][0][0]);
-      Routed o;
-      route_core<true>(r, 0, lane, o);
-      int my_sel, rank;
-      float my_w;
-      route_store(r, 0, lane, o, &my_sel, &my_w, &rank);
-      if (lane < K) {  // blob pointer and combine weight of the rank-th chosen expert (ascending id); the weights are read by the combine of THIS launch
-        st_coherent(&s2.dec_w[rank], my_sel >= 0 ? (uint64_t)s2.wptr[my_sel] : (uint64_t)0);
-        st_coherent(&s2.dec_cw[rank], my_w);
-      }
-      wait_stores_acked();
-      // META = the combine weights are out; the index and the pinned mirror (PCIe writes) are for the host and later launches
-      if (lane == 0) __hip_atomic_fetch_add(sy.ctr + LC_META * LAYER1_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_block();
-      index_small(a, scratch, scratch + IDX_MAXE);
-    }
-    __syncthreads();
-    ITEM_END
-  }
-  while (ITEM_IS(LR_R1)) {  // ---- routed stage 1: routes for itself (every workgroup derives the same set from the same logits)
-    ITEM_BEGIN
-    const int u = b / n_rg, rg = b - u * n_rg;
-    layer_wait(sy, LC_GATE, n_gate);
-    layer_trace(sy, tslot + 1);
-    const char* W = layer_selfroute(r, s1, u, &sh_w, &sh_flag);
-    if (sh_flag && W == nullptr && threadIdx.x == 0 && rg == 0) atomicExch(s1.miss_flag, 1);  // (never on the sync-free path)
-    // (an absent expert still ARRIVES: the counters must see the same number of arrivals in every launch)
-    ffn_rows_item<T, 2, NW, U1, 1, false, true>(s1, rg, W, false, (sh_flag && W) ? 1 : 0, u, red, 0);
-    layer_trace(sy, tslot + 2);
-    layer_arrive(sy, LC_H0 + u);
-    ITEM_END
-  }
-  while (ITEM_IS(LR_SH2)) {  // ---- shared expert, stage 2: 16 output columns; one more arriver of that column tile
-    ITEM_BEGIN
-    const char* W = reinterpret_cast<const char*>(sh2.wptr[sh2.E]);
-    Pre2<T, PRE> p;
-    ffn2_pre_load<T, PRE>(p, sh2, b, W, true);  // the first PRE tiles of every wave are on their way before h_shared exists
-    layer_trace(sy, tslot + 1);
-    layer_wait(sy, LC_SH1, n_sh1);
-    layer_trace(sy, tslot + 2);
-    ffn2_pre_finish<T, PRE, U2>(p, sh2, b, true, true, 0, reinterpret_cast<float (*)[256]>(&red[0][0][0]));
-    // (whoever arrives last at a column tile reads the combine weights)
-    layer_wait(sy, LC_META, 1);
-    layer_tile_done<T>(s2, sy, b, K + 1, &sh_flag);
-    ITEM_END
-  }
-  while (ITEM_IS(LR_R2)) {  // ---- routed stage 2 of slot u, 16 output columns, combine in the tail of the last arriver
-    // routes for itself like stage 1 (not the meta item's record: its weight tiles do not depend on h, so they are
-    // requested NOW, while stage 1 may still be streaming — the whole layer is one stream of weights, only h waits).
-    // Two items at a time: a workgroup that holds a second one has its weights on the way too before it waits for h
-    // (the workgroups that finish stage 1 first are the ones with two; one after the other they were the launch's tail).
-    const bool two = j + 1 < sy.maxi && (tab[j + 1] >> 24) == LR_R2;
-    const int bA = tab[j] & 0xffffff, bB = two ? tab[j + 1] & 0xffffff : 0;
-    const int tslot = ((int)blockIdx.x * sy.maxi + j) * 4;
-    layer_trace(sy, tslot + 0);
-    if (two) layer_trace(sy, tslot + 4);
-    const int uA = bA / n_col, colA = bA - uA * n_col, uB = bB / n_col, colB = bB - uB * n_col;
-    layer_wait(sy, LC_GATE, n_gate);
-    layer_trace(sy, tslot + 1);
-    const char* WA = layer_selfroute(r, s2, uA, &sh_w, &sh_flag);
-    const bool liveA = sh_flag && WA;
-    if (sh_flag && WA == nullptr && threadIdx.x == 0 && colA == 0) atomicExch(s2.miss_flag, 1);
-    constexpr int PREB = PRE > 6 ? 6 : PRE;  // (the second item's head start: as many tiles as the registers hold without spilling)
-    Pre2<T, PRE> pA;
-    Pre2<T, PREB> pB;
-    ffn2_pre_load<T, PRE>(pA, s2, colA, liveA ? WA : nullptr, false);
-    bool liveB = false;
-    if (two) {
-      __syncthreads();  // (everybody has read sh_w / sh_flag of item A)
-      const char* WB = layer_selfroute(r, s2, uB, &sh_w, &sh_flag);
-      liveB = sh_flag && WB;
-      if (sh_flag && WB == nullptr && threadIdx.x == 0 && colB == 0) atomicExch(s2.miss_flag, 1);
-      ffn2_pre_load<T, PREB>(pB, s2, colB, liveB ? WB : nullptr, false);
-      layer_trace(sy, tslot + 5);
-    }
-    layer_wait(sy, LC_H0 + uA, n_rg);
-    layer_trace(sy, tslot + 2);
-    ffn2_pre_finish<T, PRE, U2>(pA, s2, colA, false, liveA, uA, reinterpret_cast<float (*)[256]>(&red[0][0][0]));
-    layer_wait(sy, LC_META, 1);  // (long done: the combine weights of the last arriver)
-    layer_tile_done<T>(s2, sy, colA, K + (has_sh ? 1 : 0), &sh_flag);
-    layer_trace(sy, tslot + 3);
-    if (two) {
-      layer_wait(sy, LC_H0 + uB, n_rg);
-      layer_trace(sy, tslot + 6);
-      ffn2_pre_finish<T, PREB, U2>(pB, s2, colB, false, liveB, uB, reinterpret_cast<float (*)[256]>(&red[0][0][0]));
-      layer_tile_done<T>(s2, sy, colB, K + (has_sh ? 1 : 0), &sh_flag);
-      layer_trace(sy, tslot + 7);
-    }
-    j += two ? 2 : 1;
-  }
-#undef ITEM_IS
-#undef ITEM_BEGIN
-#undef ITEM_END
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,12 +361,24 @@ __global__ __launch_bounds__(512) void moe_layer1_switch_kernel(RouteArgs r, Ind
 
 // Switch: x and experts in one dtype (fp32 for Switch-base, bf16), gate in the model dtype or fp32.  false: not handled (more
 // workgroups than the chip holds at once — they must all be resident —, a reduction the split does not cover, an odd dtype mix).
-bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, hipStream_t st) {
+int layer1_switch_wgs_per_cu(int x_dtype, int gate_dtype) {
+  int n = 0;
+  hipError_t e = hipErrorInvalidValue;
+  if (x_dtype == DT_F32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_switch_kernel<float, float, 6, 4>, 512, 0);
+  else if (gate_dtype == DT_BF16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_switch_kernel<uint16_t, uint16_t, 6, 4>, 512, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_switch_kernel<uint16_t, float, 6, 4>, 512, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage& s2, const LayerSync& sy, int num_cus, int wgs_per_cu, hipStream_t st) {
   constexpr int KS = 4, P2 = 6, NW = 8;
   const int n_rg = (s1.R + 15) / 16, n_col = (s2.R + 15) / 16;
   const dim3 grid(r.E + 1 + n_rg + KS * n_col);
   const int ept = s2.dtype == DT_F32 ? 16 : 32;
-  if ((int)grid.x > 2 * num_cus || (s2.K % (ept * KS)) != 0 || (s1.K % ept) != 0 || s2.K / ept / KS > NW * P2 || r.K != 1 || s2.dtype == DT_F16 || !sy.part) return false;
+  // every workgroup resident at once: what the chip HOLDS is asked (occupancy query), not assumed; at most two per CU even if more fit
+  const int per_cu = wgs_per_cu > 0 ? (wgs_per_cu < 2 ? wgs_per_cu : 2) : 0;
+  if (per_cu == 0 || (int)grid.x > per_cu * num_cus || (s2.K % (ept * KS)) != 0 || (s1.K % ept) != 0 || s2.K / ept / KS > NW * P2 || r.K != 1 || s2.dtype == DT_F16 || !sy.part) return false;
   if (s2.dtype == DT_F32) {
     if (r.gate_dtype != DT_F32) return false;
     hipLaunchKernelGGL((moe_layer1_switch_kernel<float, float, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
@@ -624,67 +388,6 @@ bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnS
     else return false;
   }
   return hipGetLastError() == hipSuccess;
-}
-
-// The item table: which work items every workgroup walks, in which order.  Virtual CU c = workgroups c, c + ncu, c + 2 ncu, ...
-// (the dispatcher deals the workgroups of a grid round-robin; if it does not, only the balance suffers).  Items are handed
-// out role by role (gate, shared stage 1, meta, routed stage 1, shared stage 2, routed stage 2), each to the CU with the
-// fewest bytes so far; a CU's items go to its workgroups round-robin, so lists are in ascending role order.
-// Entry = role << 24 | index; 0 ends a list.  Returns the list length (entries per workgroup).
-int layer1_table(int E, int K, int H, int F, int Fs, int elem_bytes, int gate_bytes, int ncu, int wpc, std::vector<int32_t>& tab) {
-  const int n_sh1 = (Fs + 15) / 16, n_rg = (F + 15) / 16, n_col = (H + 15) / 16;
-  struct Role { int role, n; int64_t bytes; };
-  const Role roles[] = {{LR_GATE, E, std::max<int64_t>((int64_t)H * gate_bytes, 16384)}, {LR_SH1, Fs > 0 ? n_sh1 : 0, (int64_t)2 * 16 * H * elem_bytes},
-                        {LR_META, 1, 65536}, {LR_R1, K * n_rg, (int64_t)2 * 16 * H * elem_bytes},
-                        {LR_SH2, Fs > 0 ? n_col : 0, (int64_t)16 * Fs * elem_bytes}, {LR_R2, K * n_col, (int64_t)16 * F * elem_bytes}};
-  std::vector<std::vector<int32_t>> cu(ncu);
-  std::vector<int64_t> load(ncu, 0);
-  for (const Role& ro : roles)
-    for (int i = 0; i < ro.n; ++i) {
-      int best = 0;
-      for (int c = 1; c < ncu; ++c) if (load[c] < load[best]) best = c;
-      cu[best].push_back((ro.role << 24) | i);
-      load[best] += ro.bytes;
-    }
-  size_t longest = 0;
-  for (auto& l : cu) longest = std::max(longest, l.size());
-  const int maxi = (int)((longest + wpc - 1) / wpc);
-  tab.assign((size_t)ncu * wpc * maxi, 0);
-  for (int c = 0; c < ncu; ++c)
-    for (size_t j = 0; j < cu[c].size(); ++j) {
-      const int w = c + ncu * (int)(j % wpc);
-      tab[(size_t)w * maxi + j / wpc] = cu[c][j];
-    }
-  return maxi;
-}
-
-// workgroups of this kernel that one CU holds at a time (registers, LDS): the persistent grid must not exceed ncu times this
-static int layer1_wpe() { static const int w = env_int("MOEINF_LAYER1_WPE", 3) == 2 ? 2 : 3; return w; }
-int layer1_wgs_per_cu(int gate_dtype) {
-  int n = 0;
-  hipError_t e;
-  if (layer1_wpe() == 2) e = gate_dtype == DT_BF16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_kernel<uint16_t, uint16_t, 8, 4, 11, 2>, 256, 0)
-                                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_kernel<uint16_t, float, 8, 4, 11, 2>, 256, 0);
-  else e = gate_dtype == DT_BF16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_kernel<uint16_t, uint16_t, 8, 4, 11, 3>, 256, 0)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, moe_layer1_kernel<uint16_t, float, 8, 4, 11, 3>, 256, 0);
-  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return std::min(n, layer1_wpe());
-}
-
-// gate weights bf16 or fp32 (DeepSeek: fp32 gate over bf16 activations); bf16 model.  grid = the table's workgroups.
-hipError_t launch_moe_layer1(const RouteArgs& r, const IndexArgs& a, const FfnStage& sh1, const FfnStage& sh2, const FfnStage& s1, const FfnStage& s2,
-                             const LayerSync& sy, int nwg, hipStream_t st) {
-  const dim3 grid(nwg);
-  const int rl = r.kind != 0 ? 0 : 1;  // Mixtral's gate is an nn.Linear in the model dtype: logits rounded to bf16
-  // MOEINF_LAYER1_PRE: stage-2 weight tiles per wave requested ahead of h (11 | 4)
-  static const int pre = env_int("MOEINF_LAYER1_PRE", 4);  // (11 needs the 256-register budget, MOEINF_LAYER1_WPE=2: with 168 it spills)
-#define L1(GW, PP, WW) hipLaunchKernelGGL((moe_layer1_kernel<uint16_t, GW, 8, 4, PP, WW>), grid, dim3(256), 0, st, r, a, sh1, sh2, s1, s2, sy, rl)
-#define L1W(GW, PP) do { if (layer1_wpe() == 2) L1(GW, PP, 2); else L1(GW, PP, 3); } while (0)
-  if (r.gate_dtype == DT_BF16) { if (pre == 4) L1W(uint16_t, 4); else L1W(uint16_t, 11); }
-  else { if (pre == 4) L1W(float, 4); else L1W(float, 11); }
-#undef L1W
-#undef L1
-  return hipGetLastError();
 }
 
 }  // namespace moeinf

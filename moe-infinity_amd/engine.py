@@ -166,9 +166,10 @@ class MoEEngine:
             return None
         return out if out.shape == shape else out.reshape(shape)
 
-    def dispatch_mask(self, layer: int, x2: torch.Tensor, router_mask: torch.Tensor):
+    def dispatch_mask(self, layer: int, x2: torch.Tensor, router_mask: torch.Tensor, experts: Optional[Sequence[int]] = None):
         """Grouped expert FFN for a dense router_mask[T,E] (the reference's dispatch_local contract).
-        Returns (y [rows,H] expert-sorted device tensor, counts[E], hit[E])."""
+        Returns (y [rows,H] expert-sorted device tensor, counts[E], hit[E]).  ``experts``: only these columns of the mask
+        run (moeinf_dispatch_mask_subset: the experts enqueued on this engine), the others count as all-false."""
         self._check_dev(x2, self.dtype, "x")
         T, E = x2.shape[0], self.cfg.num_experts
         m = router_mask.reshape(T, E)
@@ -183,9 +184,14 @@ class MoEEngine:
         counts = np.empty(E, np.int32)
         hit = np.empty(E, np.int32)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self.lib.moeinf_dispatch_mask(self._h, layer, _ptr(x2), T, _ptr(m), m.element_size(), _ptr(y),
-                                            counts.ctypes.data_as(C.POINTER(C.c_int32)),
-                                            hit.ctypes.data_as(C.POINTER(C.c_int32)), stream))
+        if experts is None:
+            ids, n_ids = None, 0
+        else:
+            ids = (C.c_int32 * max(1, len(experts)))(*[int(e) for e in experts])
+            n_ids = len(experts)
+        check(self.lib.moeinf_dispatch_mask_subset(self._h, layer, _ptr(x2), T, _ptr(m), m.element_size(), _ptr(y),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   hit.ctypes.data_as(C.POINTER(C.c_int32)), stream, ids, n_ids))
         self._last_T = T
         return y[: int(counts.sum())], counts, hit
 
@@ -427,8 +433,16 @@ class MoEEngine:
         buf = (C.c_uint8 * len(blobs)).from_buffer_copy(blobs)
         check(self.lib.moeinf_ep_peer_attach(self._h, buf, len(blobs)))
 
-    def ep_peer_set_timeout_ms(self, ms: int):
+    def ep_peer_get_timeout_ms(self) -> int:
+        ms = C.c_int(0)
+        check(self.lib.moeinf_ep_peer_get_timeout_ms(self._h, C.byref(ms)))
+        return int(ms.value)
+
+    def ep_peer_set_timeout_ms(self, ms: int) -> int:
+        """returns the timeout that was in force (what a caller that shortens it temporarily restores)"""
+        prev = self.ep_peer_get_timeout_ms()
         check(self.lib.moeinf_ep_peer_set_timeout_ms(self._h, int(ms)))
+        return prev
 
     def ep_peer_release(self):
         """moeinf_ep_peer_release: unmap the peers and free the window (the group agreed not to use this transport)"""

@@ -192,11 +192,12 @@ class ExpertParallelMoE:
                 self.native_note = "mapping the peers' windows failed on another rank"
             self._release_peer_store(eng)
             return False
+        prev_timeout = None
         try:
             # bounded bootstrap: a peer that never publishes costs BOOT_TIMEOUT_MS per poll of the self-test, not the
-            # exchange's own (long) timeout; the caller's setting comes back below
+            # exchange's own (long) timeout; the setting that was in force comes back below
             if hasattr(eng, "ep_peer_set_timeout_ms"):
-                eng.ep_peer_set_timeout_ms(self.BOOT_TIMEOUT_MS)
+                prev_timeout = eng.ep_peer_set_timeout_ms(self.BOOT_TIMEOUT_MS)
             ok = eng.ep_peer_selftest()
             if not ok:
                 self.native_note = "self-test: wrong rows or a peer never published (timeout)"
@@ -204,8 +205,13 @@ class ExpertParallelMoE:
             ok = False
             self.native_note = f"self-test failed: {ex}"
         finally:
-            if hasattr(eng, "ep_peer_set_timeout_ms"):
-                eng.ep_peer_set_timeout_ms(int(os.environ.get("MOEINF_EP_PEER_TIMEOUT_MS", "10000")))
+            # whatever happens here, this rank must reach the collective _agree() below: the others are waiting in it
+            try:
+                if prev_timeout:
+                    eng.ep_peer_set_timeout_ms(prev_timeout)
+            except Exception as ex:  # noqa: BLE001
+                ok = False
+                self.native_note = f"restoring the exchange timeout failed: {ex}"
         if not self._agree(ok):
             if ok:
                 self.native_note = "self-test failed on another rank"

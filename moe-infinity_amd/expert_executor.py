@@ -60,11 +60,8 @@ class ExpertDispatcher:
             enq = sorted({e for _, e, s in self._queue if s == slot})
             hidden = self._hidden if self._hidden.device == eng.device else self._hidden.to(eng.device)
             mask = self._mask if self._mask.device == eng.device else self._mask.to(eng.device)
-            if len(enq) != mask.shape[1]:  # only the experts enqueued on this engine run
-                keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=mask.device)
-                keep[torch.tensor(enq, device=mask.device)] = True
-                mask = mask.bool() & keep
-            y, counts, hit = eng.dispatch_mask(layer, hidden, mask)
+            # only the experts enqueued on this engine run (moeinf_dispatch_mask_subset)
+            y, counts, hit = eng.dispatch_mask(layer, hidden, mask, experts=None if len(enq) == mask.shape[1] else enq)
             if y.device != home:
                 y = y.to(home)
             row = 0

@@ -560,13 +560,11 @@ class expert_dispatcher:
                 hidden = self._hidden if self._hidden.device == dev else self._hidden.to(dev)   # GPUFetchFunc: input.to(node device)
                 mask = self._mask if self._mask.device == dev else self._mask.to(dev)
                 enq = sorted(set(by_slot[slot]))
-                if len(enq) != mask.shape[1]:  # only the experts enqueued on this device run here
-                    keep = torch.zeros(mask.shape[1], dtype=torch.bool, device=dev)
-                    keep[torch.tensor(enq, device=dev)] = True
-                    mask = mask.bool() & keep
                 if hidden.shape[0] > eng.cfg.max_tokens:
                     eng.reserve_tokens(hidden.shape[0])
-                y, counts, hit = eng.dispatch_mask(layer, hidden, mask)
+                # only the experts enqueued on this device run here: the id list goes down with the call (no second mask, no
+                # host-to-device copy on this side of the boundary)
+                y, counts, hit = eng.dispatch_mask(layer, hidden, mask, experts=None if len(enq) == mask.shape[1] else enq)
                 if dev != home_dev:
                     y = y.to(home_dev)  # OutputFunc: output.to(output_device)
                     torch.cuda.current_stream(dev).synchronize()

@@ -52,6 +52,10 @@ def test_bench_spawns_its_own_two_ranks_and_they_exchange_over_peer_store():
     assert line["ep_transport"]["chosen"] == "peer-store", (line["ep_transport"], err[-2000:])
     tr = line["_details"]["ep_transport"]
     assert any("probation passed on every rank" in c for c in tr["candidates"]), tr
+    # every transport that works here is timed, not only the chosen one (on this shared GPU: peer-store and torch; RCCL needs
+    # one GPU per rank), and the chosen transport's figure is the line's ms_per_step
+    by = line["ep_transport"]["ms_per_step_by_transport"]
+    assert set(by) >= {"peer-store", "torch"} and by["peer-store"] == line["ms_per_step"] and by["torch"] > 0, by
     assert line["value"] > 0 and line["ep_phases_us_per_layer"], line
 
 

@@ -158,3 +158,39 @@ def test_peer_store_bootstrap_errors_are_local_and_never_block():
         e1[1].close()
     finally:
         os.environ.pop("MOEINF_EP_PEER_TIMEOUT_MS", None)
+
+
+def test_a_released_window_starts_over_at_exchange_zero_and_the_timeout_getter_round_trips():
+    """moeinf_ep_peer_release kept the exchange number, so a group whose ranks had fallen out of step (one of
+    them failed before it took its number) met again at DIFFERENT epochs after the next export / attach and failed at once
+    with flag 2 or 3.  Release resets it; and a host layer that shortens the exchange timeout for a probation restores the
+    value that was in force (getter), not the environment's default."""
+    os.environ["MOEINF_EP_PEER_TIMEOUT_MS"] = "2000"
+    try:
+        h, f, e, k, L = 512, 256, 8, 2, 1
+        ws, engs = _engines("mixtral", 1, h, f, e, k, 0, L, max_tokens=32, seed=5400)
+        eng = engs[0]
+        gate = ws[0][0].to(DEV)
+        eng.ep_peer_attach(eng.ep_peer_export(8))
+        assert eng.ep_peer_selftest()
+        for i in range(3):  # three exchanges: the window's number moves on
+            x = acts(2, h, torch.bfloat16, 5410 + i)
+            out = torch.empty(2, h, dtype=torch.bfloat16, device=DEV)
+            eng.ep_moe_forward(0, x.to(DEV), gate, out)
+            eng.sync()
+        n0 = eng.ep_transport()["exchanges"]
+        assert n0 >= 3
+        assert eng.ep_peer_get_timeout_ms() == 2000
+        assert eng.ep_peer_set_timeout_ms(750) == 2000 and eng.ep_peer_get_timeout_ms() == 750
+        eng.ep_peer_release()
+        assert eng.ep_transport()["transport"] != "peer-store"
+        eng.ep_peer_attach(eng.ep_peer_export(8))
+        assert eng.ep_transport()["exchanges"] == 0, "a fresh window counts its exchanges from zero"
+        assert eng.ep_peer_selftest()
+        x = acts(2, h, torch.bfloat16, 5420)
+        eng.ep_moe_forward(0, x.to(DEV), gate, out)
+        eng.sync()
+        assert_block_close(out.cpu(), R.block_mixtral(x[None], ws[0][0], ws[0][1], top_k=k), torch.bfloat16, "forward over the re-exported window")
+        eng.close()
+    finally:
+        os.environ.pop("MOEINF_EP_PEER_TIMEOUT_MS", None)

@@ -78,16 +78,8 @@ def test_deepseek_v2_lite_layer(t):
     experts, shared = fill_layer_on_gpu(eng, "deepseek", 0, 2234)
     gate = _gate(cfg.num_experts, cfg.hidden, torch.bfloat16, 4322, 0.02)
     x = acts(t, cfg.hidden, torch.bfloat16, 2025)
-    expect_one_launch = t == 1 and os.environ.get("MOEINF_TEST_EXPECT_LAYER1") == "1"  # (test_one_launch_decode_layer_is_parity_green)
-    if expect_one_launch:  # the one-launch layer is a form of the SYNC-FREE path: every expert of the layer resident first
-        eng.prefetch(0, list(range(cfg.num_experts)))
-        eng.sync_copies()
-        eng.set_profiling(True)
     for _ in range(2):
         out = eng.forward(0, x.to(DEV), gate.to(DEV))
-    if expect_one_launch:
-        assert eng.profile()["fused_layers"] >= 1, "MOEINF_LAYER1=1 but the layer did not run as one launch"
-        eng.set_profiling(False)
     ref = R.block_deepseek(x[None], gate, experts, cfg.top_k, shared=shared, norm_topk_prob=bool(cfg.norm_topk_prob),
                            routed_scaling_factor=cfg.routed_scaling_factor)
     r = _check_index(eng, ref)
@@ -325,21 +317,3 @@ def test_mixtral_8x7b_layer_skewed_routing_takes_several_passes():
         assert_block_close(out, ref, torch.bfloat16, what)
     assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.bfloat16, "Mixtral-8x7B layer, skewed routing", rows=got_rows)
     eng.close()
-
-
-@pytest.mark.parametrize("knobs", [{}, {"MOEINF_LAYER1_WPE": "2", "MOEINF_LAYER1_PRE": "11"}, {"MOEINF_LAYER1_POLL": "vector"}],
-                         ids=["default_budget", "256_registers_all_stage2_tiles_ahead_of_h", "counters_polled_with_vector_loads"])
-def test_one_launch_decode_layer_is_parity_green(knobs):
-    """MOEINF_LAYER1=1 (opt-in, csrc/layer_fused.hip): a whole batch-1 DeepSeek layer — gate, shared expert, self-routing
-    stage 1, stage 2, combine — as ONE persistent launch whose work items hand over through counters in device memory.  The
-    DeepSeek batch-1 cases (full-size layer, golden vectors, self-routing incl. ties, the chained model) in a child process with
-    the knob set (the engine reads it once per process); the child fails if the one-launch path did not actually run."""
-    import subprocess
-    import sys
-
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MOEINF_LAYER1="1", MOEINF_TEST_EXPECT_LAYER1="1", **knobs)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-k",
-                        "(deepseek_v2_lite_layer and decode_b1) or deepseek_decode_b1 or (batch1_decode_selfrouting and deepseek) or (ties_lowest and deepseek)"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]

@@ -107,40 +107,3 @@ def test_environment_knobs_are_honoured(monkeypatch):
     assert form(BF16, 2, 4096, 14336, 8, 193)[:2] == (12, 0)
     monkeypatch.setenv("MOEINF_RING2_MAX_ROWS", "256")
     assert form(BF16, 2, 4096, 14336, 8, 257)[0] == 0
-
-
-def test_item_table_of_the_one_launch_decode_layer():
-    """csrc/layer_fused.hip: every work item of the layer appears exactly once; a workgroup's list is in ascending role order
-    (what makes the in-kernel waits acyclic: a workgroup only waits for items of lower roles); the bytes per virtual CU
-    (workgroups c, c + ncu, ...) are balanced."""
-    import ctypes as C
-
-    import numpy as np
-
-    from moe_infinity_amd._lib import check, load_library
-
-    lib = load_library()
-    for (E, K, H, F, Fs, ncu, wpc) in [(64, 6, 2048, 1408, 2816, 256, 3), (64, 6, 2048, 1408, 2816, 256, 4), (8, 2, 4096, 14336, 0, 256, 3),
-                                       (16, 4, 256, 192, 384, 256, 3), (64, 6, 2048, 1408, 2816, 80, 2)]:
-        out = np.zeros(ncu * wpc * 64, np.int32)
-        n = C.c_int32()
-        check(lib.moeinf_layer1_table(E, K, H, F, Fs, 2, 4, ncu, wpc, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size, C.byref(n)))
-        maxi = n.value
-        tab = out[: ncu * wpc * maxi].reshape(ncu * wpc, maxi)
-        want = {1: E, 2: (Fs + 15) // 16 if Fs else 0, 3: 1, 4: K * ((F + 15) // 16), 5: (H + 15) // 16 if Fs else 0, 6: K * ((H + 15) // 16)}
-        seen = {r: set() for r in want}
-        for w in range(tab.shape[0]):
-            roles = [int(e) >> 24 for e in tab[w] if e]
-            assert roles == sorted(roles), (w, roles)
-            assert all(e == 0 for e in tab[w][len(roles):]), "a list ends at its first 0"
-            for e in tab[w][: len(roles)]:
-                r, i = int(e) >> 24, int(e) & 0xFFFFFF
-                assert i not in seen[r], (r, i)
-                seen[r].add(i)
-        for r, cnt in want.items():
-            assert seen[r] == set(range(cnt)), (r, cnt, len(seen[r]))
-        cost = {1: max(H * 4, 16384), 2: 2 * 16 * H * 2, 3: 65536, 4: 2 * 16 * H * 2, 5: 16 * Fs * 2, 6: 16 * F * 2}
-        per_cu = np.zeros(ncu)
-        for w in range(tab.shape[0]):
-            per_cu[w % ncu] += sum(cost[int(e) >> 24] for e in tab[w] if e)
-        assert per_cu.max() - per_cu.min() <= max(cost.values()), (per_cu.min(), per_cu.max())

@@ -84,7 +84,7 @@ def measure(workload="mixtral-8x7b", layers=8, steps=20, warmup=3, directory=Non
         tid = 0
         t0 = time.time()
         for l in range(L):
-            gates.append(torch.empty(E, H, dtype=torch.float32 if family == "deepseek" else dt, device=dev).normal_(0.0, 0.02, generator=gen))
+            gates.append(torch.empty(E, H, dtype=dt, device=dev).normal_(0.0, 0.02, generator=gen))  # (the gate is a parameter in the model dtype; DeepSeek's MoEGate up-casts it)
             if Fs:
                 shared.append([torch.empty(s, dtype=dt, device=dev).normal_(0.0, 0.02, generator=gen) for s in [(Fs, H), (Fs, H), (H, Fs)]])
             ids_l = []
@@ -181,6 +181,7 @@ def measure(workload="mixtral-8x7b", layers=8, steps=20, warmup=3, directory=Non
             run(block, 0, warmup)
             torch.cuda.synchronize(dev)
             timer.t.clear(), timer.n.clear()
+            eng.reset_stats()
             t0 = time.perf_counter()
             run(block, warmup, steps)
             torch.cuda.synchronize(dev)
@@ -213,6 +214,10 @@ def measure(workload="mixtral-8x7b", layers=8, steps=20, warmup=3, directory=Non
             "over_fused": round(res["dropin"] / res["fused"], 3),
             "calls_per_token": round(sum(calls[k]["calls_per_layer"] for k in boundary) * L_model, 1),
             "host_us_per_call": round(sum(calls[k]["host_us_per_layer"] for k in boundary) / max(1e-9, sum(calls[k]["calls_per_layer"] for k in boundary)), 1),
+            # who spends the drop-in path's host time: this repo's side of the boundary vs the reference's own Python around it
+            "boundary_us_per_layer": round(sum(calls[k]["host_us_per_layer"] for k in boundary), 1),
+            "reference_python_us_per_layer": round(calls["python_router_and_masks"]["host_us_per_layer"] + calls["python_combine"]["host_us_per_layer"]
+                                                   + calls["dispatch_local_total"]["host_us_per_layer"] - sum(calls[k]["host_us_per_layer"] for k in boundary), 1),
             "host_calls": calls, "hit_rate": round(st["expert_hits"] / max(1, st["expert_hits"] + st["expert_misses"]), 4),
             "parity_ok": parity_ok, "parity_is": "drop-in block output == fused block output within 2^-6 relative (first layer)",
         }

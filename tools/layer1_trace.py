@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Timeline of the one-launch decode layer (csrc/layer_fused.hip): runs a few DeepSeek-V2-Lite batch-1 forwards with
-MOEINF_LAYER1_TRACE set (the engine writes the per-workgroup timestamps of the LAST launch at destroy) and prints, per role,
+"""Timeline of the fused decode launches (csrc/layer_fused.hip: the gate + stage-1 front of the gated families, the one-launch
+Switch layer): runs a few batch-1 forwards with MOEINF_LAYER1_TRACE set (the engine writes the per-workgroup timestamps of the LAST launch at destroy) and prints, per role,
 when its workgroups started / got past their waits / finished (microseconds after the first workgroup started).
 usage: layer1_trace.py [--switch | --mixtral] [out.txt]   (--switch: Switch-base-8, the one-launch form that is its default; extra MOEINF_*
-knobs are taken from the environment; DeepSeek needs MOEINF_LAYER1=1)"""
+knobs are taken from the environment)"""
 import os, statistics, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
