@@ -975,6 +975,7 @@ def main():
     ap.add_argument("--offload-attn-us", type=float, default=270.1, help="that leg's attention stand-in per layer (profiles/r04_attention_block_time_stock_pytorch.jsonl: DeepSeek-V2-Lite batch 1, context 2048)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
     ap.add_argument("--no-fp16-legs", action="store_true", help="skip the fp16-expert legs of other_configs")
+    ap.add_argument("--dtype", default="model", choices=["model", "fp16"], help="fp16: the main leg with fp16 experts (the reference's dtype id 2) instead of the model's own dtype (profiling the fp16 kernels on their own)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the path through prefetch_op.expert_dispatcher as the reference's dispatch_local drives it, timed beside the fused path)")
     ap.add_argument("--dropin-layers", type=int, default=8, help="full-size MoE layers of the drop-in leg (its offload directory holds every expert of them: 8 Mixtral layers = 21 GiB)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic pass (two rocprofv3 --pmc child runs, ~1 min): roofline.traffic then comes from profiles/ (static)")
@@ -1015,7 +1016,12 @@ def main():
     if world > 1:
         dist.barrier()
 
-    r = run_workload(args, args.workload, args.batch, world, rank, local_rank, dev, use_ep, True, dist)
+    main_dtype = None
+    if args.dtype == "fp16":
+        from moe_infinity_amd import config as Cf_
+
+        main_dtype = Cf_.DTYPE_F16
+    r = run_workload(args, args.workload, args.batch, world, rank, local_rank, dev, use_ep, True, dist, dtype_id=main_dtype)
     # roofline.traffic measured in THIS run (the main engine is closed: its HBM and pinned memory are free for the children)
     if rank == 0 and world == 1 and not use_ep and not args.no_traffic and r.get("roof"):
         t0 = time.time()
@@ -1033,7 +1039,7 @@ def main():
         else:
             r["roof"]["traffic_live_attempt"] = note
     others = []
-    default_main = (args.workload == "mixtral-8x7b" and args.batch == 1 and not args.layers and not args.budget_gib)
+    default_main = (args.workload == "mixtral-8x7b" and args.batch == 1 and not args.layers and not args.budget_gib and args.dtype == "model")
     if world == 1 and not use_ep and default_main and not args.no_other_configs:
         for wl, b in (("deepseek-v2-lite", 1), ("nllb-moe-54b", 32), ("switch-base-8", 1)):
             try:

@@ -129,6 +129,16 @@ static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
   CHK(dmalloc(&g->d_chunk, ((T * K + 1023) / 1024 + 1) * (size_t)std::max(g->E, g->cfg.ep_size)));
   HIPCHK(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   HIPCHK(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
+  // ffn_gemm_big's split of short last passes (down projection of a long prefill): engines that can see more than 256 rows per
+  // expert, a reduction of at least 4096, and a workspace of at most 160 MB (Mixtral-8x7B: 128 slabs x 4 x 128 KB = 64 MB)
+  if (!g->d_big_ws && g->dt != DT_F32 && g->F >= 4096 && rows / (size_t)std::max(1, g->E) > 256) {
+    const size_t slabs = (size_t)((g->H + 255) / 256) * (size_t)(g->E + 1);
+    const size_t bytes = slabs * BIG_SPLIT_MAX * BIG_SPLIT_PART_FLOATS * sizeof(float);
+    if (bytes <= ((size_t)160 << 20) && hipMalloc((void**)&g->d_big_ws, bytes) == hipSuccess) {
+      if (hipMalloc((void**)&g->d_big_ctr, slabs * sizeof(int32_t)) == hipSuccess && hipMemset(g->d_big_ctr, 0, slabs * sizeof(int32_t)) == hipSuccess) g->big_ws_slabs = (int)slabs;
+      else { (void)hipGetLastError(); hipFree(g->d_big_ws); g->d_big_ws = nullptr; }
+    } else (void)hipGetLastError();
+  }
   return MOEINF_OK;
 }
 
@@ -187,6 +197,9 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (g->h_la_idx) hipHostFree(g->h_la_idx);
   if (g->h_la_w) hipHostFree(g->h_la_w);
   if (g->h_keep) hipHostFree(g->h_keep);
+  if (g->d_big_ws) hipFree(g->d_big_ws);
+  if (g->d_big_ctr) hipFree(g->d_big_ctr);
+  if (g->d_front1_perm) hipFree(g->d_front1_perm);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
@@ -858,6 +871,7 @@ void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64
     s.K = g->F; s.R = g->H; s.K_sh = g->Fs; s.R_sh = g->H;
     s.in = g->d_h; s.ld_in = g->ldh; s.row_map = nullptr; s.out = g->d_y; s.ld_out = g->H;
     if (g->ovr_out) { s.out = g->ovr_out; s.out_map = g->ovr_map; }
+    s.big_ws = g->d_big_ws; s.big_ctr = g->d_big_ctr; s.big_ws_slabs = g->big_ws_slabs;
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[2]; s.off_a_sh = bs.off[2]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_SWITCH_GATED) { s.off_a = b.off[2]; s.epi = EPI_NONE; }  // wo
@@ -1251,6 +1265,19 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
         const int nb = g->E + (sr->sh1 ? (g->Fs + 15) / 16 : 0) + 1 + g->K * ((g->F + 15) / 16) + (sr->sh2 ? (g->H + 15) / 16 : 0);
         if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
         sy.trace = g->d_layer_trace;
+      }
+      // MOEINF_FRONT1_BALANCE=1: the physical order that evens out the bytes per CU (kernels.h: front1_balanced_order)
+      static const bool f1_balance = getenv("MOEINF_FRONT1_BALANCE") ? atoi(getenv("MOEINF_FRONT1_BALANCE")) != 0 : false;
+      if (f1_balance && sr->sh1 && sr->sh2) {
+        if (!g->d_front1_perm) {
+          if (!g->num_cus) (void)hipDeviceGetAttribute(&g->num_cus, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
+          const int n_sh1 = (g->Fs + 15) / 16, n_r1 = g->K * ((g->F + 15) / 16), n_sh2 = (g->H + 15) / 16;
+          const int64_t gb = (int64_t)g->H * (sr->ra->gate_dtype == DT_F32 ? 4 : 2);
+          const std::vector<int32_t> perm = front1_balanced_order(g->E, n_sh1, n_r1, n_sh2, gb, (int64_t)2 * 16 * g->H * g->es, (int64_t)2 * 16 * g->H * g->es, (int64_t)16 * g->Fs * g->es, g->num_cus > 0 ? g->num_cus : 256);
+          if (hipMalloc((void**)&g->d_front1_perm, perm.size() * sizeof(int32_t)) != hipSuccess) { g->d_front1_perm = nullptr; (void)hipGetLastError(); }
+          else { HIPCHK(hipMemcpy(g->d_front1_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice)); g->front1_perm_n = (int)perm.size(); }
+        }
+        sy.perm = g->d_front1_perm; sy.perm_n = g->front1_perm_n;
       }
       HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
       g->layer1_launches += 1;  // only a launch that went out moves the grow-only counters' target (a failed one must not leave them out of step)

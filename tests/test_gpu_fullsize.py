@@ -317,3 +317,54 @@ def test_mixtral_8x7b_layer_skewed_routing_takes_several_passes():
         assert_block_close(out, ref, torch.bfloat16, what)
     assert_as_accurate_as_the_oracle(out, ref, "mixtral", x[None], experts, torch.bfloat16, "Mixtral-8x7B layer, skewed routing", rows=got_rows)
     eng.close()
+
+
+_SPLIT_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from helpers import acts, fill_layer_on_gpu
+from moe_infinity_amd import MoEEngine, config as Cf
+t = 2048
+cfg = Cf.mixtral_8x7b(max_tokens=t); cfg.num_layers = 1
+eng = MoEEngine(cfg)
+fill_layer_on_gpu(eng, "mixtral", 0, 1234)
+g = torch.Generator().manual_seed(4321)
+gate = (torch.randn(cfg.num_experts, cfg.hidden, generator=g) * 0.02).to(torch.bfloat16)
+x = acts(t, cfg.hidden, torch.bfloat16, 2024)
+for _ in range(2):
+    out = eng.forward(0, x.to("cuda:0"), gate.to("cuda:0"))
+counts = eng.routing()["counts"]
+torch.save({"out": out.cpu(), "counts": torch.tensor(counts)}, sys.argv[3])
+eng.close()
+'''
+
+
+def test_big_gemm_short_last_passes_are_split_over_idle_cus(tmp_path):
+    """ffn_gemm_big (round 6): when the full 256-token passes of the down projection fill their rounds exactly, the short last
+    passes (a handful of tokens each, bound by ONE CU streaming a 7.3 MB weight slab) are split along the REDUCTION over the
+    idle CUs, fp32 partial tiles added in a fixed order by the last arriver.  2 048 Mixtral tokens: 512 rows per expert on
+    average = two full passes per slab = exactly one round of 256 workgroups, every expert above 512 rows has a short third pass.
+    Same layer with MOEINF_GEMM_BIG_SPLIT=1 (no split) and the default (4): the outputs differ in a few last bits (another
+    fp32 summation order for the split passes' tokens — which shows the split path ran) and agree within two bf16 ulps; the
+    default's parity against the oracle is test_mixtral_8x7b_layer[prefill_t2048_compute_bound_gemm]."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for split in ("1", "4"):
+        path = str(tmp_path / f"split{split}.pt")
+        r = subprocess.run([sys.executable, "-c", _SPLIT_CHILD, os.path.dirname(here), here, path], env=dict(os.environ, MOEINF_GEMM_BIG_SPLIT=split),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[split] = torch.load(path)
+    counts = outs["4"]["counts"].numpy()
+    assert torch.equal(outs["1"]["counts"], outs["4"]["counts"])
+    short = [int(c) for c in counts[:8] if 512 < c <= 512 + 128]
+    assert short, f"this input is meant to leave short third passes (rows per expert: {counts[:8]})"
+    a, b = outs["1"]["out"].float(), outs["4"]["out"].float()
+    assert not torch.equal(a, b), "identical bits: the split path did not run (it changes the fp32 summation order of the short passes' tokens)"
+    tol = 2.0 ** -7 * torch.maximum(torch.maximum(a.abs(), b.abs()), a.abs().mean())
+    assert bool(((a - b).abs() <= 2 * tol).all()), float(((a - b).abs() / tol).max())
+    frac = float((a != b).float().mean())
+    assert frac < 0.05, f"{frac:.3f} of the elements differ: only the short passes' tokens may"

@@ -12,6 +12,7 @@
 #   bench2                two ranks on this one GPU over the peer-store transport (8 layers)
 #   kt:<workload>[:B]     rocprofv3 --kernel-trace --stats of a lean bench of <workload> (decode batch B)
 #   pmc:<workload>:<C>[:B] rocprofv3 --pmc <C> --kernel-trace (C = one counter set, '+'-separated) over 8 layers
+#   mfma:<workload>:<P>   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over a P-token prefill (8 layers): busy fraction + clock
 #   py:<script>[:args]    python tools/<script> with ':'-separated args, output to <script>.log
 # Every profiler / python invocation is wrapped in `timeout`; PMC passes are their own runs (kernel-trace only).
 set -u
@@ -53,6 +54,19 @@ for task in "$@"; do
           python "$R/bench.py" --workload "$a1" --batch "$b" --steps 3 --warmup 1 $LEAN --layers 8 --prompt ${GPU_RUN_PROMPT:-0} ${GPU_RUN_BENCH_FLAGS:-} > /dev/null 2> "$R/$OUT/pmc_${a2}_${tag}_b$b.err")
       python tools/pmc_kernel_means.py "$OUT/pmc_${a2}_${tag}_b$b/m_counter_collection.csv" > "$OUT/pmc_${a2}_${tag}_b$b.txt" 2>&1; head -20 "$OUT/pmc_${a2}_${tag}_b$b.txt"
       rm -f "$OUT"/pmc_*/m_kernel_trace.csv "$OUT"/pmc_*/m_counter_collection.csv ;;
+    mfma)  # mfma:<workload>:<prompt tokens>: MFMA-pipe busy cycles + GUI-active cycles (= the clock the chip held) of the prefill GEMMs
+      tag=${a1//-/}; tag=${tag//./}
+      (cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/$OUT/pmc_mfma_${tag}_p$a2" -o m -- \
+          python "$R/bench.py" --workload "$a1" --steps 2 --warmup 1 $LEAN --layers 8 --prompt "$a2" > /dev/null 2> "$R/$OUT/pmc_mfma_${tag}_p$a2.err")
+      python tools/mfma_summary.py "$OUT/pmc_mfma_${tag}_p$a2/m_counter_collection.csv" "$OUT/pmc_mfma_${tag}_p$a2/m_kernel_trace.csv" "$OUT/pmc_mfma_prefill${a2}_${tag}.json" > /dev/null 2> "$OUT/mfma_summary.err"
+      python - "$OUT/pmc_mfma_prefill${a2}_${tag}.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in d["kernels"].items():
+    if v["duration_ns"] > 50000:
+        print(k[:64], "us %.1f" % (v["duration_ns"] / 1e3), "busy %.3f" % v["mfma_busy_frac_by_gui_active"], "GHz %.2f" % (v["GRBM_GUI_ACTIVE"] / v["duration_ns"] / 8), "launches", v["launches"])
+PY
+      rm -f "$OUT"/pmc_mfma_*/m_kernel_trace.csv "$OUT"/pmc_mfma_*/m_counter_collection.csv ;;
     py)
       args=(); [ -n "${a2:-}" ] && IFS=',' read -r -a args <<< "$a2"
       timeout ${GPU_RUN_PY_TIMEOUT:-900} python "tools/$a1" "${args[@]}" > "$OUT/${a1%.py}.log" 2>&1; echo "$a1 exit $?"; tail -${GPU_RUN_TAIL:-30} "$OUT/${a1%.py}.log" ;;
