@@ -55,7 +55,8 @@ enum {
   MOEINF_ROUTER_MIXTRAL = 0,  /* moe_infinity/models/mixtral.py:46-54 */
   MOEINF_ROUTER_DEEPSEEK = 1, /* models/modeling_deepseek/modeling_deepseek.py:463-512 (MoEGate) */
   MOEINF_ROUTER_SWITCH = 2,   /* HF SwitchTransformersTop1Router @ models/switch_transformers.py:76 */
-  MOEINF_ROUTER_NLLB = 3      /* HF NllbMoeTop2Router @ models/nllb_moe.py:53 */
+  MOEINF_ROUTER_NLLB = 3,     /* HF NllbMoeTop2Router @ models/nllb_moe.py:53 */
+  MOEINF_ROUTER_SOFTMAX_TOPK = 4 /* Grok / Arctic: softmax -> top-k, NO renormalisation (models/grok.py:38-45, arctic.py:39-45); otherwise Mixtral's */
 };
 
 /* cache replacement policy. LFU-in-cache is what the reference actually runs

@@ -87,6 +87,32 @@ class SyncMixtralSparseMoeBlock(_MoeBlockBase):
                                router_kind=Cf.ROUTER_MIXTRAL, **kw)
 
 
+class SyncGrokMoeBlock(_MoeBlockBase):
+    """moe_infinity/models/grok.py:12-130 (constructor signature (hidden_dim, ffn_dim, num_experts, top_k), :16-18): softmax ->
+    top-k WITHOUT renormalisation (:38-45), dispatch, Mixtral's combine (:80-86) — the one block of the reference whose
+    predictor / prefetcher calls are live (:60-68; here: _MoeBlockBase._run).  The experts are registered in the reference's blob
+    order (named_parameters of MoeMLP: linear_v, linear_1, linear) and run as expert type 4, which is what the reference's core
+    does for this architecture (moe_infinity/common/constants.py:33; core/parallel/expert_module.cpp:147-175)."""
+
+    def __init__(self, hidden_dim: int, ffn_dim: int, num_experts: int, top_k: int):
+        super().__init__()
+        self.hidden_dim, self.ffn_dim, self.num_experts, self.top_k = hidden_dim, ffn_dim, num_experts, top_k
+        self.gate = nn.Linear(self.hidden_dim, self.num_experts, bias=False)
+
+    def _gate_weight(self):
+        return self.gate.weight
+
+    def forward(self, hidden_states: torch.Tensor):
+        final = self._run(hidden_states)
+        router_logits, _, _ = self.engine.routing_tensors(logits=True)
+        return final, router_logits.to(hidden_states.dtype)
+
+    @staticmethod
+    def engine_config(hidden_dim, ffn_dim, num_experts, top_k, num_layers, **kw) -> Cf.EngineConfig:
+        return Cf.EngineConfig(num_layers=num_layers, num_experts=num_experts, expert_type=Cf.EXPERT_MIXTRAL, hidden=hidden_dim,
+                               inter=ffn_dim, top_k=top_k, router_kind=Cf.ROUTER_SOFTMAX_TOPK, **kw)
+
+
 class DeepseekMoEBlock(_MoeBlockBase):
     def __init__(self, config):
         super().__init__()

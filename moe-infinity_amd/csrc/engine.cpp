@@ -91,7 +91,7 @@ static int validate(const moeinf_config* c) {
   if (c->hidden <= 0 || c->inter <= 0 || c->hidden % ev || c->inter % ev) return fail(MOEINF_ERR_INVALID, "hidden/inter must be positive multiples of %d", ev);
   if (c->shared_inter < 0 || c->shared_inter % ev) return fail(MOEINF_ERR_INVALID, "shared_inter must be a multiple of %d", ev);
   if (c->top_k <= 0 || c->top_k > 8 || c->top_k > c->num_experts) return fail(MOEINF_ERR_INVALID, "top_k must be in 1..min(8,E)");
-  if (c->router_kind < 0 || c->router_kind > 3) return fail(MOEINF_ERR_INVALID, "router_kind");
+  if (c->router_kind < 0 || c->router_kind > MOEINF_ROUTER_SOFTMAX_TOPK) return fail(MOEINF_ERR_INVALID, "router_kind");
   if (c->router_kind == MOEINF_ROUTER_SWITCH && c->top_k != 1) return fail(MOEINF_ERR_INVALID, "switch router is top-1");
   if (c->router_kind == MOEINF_ROUTER_NLLB && c->top_k != 2) return fail(MOEINF_ERR_INVALID, "nllb router is top-2");
   if (c->router_kind == MOEINF_ROUTER_DEEPSEEK && c->n_group > 1) {
@@ -129,16 +129,6 @@ static int alloc_token_workspace(moeinf_engine* g, int max_tokens) {
   CHK(dmalloc(&g->d_chunk, ((T * K + 1023) / 1024 + 1) * (size_t)std::max(g->E, g->cfg.ep_size)));
   HIPCHK(hipMalloc(&g->d_h, rows * (size_t)g->ldh * g->es));
   HIPCHK(hipMalloc(&g->d_y, rows * (size_t)g->H * g->es));
-  // ffn_gemm_big's split of short last passes (down projection of a long prefill): engines that can see more than 256 rows per
-  // expert, a reduction of at least 4096, and a workspace of at most 160 MB (Mixtral-8x7B: 128 slabs x 4 x 128 KB = 64 MB)
-  if (!g->d_big_ws && g->dt != DT_F32 && g->F >= 4096 && rows / (size_t)std::max(1, g->E) > 256) {
-    const size_t slabs = (size_t)((g->H + 255) / 256) * (size_t)(g->E + 1);
-    const size_t bytes = slabs * BIG_SPLIT_MAX * BIG_SPLIT_PART_FLOATS * sizeof(float);
-    if (bytes <= ((size_t)160 << 20) && hipMalloc((void**)&g->d_big_ws, bytes) == hipSuccess) {
-      if (hipMalloc((void**)&g->d_big_ctr, slabs * sizeof(int32_t)) == hipSuccess && hipMemset(g->d_big_ctr, 0, slabs * sizeof(int32_t)) == hipSuccess) g->big_ws_slabs = (int)slabs;
-      else { (void)hipGetLastError(); hipFree(g->d_big_ws); g->d_big_ws = nullptr; }
-    } else (void)hipGetLastError();
-  }
   return MOEINF_OK;
 }
 
@@ -197,9 +187,6 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (g->h_la_idx) hipHostFree(g->h_la_idx);
   if (g->h_la_w) hipHostFree(g->h_la_w);
   if (g->h_keep) hipHostFree(g->h_keep);
-  if (g->d_big_ws) hipFree(g->d_big_ws);
-  if (g->d_big_ctr) hipFree(g->d_big_ctr);
-  if (g->d_front1_perm) hipFree(g->d_front1_perm);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
@@ -235,6 +222,10 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   DeviceScope on_dev_(cfg->device_id); HIPCHK(on_dev_.err);
   moeinf_engine* g = new moeinf_engine();
   g->cfg = *cfg;
+  // Grok / Arctic (moe_infinity/models/grok.py:38-45): Mixtral's router without the renormalisation.  Everything else about the
+  // kind — bf16 gate logits, selection, dispatch, combine, which kernels run — is Mixtral's: the engine keeps ONE kind for it
+  // and a flag for the weights.
+  if (g->cfg.router_kind == MOEINF_ROUTER_SOFTMAX_TOPK) { g->route_no_renorm = true; g->cfg.router_kind = MOEINF_ROUTER_MIXTRAL; }
   memset(&g->st, 0, sizeof g->st);
   memset(&g->prof, 0, sizeof g->prof);
   memset(&g->ep_prof, 0, sizeof g->ep_prof);
@@ -871,7 +862,6 @@ void fill_stage(const moeinf_engine* g, int layer, int stage, FfnStage& s, int64
     s.K = g->F; s.R = g->H; s.K_sh = g->Fs; s.R_sh = g->H;
     s.in = g->d_h; s.ld_in = g->ldh; s.row_map = nullptr; s.out = g->d_y; s.ld_out = g->H;
     if (g->ovr_out) { s.out = g->ovr_out; s.out_map = g->ovr_map; }
-    s.big_ws = g->d_big_ws; s.big_ctr = g->d_big_ctr; s.big_ws_slabs = g->big_ws_slabs;
     if (et == MOEINF_EXPERT_MIXTRAL) { s.off_a = b.off[1]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_DEEPSEEK) { s.off_a = b.off[2]; s.off_a_sh = bs.off[2]; s.epi = EPI_NONE; }
     else if (et == MOEINF_EXPERT_SWITCH_GATED) { s.off_a = b.off[2]; s.epi = EPI_NONE; }  // wo
@@ -1266,19 +1256,7 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
         if (!g->d_layer_trace) { if (hipMalloc((void**)&g->d_layer_trace, (size_t)nb * 32) != hipSuccess) g->d_layer_trace = nullptr; else (void)hipMemset(g->d_layer_trace, 0, (size_t)nb * 32); g->layer1_trace_blocks = nb; }
         sy.trace = g->d_layer_trace;
       }
-      // MOEINF_FRONT1_BALANCE=1: the physical order that evens out the bytes per CU (kernels.h: front1_balanced_order)
-      static const bool f1_balance = getenv("MOEINF_FRONT1_BALANCE") ? atoi(getenv("MOEINF_FRONT1_BALANCE")) != 0 : false;
-      if (f1_balance && sr->sh1 && sr->sh2) {
-        if (!g->d_front1_perm) {
-          if (!g->num_cus) (void)hipDeviceGetAttribute(&g->num_cus, hipDeviceAttributeMultiprocessorCount, g->cfg.device_id);
-          const int n_sh1 = (g->Fs + 15) / 16, n_r1 = g->K * ((g->F + 15) / 16), n_sh2 = (g->H + 15) / 16;
-          const int64_t gb = (int64_t)g->H * (sr->ra->gate_dtype == DT_F32 ? 4 : 2);
-          const std::vector<int32_t> perm = front1_balanced_order(g->E, n_sh1, n_r1, n_sh2, gb, (int64_t)2 * 16 * g->H * g->es, (int64_t)2 * 16 * g->H * g->es, (int64_t)16 * g->Fs * g->es, g->num_cus > 0 ? g->num_cus : 256);
-          if (hipMalloc((void**)&g->d_front1_perm, perm.size() * sizeof(int32_t)) != hipSuccess) { g->d_front1_perm = nullptr; (void)hipGetLastError(); }
-          else { HIPCHK(hipMemcpy(g->d_front1_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice)); g->front1_perm_n = (int)perm.size(); }
-        }
-        sy.perm = g->d_front1_perm; sy.perm_n = g->front1_perm_n;
-      }
+      // (a physical workgroup order that evens out the bytes per CU was measured in round 6: slower, profiles/r06_deepseek_front1_balanced_order_rejected.txt)
       HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
       g->layer1_launches += 1;  // only a launch that went out moves the grow-only counters' target (a failed one must not leave them out of step)
     } else if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
@@ -1334,6 +1312,7 @@ void make_route_args(const moeinf_engine* g, const void* x_dev, const void* gate
   ra.T = T; ra.H = g->H; ra.E = g->E; ra.K = g->K;
   ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : (g->cfg.gate_dtype == MOEINF_DTYPE_F16 ? DT_F16 : DT_F32);
   ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
+  ra.no_renorm = g->route_no_renorm ? 1 : 0;
   ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
   ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
   ra.router_prob = g->d_router_prob;

@@ -219,11 +219,7 @@ struct moeinf_engine {
   std::vector<int> la_list;            // node indices predicted for the next layer, best first
   int num_cus = 0;                     // of THIS engine's device
   int layer1_switch_wgs_per_cu = -1;   // occupancy of the one-launch Switch kernel (asked once per engine)
-  float* d_big_ws = nullptr;           // ffn_gemm_big: split short last passes (FfnStage::big_ws)
-  int32_t* d_big_ctr = nullptr;
-  int big_ws_slabs = 0;
-  int32_t* d_front1_perm = nullptr;    // balanced physical order of the front launch (kernels.h: front1_balanced_order)
-  int front1_perm_n = 0;
+  bool route_no_renorm = false;        // MOEINF_ROUTER_SOFTMAX_TOPK (Grok / Arctic): cfg.router_kind is stored as MIXTRAL
   uint8_t* h_keep = nullptr;           // moeinf_dispatch_mask_subset: pinned byte per expert
   hipEvent_t busy_mark = nullptr;  // stop event of the latest-ending copy interval accounted so far (union of the lanes' busy time)
   int64_t slot_bytes = 0;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void big_read_frags(u32x4 (&af)[2][NMAT][RT], u32x4 (
 // from HBM/MALL and need the longer lead; activations mostly hit in L2).  Past the end the issues are clamped re-reads
 // into slots that are already consumed, so the count never varies.
 template <typename T, int NMAT, bool RING3, int MODE>  // T: uint16_t = bf16, half_t = fp16 (the same tiles, the f16 matrix instruction)
-__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map, int tail_max, int chunk, int split_max, int num_cus) {
+__global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, int ny, int nz, int xcd_map, int tail_max, int chunk, int move_short, int num_cus) {
   constexpr int EPT = 32, EPV = 8;
   constexpr int RGB = 16 / NMAT;   // row groups (16 rows) of EACH matrix per block
   constexpr int RT = 4 / NMAT;     // 32-row tiles of each matrix per wave
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
   // 1-D grid, XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule; a wrong guess costs speed, never
   // correctness).  The token passes of ONE weight slab (row block bx of expert slot u, g = u * nx + bx) get ids 8 apart —
   // the same XCD, dispatched together — so the slab streams from HBM once and the other passes hit it in that XCD's L2.
-  int pass0, g, part = 0;
+  int pass0, g;
   if (xcd_map) {
     // Slabs are dealt to the XCDs (= id % 8) in CHUNKS of `chunk` (4) consecutive slabs in (expert, row block) order, so
     // the ~32 workgroups an XCD runs at a time are a few slabs x (nz - 1) passes of ONE expert: they stream those weight slabs
@@ -85,12 +85,14 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
     if ((int)blockIdx.x < nfull) {
       const int tq = blockIdx.x >> 3;
       xcd = blockIdx.x & 7; pass0 = tq % (nz - 1); loc = tq / (nz - 1);
-    } else {
-      // ... and with split_max > 1 the ragged region is there split_max times over: copy `part` of a slab's last pass computes
-      // the part-th share of the REDUCTION when the short passes are split (below); copies that are not needed leave at once
-      int idb = (int)blockIdx.x - nfull;
-      part = idb / (per * 8); idb -= part * (per * 8);
+    } else if ((int)blockIdx.x < nfull + per * 8) {
+      const int idb = (int)blockIdx.x - nfull;
       xcd = idb & 7; pass0 = nz - 1; loc = idb >> 3;
+    } else {
+      // SHORT region (round 6; move_short >= 1): the very end of the grid, one workgroup per slab, for a slab's SHORT last pass
+      // when it is moved behind the full passes (below)
+      const int idb = (int)blockIdx.x - nfull - per * 8;
+      xcd = idb & 7; pass0 = -1; loc = idb >> 3;  // (the pass index comes from the device-side count)
     }
     g = ((loc / chunk) * 8 + xcd) * chunk + loc % chunk;
   } else {  // MOEINF_GEMM_BIG_XCD=0 (A/B): passes adjacent in id, i.e. spread over the XCDs
@@ -118,42 +120,45 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
   const int wm = wave >> 2, wn = wave & 3;
   const int KB = K / EPT;  // K % 64 == 0 (checked by the launcher)
   const int KS = KB / KK;
-  // SPLIT SHORT LAST PASSES (round 6).  A short last pass (up to tail_max tokens) is bound by ONE CU streaming the slab's
-  // whole reduction (Mixtral's down projection: 7.3 MB at ~30 GB/s per CU = 240 us for a handful of tokens); when the full
-  // passes fill their rounds exactly, those passes are a round of their own with three quarters of the chip idle (4 096
-  // Mixtral tokens: a quarter of the down projection's time, profiles/r05_big_gemm_ragged_token_counts_diag.txt).  Every
-  // workgroup of the ragged region derives the SAME split factor from the device-side counts: S = idle CUs of the last
-  // round of full passes / number of short passes (1: no split — e.g. when the short passes fit beside a partial round of
-  // full ones, where splitting only added work: the round-5 experiment that split unconditionally lost 17 % at 3 072 tokens).
-  // Copy `part` < S streams its share of the reduction, leaves fp32 partial tiles in the workspace, and the LAST arriver of
-  // a slab adds them in part order (a fixed order: the result does not depend on who is last) and runs the epilogue.
-  int S = 1;
-  if (NMAT == 1 && split_max > 1 && pass0 == nz - 1 && xcd_map && s.big_ws && g < s.big_ws_slabs && !sh) {
-    const int nact = s.n_active_host >= 0 ? s.n_active_host : *s.n_active;
-    int n_full = 0, n_short = 0;
-    for (int u0 = 0; u0 < nact; u0 += 64) {  // every wave computes it (64 experts per step): no LDS, no barrier
-      const int uu = u0 + lane;
-      int f = 0, sp = 0;
-      if (uu < nact) {
-        const int ee = s.active[uu];
-        const int c = s.counts[ee];
-        const int pe = (c + 255) >> 8;
-        const int nxe = (((ee == s.E ? s.R_sh : s.R) + 15) / 16 + RGB - 1) / RGB;
-        f = nxe * min(pe, nz - 1);
-        if (pe == nz) { if (c - (nz - 1) * 256 <= tail_max) sp = nxe; else f += nxe; }
-        else if (pe > nz) f += nxe * (pe - (nz - 1));
-      }
+  // SHORT LAST PASSES BEHIND THE FULL ONES, WHEN THAT PAYS (round 6).  A short last pass (up to tail_max tokens) IN ITS SLOT runs
+  // beside its slab's full passes on the same XCD and rides their weight stream through L2 — cheap.  But when the full passes are
+  // two or more EXACT rounds of the chip (4 096 Mixtral tokens: 512 = 2 x 256), the short passes scattered between them open a
+  // third round for everybody; then — and only then — they are run from the SHORT region at the end of the grid (longest jobs
+  // first): down projection 1 004 -> 960 us at 4 096 tokens, 780 -> 753 at 3 840, 1 015 -> 992 at 4 224.  Unconditionally
+  // moved they lose 5-60 % at 1 536 / 2 048 / 3 072 tokens (alone at the end a short pass streams its slab again, latency-bound),
+  // and SPLITTING their reduction over idle CUs (fp32 partials, last arriver adds) never beat moving them: both measured,
+  // profiles/r06_big_gemm_short_passes_moved_and_split_ab.txt.  Every workgroup concerned derives the same decision from the
+  // device-side counts.
+  const bool can_move = NMAT == 1 && move_short >= 1 && xcd_map && !sh;
+  const int pe_own = (cnt + 255) >> 8;
+  const bool short_last = can_move && pe_own >= 1 && pe_own <= nz && cnt - (pe_own - 1) * 256 <= tail_max;
+  if (pass0 < 0 || (short_last && pass0 == pe_own - 1)) {
+    if (!short_last) return;  // (SHORT region: nothing to run for this slab)
+    bool moved = move_short >= 2;  // (2: always, A/B)
+    if (!moved) {
+      const int nact = s.n_active_host >= 0 ? s.n_active_host : *s.n_active;
+      int n_full = 0;
+      for (int u0 = 0; u0 < nact; u0 += 64) {  // every wave computes it (64 experts per step): no LDS, no barrier
+        const int uu = u0 + lane;
+        int f = 0;
+        if (uu < nact) {
+          const int ee = s.active[uu];
+          const int c = s.counts[ee];
+          const int pe = (c + 255) >> 8;
+          const int nxe = (((ee == s.E ? s.R_sh : s.R) + 15) / 16 + RGB - 1) / RGB;
+          const bool shrt = ee != s.E && pe >= 1 && pe <= nz && c - (pe - 1) * 256 <= tail_max;
+          f = nxe * (pe - (shrt ? 1 : 0));
+        }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o); sp += __shfl_xor(sp, o); }
-      n_full += f; n_short += sp;
+        for (int o = 32; o > 0; o >>= 1) f += __shfl_xor(f, o);
+        n_full += f;
+      }
+      moved = n_full >= 2 * num_cus && n_full % num_cus == 0;
     }
-    const int rem = n_full % num_cus;
-    const int idle = rem ? num_cus - rem : num_cus;
-    if (n_short > 0) S = max(1, min(split_max, idle / n_short));
-    if (((cnt + 255) >> 8) != nz || cnt - (nz - 1) * 256 > tail_max) S = 1;  // this slab's last pass is not a short one (or loops): never split
-    S = __builtin_amdgcn_readfirstlane(S);  // uniform: a scalar register, not one per lane across the main loop
+    if ((pass0 < 0) != moved) return;  // the slot's workgroup runs it in place, or the SHORT region's does — never both
+    pass0 = pe_own - 1;
   }
-  if (part >= S) return;
+
   const size_t rg_stride = (size_t)KB * 1024;
   const char* wbase[NMAT];
   wbase[0] = W + (sh ? s.off_a_sh : s.off_a);
@@ -249,14 +254,13 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
         for (int i = 0; i < 2; ++i)
           __builtin_amdgcn_global_load_lds((gptr_t)(xrp[i] + (size_t)ks * KK * EPT), (lptr_t)(base + ABYTES + (wave + 8 * i) * 1024), 16, 0, 0);
       };
-      const int ks0 = S > 1 ? (int)((long long)KS * part / S) : 0, ks1 = S > 1 ? (int)((long long)KS * (part + 1) / S) : KS;  // this copy's share of the reduction
-      issue_t(ks0, 0);
-      issue_t(min(ks0 + 1, ks1 - 1), 1);
-      for (int ks = ks0; ks < ks1; ++ks) {
+      issue_t(0, 0);
+      issue_t(min(1, KS - 1), 1);
+      for (int ks = 0; ks < KS; ++ks) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage ks landed (this wave's share); stage ks+1 may be in flight
         __builtin_amdgcn_s_barrier();                      // ... everybody's; stage ks-1 is consumed
-        issue_t(min(ks + 2, ks1 - 1), (ks - ks0 + 2) % 3);  // past the end: clamped re-reads into a consumed slot, the count stays fixed
-        const char* ab = smem + ((ks - ks0) % 3) * TSTAGE;
+        issue_t(min(ks + 2, KS - 1), (ks + 2) % 3);        // past the end: clamped re-reads into a consumed slot, the count stays fixed
+        const char* ab = smem + (ks % 3) * TSTAGE;
         const char* bb = ab + ABYTES + b_off_t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -435,41 +439,6 @@ __global__ __launch_bounds__(512) void ffn_gemm_big_kernel(FfnStage s, int nx, i
     }
     }
     if (RING3 || tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped issues past the last stage
-    if (S > 1) {  // (block-uniform; only short passes of the plain stage get here with S > 1)
-      float* wsb = s.big_ws + ((size_t)g * BIG_SPLIT_MAX) * BIG_SPLIT_PART_FLOATS + ((size_t)wave * 4 * 64 + lane) * 16;
-      float* mine = wsb + (size_t)part * BIG_SPLIT_PART_FLOATS;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < nct) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(mine + (size_t)c * 64 * 16 + q * 4) = make_float4(acc[0][c >> 1][c & 1][q * 4], acc[0][c >> 1][c & 1][q * 4 + 1], acc[0][c >> 1][c & 1][q * 4 + 2], acc[0][c >> 1][c & 1][q * 4 + 3]);
-        }
-      __threadfence();  // the partial tiles are visible device-wide before the arrival
-      __syncthreads();
-      int* sh_last = reinterpret_cast<int*>(smem);  // (the fragment images are dead: every wave passed the barrier above)
-      if (threadIdx.x == 0) *sh_last = __hip_atomic_fetch_add(&s.big_ctr[g], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
-      __syncthreads();
-      const bool last = *sh_last != 0;
-      __syncthreads();  // (the epilogue below overwrites smem)
-      if (!last) return;  // (a split pass is the only pass of its workgroup: pe == nz)
-      __threadfence();
-      if (threadIdx.x == 0) s.big_ctr[g] = 0;  // zero between launches
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < nct) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[0][c >> 1][c & 1][i] = 0.f;
-          for (int pp = 0; pp < S; ++pp) {  // part order: the sum does not depend on which copy arrived last
-            const float* src = wsb + (size_t)pp * BIG_SPLIT_PART_FLOATS + (size_t)c * 64 * 16;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 v = *reinterpret_cast<const float4*>(src + q * 4);
-              acc[0][c >> 1][c & 1][q * 4] += v.x; acc[0][c >> 1][c & 1][q * 4 + 1] += v.y; acc[0][c >> 1][c & 1][q * 4 + 2] += v.z; acc[0][c >> 1][c & 1][q * 4 + 3] += v.w;
-            }
-          }
-        }
-    }
     // epilogue: the output tile goes through the (now idle) LDS so that the global stores are whole rows.  Straight from
     // the accumulators a lane owns 4 consecutive rows of ONE token — every store instruction touches 32 token rows with
     // 16 bytes each, 4 096 partial-line writes per workgroup: 17 us of a 86-us workgroup (ablation: 1 532 -> 1 254 us for
@@ -599,21 +568,22 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   const int nx = (rmax + 255 / nmat) / (256 / nmat), ny = (int)grid.y, nz = passes > 8 ? 8 : passes;
   static const int chunk_env = env_int("MOEINF_GEMM_BIG_CHUNK", 4);
   const int chunk = chunk_env < 1 ? 1 : chunk_env;
-  // split of short last passes (plain stage, long reduction, workspace present): the ragged region of the grid BIG_SPLIT_MAX times over
-  static const int split_env = env_int("MOEINF_GEMM_BIG_SPLIT", BIG_SPLIT_MAX);
+  // short last passes of the plain stage with a long reduction run from the END of the grid when the full passes are two or more
+  // exact rounds (kernel: SHORT region).  MOEINF_GEMM_BIG_MOVE: 0 = never (the round-5 form), 1 = by that rule (default), 2 = always
+  static const int move_env = env_int("MOEINF_GEMM_BIG_MOVE", 1);
   static int num_cus = 0;
   if (!num_cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cus <= 0) num_cus = 256; }
-  const int split_max = (nmat == 1 && s.big_ws && s.K >= 4096 && nx * ny <= s.big_ws_slabs) ? std::max(1, std::min(BIG_SPLIT_MAX, split_env)) : 1;
+  const int move_short = (nmat == 1 && s.K >= 4096) ? std::max(0, std::min(2, move_env)) : 0;
   const int per8 = chunk * (((nx * ny + chunk - 1) / chunk + 7) / 8) * 8;
-  const dim3 g((unsigned)(per8 * (nz - 1 + split_max)));
+  const dim3 g((unsigned)(per8 * (nz + (move_short ? 1 : 0))));
   static const int xcd_map = env_int("MOEINF_GEMM_BIG_XCD", 1);
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
   static const int tail_max = env_int("MOEINF_GEMM_BIG_TAIL", 128);  // tokens up to which a last pass runs the short-pass variant (0: never)
   static const int mode = env_int("MOEINF_GEMM_BIG_MODE", 2);  // 2: ping-pong (the two waves of a SIMD alternate load / compute slots), 1: both in step
-#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<uint16_t, NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, split_max, num_cus)
+#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<uint16_t, NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus)
   if (s.dtype == DT_F16) {  // fp16 experts: the default schedule only (three-deep weight ring, ping-pong)
-    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 2, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, split_max, num_cus);
-    else hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 1, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, split_max, num_cus);
+    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 2, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
+    else hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 1, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
     return true;
   }
   if (ring3) {

@@ -880,6 +880,7 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
   if (a.kind == 0) {
     float den = 0.f;
     for (int k = 0; k < K; ++k) den += val[k];
+    if (a.no_renorm) den = 1.f;  // Grok / Arctic: the softmax probabilities themselves, cast to the model dtype (x / 1.0f is exact)
     for (int k = 0; k < K; ++k) w[k] = round_model(xdt, val[k] / den);
   } else if (a.kind == 1) {
     if (K > 1 && a.norm_topk_prob) {

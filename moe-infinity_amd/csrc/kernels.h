@@ -115,14 +115,8 @@ struct FfnStage {
   // upper bound of the row index the stage reads from `in` (engine: max_tokens * (K + 1)); 0 = unknown.  ffn_gemm_ring2 keeps
   // element offsets into `in` in 32 bits: its launchers decline a stage whose rows_bound * ld_in does not fit (round-4 advice)
   int64_t rows_bound;
-  // ffn_gemm_big, plain stage with a long reduction: workspace for splitting the REDUCTION of short last passes over the CUs a
-  // partial last round leaves idle (fp32 partial tiles + one arrival counter per weight slab; engine: alloc_token_workspace)
-  float* big_ws;           // [big_ws_slabs][BIG_SPLIT_MAX][8 waves][4 tiles][64 lanes][16] fp32, or nullptr
-  int32_t* big_ctr;        // [big_ws_slabs], zero between launches (the last arriver resets its own)
-  int big_ws_slabs;
 };
-constexpr int BIG_SPLIT_MAX = 4;
-constexpr size_t BIG_SPLIT_PART_FLOATS = (size_t)8 * 4 * 64 * 16;  // one workgroup's short-pass accumulators
+
 // ---- which form of ffn_gemm_ring2 a stage takes: pure host logic, shared by the launchers (ffn_gemm.hip) and the introspection
 // export moeinf_ffn_ring2_form (engine.cpp), which tests/test_kernel_selection_cpu.py pins against DESIGN.md section 4.3.
 // (Round 4: the launcher once asked for max_rows <= 192 where the sync-free path's estimate is 193 — the kernel silently never
@@ -204,6 +198,7 @@ struct RouteArgs {
   int32_t* pair_valid;  // [T,K]
   int32_t* pair_order;  // [T,K] k-indices sorted by ascending expert id
   float* router_prob;   // [T] (Switch: max prob)
+  int no_renorm;        // kind MIXTRAL only: 1 = the top-k probabilities are NOT renormalised (Grok / Arctic, grok.py:38-45)
 };
 hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st);
 hipError_t launch_route_topk(const RouteArgs& a, hipStream_t st);
@@ -270,19 +265,9 @@ struct LayerSync {
   int sleep;                  // s_sleep(2) repetitions between two polls
   int scalar_poll;            // 1: the counters are polled with scalar loads (they live in uncached memory); 0: agent-scope vector loads
   float* part;                // Switch form: [4][H] fp32 partial sums of the split stage-2 reduction
-  const int32_t* perm;        // front launch: physical workgroup id -> logical id (role order), -1 = filler that leaves at once; nullptr: identity
-  int perm_n;                 // entries of perm = the grid of the balanced form
 };
 // the FRONT of a batch-1 layer of the gated families in one launch: gate | (shared stage 1) | meta | self-routing stage 1 |
 // (shared stage 2); stage 2 + combine stay launch_ffn2_decode1.  sh1 / sh2: the hidden shared expert's stages or nullptr.
-// Physical order of the front launch's workgroups that evens out the BYTES each CU streams (round 6).  All workgroups of the launch
-// are resident at once and the dispatcher deals consecutive ids round-robin (id % 8 -> XCD, then CU by CU), so in role order some
-// CUs end up with three 131-KB items plus a 90-KB one (483 KB) while the average is 405 KB — and the launch ends when the fullest CU
-// does (profiles/r05_front1_timeline_deepseekv2lite.txt: items end between 11.8 and 20.5 us).  Items are dealt to 8 x 32 bins
-// (one per CU) longest first within the dependency order gate | shared stage 1 | meta | routed stage 1 | shared stage 2, and
-// row r of bin c gets physical id r * 256 + c (fillers where a bin has no r-th item); every dependency still has a smaller
-// physical id than its consumer.  Returns the table (logical ids / -1); pure host logic.
-std::vector<int32_t> front1_balanced_order(int E, int n_sh1, int n_r1, int n_sh2, int64_t gate_bytes, int64_t sh1_bytes, int64_t r1_bytes, int64_t sh2_bytes, int bins);
 hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnStage* sh1, const FfnStage* sh2, const FfnStage& s1, const LayerSync& sy, hipStream_t st);
 // the Switch form (top-1, plain experts, no shared expert): E + 1 + F/16 + 4 * H/16 workgroups of eight waves, all resident at once;
 // false: not handled (the caller runs the three launches)

@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void moe_
   const int lane = threadIdx.x & 63;
   const int K = r.K, E = r.E;
   const int n_rg = (s1.R + 15) / 16;
-  int b = sy.perm ? sy.perm[blockIdx.x] : (int)blockIdx.x;  // (balanced form: physical id -> logical id)
-  if (b < 0) return;                                        // filler
+  int b = blockIdx.x;
   const int tslot = (int)blockIdx.x * 4;
   layer_trace(sy, tslot + 0);
   if (b < E) {  // ---- gate
@@ -204,31 +203,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void moe_
   }
 }
 
-std::vector<int32_t> front1_balanced_order(int E, int n_sh1, int n_r1, int n_sh2, int64_t gate_bytes, int64_t sh1_bytes, int64_t r1_bytes, int64_t sh2_bytes, int bins) {
-  struct Cls { int first, n; int64_t bytes; };
-  const Cls cls[] = {{0, E, gate_bytes}, {E, n_sh1, sh1_bytes}, {E + n_sh1, 1, 1024}, {E + n_sh1 + 1, n_r1, r1_bytes}, {E + n_sh1 + 1 + n_r1, n_sh2, sh2_bytes}};
-  std::vector<std::vector<int32_t>> bin(bins);
-  std::vector<int64_t> load(bins, 0);
-  for (const Cls& c : cls)
-    for (int i = 0; i < c.n; ++i) {
-      int best = 0;
-      for (int j = 1; j < bins; ++j) if (load[j] < load[best]) best = j;  // ties: the lowest bin
-      bin[best].push_back(c.first + i);
-      load[best] += c.bytes;
-    }
-  size_t rows = 0;
-  for (auto& b : bin) rows = std::max(rows, b.size());
-  std::vector<int32_t> perm(rows * (size_t)bins, -1);
-  for (int c = 0; c < bins; ++c)
-    for (size_t r = 0; r < bin[c].size(); ++r) perm[r * bins + c] = bin[c][r];
-  return perm;
-}
-
 // bf16 / fp16 model with the gate in the model dtype or fp32; sh1 / sh2 = the hidden shared expert's stages or nullptr
 hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnStage* sh1, const FfnStage* sh2, const FfnStage& s1, const LayerSync& sy, hipStream_t st) {
   const int n_rg = (s1.R + 15) / 16;
   const int n_sh1 = sh1 ? (sh1->R_sh + 15) / 16 : 0, n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
-  const dim3 grid(sy.perm ? (unsigned)sy.perm_n : (unsigned)(r.E + n_sh1 + 1 + r.K * n_rg + n_sh2));
+  const dim3 grid(r.E + n_sh1 + 1 + r.K * n_rg + n_sh2);
   // (as launch_ffn1_selfroute: a multi-round grid streams best with FOUR workgroups per CU, capped through dynamic LDS, and
   // four tiles per wave, matrix and batch; a grid that is resident all at once takes eight)
   static const int lds_env = env_int("MOEINF_SR_LDS_KB", -1);

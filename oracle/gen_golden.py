@@ -83,7 +83,7 @@ def import_reference():
 
     mm.MixtralBlockSparseTop2MLP = MixtralBlockSparseTop2MLP
     mods = {}
-    for n in ("mixtral", "deepseek", "switch_transformers", "nllb_moe"):
+    for n in ("mixtral", "deepseek", "switch_transformers", "nllb_moe", "grok"):
         mods[n] = importlib.import_module(f"moe_infinity.models.{n}")
     mods["executor"] = importlib.import_module("moe_infinity.distributed.expert_executor")
     return mods
@@ -162,6 +162,55 @@ def gen_mixtral(mods, name, b, s, h, f, e, k, seed, dtype=torch.bfloat16):
         rw, sel = torch.topk(rw, k, dim=-1)
         rw = (rw / rw.sum(-1, keepdim=True)).to(dtype)
     np.savez_compressed(os.path.join(OUT, name), x=npf(x), out=npf(out), logits=npf(logits), topk_idx=npf(sel),
+                        topk_w=npf(rw), meta=np.array([b, s, h, f, e, k, seed]), wsum=checksum(gate, experts))
+    print(name, "ok", out.float().abs().mean().item())
+
+
+def gen_grok(mods, name, b, s, h, f, e, k, seed, dtype=torch.bfloat16):
+    """SyncGrokMoeBlock.forward (moe_infinity/models/grok.py:34-95): its router (no renormalisation), its dispatch_local call and
+    its combine loop are the reference's own code; the expert FFN behind the dispatcher is what the reference's CORE runs for this
+    architecture — expert type 4 (common/constants.py:33) over the blob in named_parameters order (linear_v, linear_1, linear),
+    i.e. MixtralExpert's silu(x W0^T) * (x W2^T) W1^T (core/parallel/expert_module.cpp:147-175).  The predictor / prefetcher the
+    block calls every forward are the reference's own classes over a recording handle (their output does not enter the block's
+    result)."""
+    import torch.nn.functional as Fn
+
+    blk = mods["grok"].SyncGrokMoeBlock(h, f, e, k).to(dtype)
+    gate, experts, _ = make_weights("mixtral", h, f, e, seed, dtype)  # (w1 [F,H], w2 [H,F], w3 [F,H]) = blob tensors 0, 1, 2
+    with torch.no_grad():
+        blk.gate.weight.copy_(gate)
+        for ex, (w1, w2, w3) in zip(blk.experts, experts):
+            ex.linear_v.weight.copy_(w1)
+            ex.linear_1.weight.copy_(w2)
+            ex.linear.weight.copy_(w3)
+    order = [n for n, _ in blk.experts[0].named_parameters()]
+    assert order == ["linear_v.weight", "linear_1.weight", "linear.weight"], order
+
+    def core_type4(i):
+        ex = blk.experts[i]
+        t = [p for _, p in ex.named_parameters()]  # the blob's tensor order (model_offload.py:645-671)
+        return lambda x: Fn.linear(Fn.silu(Fn.linear(x, t[0])) * Fn.linear(x, t[2]), t[1])
+
+    class _Predictor:
+        def predict(self, seq_id, expert_index, layer_id):
+            return torch.zeros(1, e)
+
+    class _Prefetcher:
+        def prefetch_experts(self, layer_id, expert_matrix):
+            return None
+
+    blk.layer_id = 0
+    blk.seq_id_list = list(range(b))
+    blk.expert_predictor, blk.expert_prefetcher = _Predictor(), _Prefetcher()
+    blk.expert_executor = make_executor(mods, FakeDispatcher(core_type4))
+    x = acts(b * s, h, dtype, 2024 + seed).reshape(b, s, h)
+    with torch.no_grad():
+        ret = blk(x)
+        out, logits = ret[0], ret[1]
+        rw = torch.softmax(logits, dim=1, dtype=torch.float)
+        rw, sel = torch.topk(rw, k, dim=-1)
+        rw = rw.to(dtype)
+    np.savez_compressed(os.path.join(OUT, name), x=npf(x), out=npf(out.reshape(b, s, h)), logits=npf(logits), topk_idx=npf(sel),
                         topk_w=npf(rw), meta=np.array([b, s, h, f, e, k, seed]), wsum=checksum(gate, experts))
     print(name, "ok", out.float().abs().mean().item())
 
@@ -378,6 +427,8 @@ def main():
     gen_mixtral(mods, "mixtral_decode_b1.npz", 1, 1, 256, 512, 8, 2, seed=1)
     gen_mixtral(mods, "mixtral_decode_b4.npz", 4, 1, 256, 512, 8, 2, seed=2)
     gen_mixtral(mods, "mixtral_prefill_t48.npz", 2, 24, 256, 512, 8, 2, seed=3)
+    gen_grok(mods, "grok_decode_b1.npz", 1, 1, 256, 512, 8, 2, seed=13)
+    gen_grok(mods, "grok_prefill_t40.npz", 2, 20, 256, 512, 8, 2, seed=14)
     gen_deepseek(mods, "deepseek_decode_b1.npz", 1, 1, 256, 176, 64, 6, 2, seed=4)
     gen_deepseek(mods, "deepseek_prefill_t40.npz", 2, 20, 256, 176, 64, 6, 2, seed=5)
     gen_deepseek(mods, "deepseek_group_t16.npz", 1, 16, 256, 176, 64, 6, 2, seed=6, topk_method="group_limited_greedy",

@@ -89,6 +89,15 @@ def route_mixtral(x2d: torch.Tensor, wg: torch.Tensor, top_k: int):
     return selected, routing_weights, router_logits
 
 
+def route_softmax_topk(x2d: torch.Tensor, wg: torch.Tensor, top_k: int):
+    """moe_infinity/models/grok.py:38-45 (= arctic.py:39-45): Mixtral's router WITHOUT the renormalisation —
+    gate in model dtype -> softmax in fp32 -> top-k -> cast back."""
+    router_logits = gate_logits(x2d, wg, x2d.dtype)
+    routing_weights = F.softmax(router_logits, dim=1, dtype=torch.float)
+    routing_weights, selected = topk_lowest_index(routing_weights, top_k)
+    return selected, routing_weights.to(x2d.dtype), router_logits
+
+
 def route_deepseek(
     x2d: torch.Tensor,
     wg: torch.Tensor,
@@ -300,6 +309,27 @@ def block_mixtral(x3d, wg, experts, top_k=2, layer_id=0) -> BlockResult:
     b, s, h = x3d.shape
     x = x3d.reshape(-1, h)
     sel, w, logits = route_mixtral(x, wg, top_k)
+    router_mask, weights_mask = masks_from_topk(sel, w, wg.shape[0])
+    final = torch.zeros((b * s, h), dtype=x.dtype)
+    res = dispatch_local(x, router_mask, layer_id, experts, MIXTRAL_DENSE_ACT_DENSE)
+    r = BlockResult(out=None, topk_idx=sel, topk_w=w, router_mask=router_mask, weights_mask=weights_mask, logits=logits)
+    for output, _, idx, _ in res:
+        tok = router_mask[:, idx].bool()
+        final[tok, :] += output * weights_mask[tok, idx][:, None]
+        r.expert_out[idx] = output
+    r.out = final.reshape(b, s, h)
+    return r
+
+
+def block_grok(x3d, wg, experts, top_k=2, layer_id=0) -> BlockResult:
+    """moe_infinity/models/grok.py:34-95 (SyncGrokMoeBlock.forward): softmax -> top-k, NO renormalisation, the combine of the
+    Mixtral block.  ``experts`` = every expert's tensors in the reference's blob order (named_parameters of MoeMLP: linear_v,
+    linear_1, linear), run by the reference's core as expert type 4 (moe_infinity/common/constants.py:33: "grok": 4 ->
+    MixtralExpert, core/parallel/expert_module.cpp:147-175: silu(x W[0]^T) * (x W[2]^T) then W[1]) — what the reference
+    computes for this architecture, which is not the model's own gelu(linear x) * linear_v x."""
+    b, s, h = x3d.shape
+    x = x3d.reshape(-1, h)
+    sel, w, logits = route_softmax_topk(x, wg, top_k)
     router_mask, weights_mask = masks_from_topk(sel, w, wg.shape[0])
     final = torch.zeros((b * s, h), dtype=x.dtype)
     res = dispatch_local(x, router_mask, layer_id, experts, MIXTRAL_DENSE_ACT_DENSE)

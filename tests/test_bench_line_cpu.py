@@ -68,3 +68,22 @@ def test_bench_py_prints_the_compact_line_only():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "bench_line.compact(" in src and "bench_line.check(" in src
     assert src.count("os.write(real_stdout") == 1  # one writer of the driver's stdout
+
+
+def test_the_offload_leg_gets_every_local_it_needs_from_run_workload():
+    """bench_legs/offload.py takes run_workload's state as a namespace built from locals(): every name it lists must be a
+    local of that function (a rename on either side would only fail on the GPU box, minutes into a run)."""
+    import ast
+
+    from bench_legs import offload
+
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "run_workload")
+    local = {a.arg for a in fn.args.args}
+    for n in ast.walk(fn):
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            local.add(n.id)
+        elif isinstance(n, ast.alias):
+            local.add((n.asname or n.name).split(".")[0])
+    missing = [k for k in offload.NEEDS if k not in local]
+    assert not missing, missing

@@ -57,6 +57,37 @@ def test_mixtral_golden(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["grok_decode_b1.npz", "grok_prefill_t40.npz"])
+def test_grok_golden(name):
+    """MOEINF_ROUTER_SOFTMAX_TOPK (round 6): the Grok / Arctic router — softmax -> top-k, NO renormalisation
+    (moe_infinity/models/grok.py:38-45) — against the reference block's own output (oracle/gen_golden.py gen_grok) and the
+    oracle; the second forward of the batch-1 case takes the self-routing path (weights from the meta block's route_core)."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd.blocks import SyncGrokMoeBlock
+
+    z = load_golden(name)
+    b, s, h, f, e, k, seed = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights("mixtral", h, f, e, seed, torch.bfloat16)
+    np.testing.assert_array_equal(checksum(gate, experts), z["wsum"])
+    eng = MoEEngine(SyncGrokMoeBlock.engine_config(h, f, e, k, num_layers=1, device_memory_ratio=0.5, max_tokens=b * s))
+    register_all(eng, experts)
+    x = tt(z["x"], torch.bfloat16)
+    ref = R.block_grok(x, gate, experts, top_k=k)
+    for rnd in range(2):  # decision path, then the sync-free path
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        r = _check_routing_exact(eng, ref)
+        assert np.array_equal(r["topk_idx"], z["topk_idx"].astype(np.int32))
+        assert np.array_equal(eng.logits(), z["logits"].astype(np.float32)), "bf16 gate logits must be bit-equal"
+        got_w = torch.from_numpy(r["topk_w"]).float()
+        assert torch.equal(got_w, tt(z["topk_w"], torch.float32)), f"round {rnd}: un-renormalised weights are bit-equal to the reference's"
+        assert float(got_w.sum(-1).max()) < 0.999
+        assert_block_close(out, ref, torch.bfloat16, f"round {rnd}: block output vs oracle")
+        assert_block_close(out, ref, torch.bfloat16, f"round {rnd}: block output vs reference golden", golden=tt(z["out"], torch.float32))
+    eng.close()
+    with pytest.raises(Exception):  # the kind is Mixtral's in everything but the weights: top_k limits hold
+        MoEEngine(SyncGrokMoeBlock.engine_config(h, f, e, 9, num_layers=1))
+
+
 @pytest.mark.parametrize("name", ["deepseek_decode_b1.npz", "deepseek_prefill_t40.npz", "deepseek_group_t16.npz"])
 def test_deepseek_golden(name):
     z = load_golden(name)

@@ -51,6 +51,23 @@ def test_mixtral_block_matches_reference(name):
     assert_close_model_dtype(r.out, t(z["out"], torch.float32), torch.bfloat16, "out")
 
 
+@pytest.mark.parametrize("name", ["grok_decode_b1.npz", "grok_prefill_t40.npz"])
+def test_grok_block_matches_reference(name):
+    """SyncGrokMoeBlock (moe_infinity/models/grok.py:34-95): softmax -> top-2 WITHOUT renormalisation; experts as the reference's
+    core runs them for this architecture (type 4 over the blob in named_parameters order; oracle/gen_golden.py gen_grok)."""
+    z = load(name)
+    b, s, h, f, e, k, seed = [int(v) for v in z["meta"]]
+    gate, experts, _ = make_weights("mixtral", h, f, e, seed, torch.bfloat16)
+    np.testing.assert_allclose(checksum(gate, experts), z["wsum"], rtol=0, atol=0)
+    x = t(z["x"], torch.bfloat16)
+    r = R.block_grok(x, gate, experts, top_k=k)
+    assert torch.equal(r.topk_idx, t(z["topk_idx"], torch.int64)), name
+    assert torch.equal(r.logits.float(), t(z["logits"], torch.float32)), "gate logits (bf16) must be bit-equal"
+    assert torch.equal(r.topk_w.float(), t(z["topk_w"], torch.float32)), "un-renormalised weights are a cast of the softmax: bit-equal"
+    assert float(r.topk_w.float().sum(-1).max()) < 0.999, "the weights of a token do not sum to one (no renormalisation)"
+    assert_close_model_dtype(r.out, t(z["out"], torch.float32), torch.bfloat16, "out")
+
+
 @pytest.mark.parametrize("name", ["deepseek_decode_b1.npz", "deepseek_prefill_t40.npz", "deepseek_group_t16.npz"])
 def test_deepseek_block_matches_reference(name):
     z = load(name)

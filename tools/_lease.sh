@@ -1,8 +1,6 @@
-# round 6, lease g: the full GPU suite at HEAD, then the profiles that had none (NLLB batch 32, Switch, fp16), DeepSeek at HEAD, the prefill GEMM's MFMA busy + clock + L2
-bash tools/gpu_run.sh r6g build pytest smoke
-bash tools/gpu_run.sh r6g kt:nllb-moe-54b:32 pmc:nllb-moe-54b:FETCH_SIZE:32 pmc:nllb-moe-54b:WRITE_SIZE:32
-bash tools/gpu_run.sh r6g kt:switch-base-8 pmc:switch-base-8:FETCH_SIZE pmc:switch-base-8:WRITE_SIZE
-bash tools/gpu_run.sh r6g kt:deepseek-v2-lite pmc:deepseek-v2-lite:FETCH_SIZE pmc:deepseek-v2-lite:WRITE_SIZE
-GPU_RUN_BENCH_FLAGS="--dtype fp16" bash tools/gpu_run.sh r6g_fp16 kt:mixtral-8x7b kt:deepseek-v2-lite kt:nllb-moe-54b:32
-bash tools/gpu_run.sh r6g mfma:mixtral-8x7b:4096
-GPU_RUN_PROMPT=4096 bash tools/gpu_run.sh r6g pmc:mixtral-8x7b:TCC_HIT_sum+TCC_MISS_sum
+# round 6, lease i: ffn_gemm_big — short last passes moved to the end of the grid and split (A/B by token count + parity)
+mkdir -p gpurun_out/r6i
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -k "mixtral_8x7b_layer or short_last_passes or skewed or (deepseek_v2_lite_layer and 4096) or nllb_moe_54b_layer_prefill" 2>&1 | tail -6
+for t in 4096 3072 3840 4224 2048 1536 2560; do
+SWEEP_ENVS="MOEINF_GEMM_BIG_SPLIT=0;MOEINF_GEMM_BIG_SPLIT=1;MOEINF_GEMM_BIG_SPLIT=4;MOEINF_GEMM_BIG_SPLIT=0;MOEINF_GEMM_BIG_SPLIT=1;MOEINF_GEMM_BIG_SPLIT=4" timeout 600 python tools/ffn_sweep.py mixtral_8x7b:$t:2 2>&1 | tee -a gpurun_out/r6i/big_split.txt
+done
