@@ -151,7 +151,7 @@ def offload_regime(c):
             return {"routing": routing, "policy": policy, "speculation": spec_name,
                     "speculation_kind": {False: "none", True: "eam", "lookahead": f"gate-lookahead top{la_max or 2 * K}"}[speculate],
                     "activations": f"residual stream x_(l+1) = rmsnorm(x_l + {RES_EPS} n_l), cos 0.894" if residual else "independent per layer (seed 2024 + layer)",
-                    "prefetch_precision": None if not s_["prefetch_issued"] else round(s_["prefetch_useful"] / max(1, s_["prefetch_issued"]), 4),
+                    "prefetch_precision": None if not s_["prefetch_issued"] else round(min(1.0, s_["prefetch_useful"] / max(1, s_["prefetch_issued"])), 4),  # (copies issued in the settling steps can be used after the counters were reset: capped at 1)
                     "prefetch_wasted": s_.get("prefetch_wasted"), "prefetch_settled": done,
                     "attention_standin_us_per_layer": round(reps * one_us, 1) if with_attn else 0.0,
                     "steps": nsteps_leg, "ms_per_token": round(el * 1e3 / nsteps_leg / B, 3),
