@@ -187,6 +187,7 @@ extern "C" int moeinf_destroy(moeinf_engine* g) {
   if (g->h_la_idx) hipHostFree(g->h_la_idx);
   if (g->h_la_w) hipHostFree(g->h_la_w);
   if (g->h_keep) hipHostFree(g->h_keep);
+  if (g->d_copy_ts) hipFree(g->d_copy_ts);
   for (auto& pr : g->copy_timers) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   free_token_workspace(g);
   void* bufs[] = {g->d_wptr, g->d_counts, g->d_offsets, g->d_active, g->d_n_active,
@@ -309,6 +310,16 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     bool vec_ok = true;
     for (int i = 0; i < g->dlay.n; ++i) if (g->dlay.K[i] == 0 && (g->dlay.size[i] % 16) != 0) vec_ok = false;
     g->whole_blob = g->lay.total <= cap && vec_ok;
+    // MOEINF_H2D_PULL (default 1): the pull form needs 16-byte vector pieces like the whole-blob re-tile; MOEINF_H2D_PULL_WGS: workgroups per launch
+    const char* pe = getenv("MOEINF_H2D_PULL");
+    g->h2d_pull = (pe ? atoi(pe) != 0 : true) && vec_ok;
+    const char* pw = getenv("MOEINF_H2D_PULL_WGS");
+    g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : 16;
+    if (g->h2d_pull) {
+      TRYHIP(hipMalloc((void**)&g->d_copy_ts, (size_t)kCopyTsRing * 32));
+      TRYHIP(hipMemset(g->d_copy_ts, 0, (size_t)kCopyTsRing * 32));
+      g->copy_ts_expect.assign(kCopyTsRing, 0);
+    }
     if (g->whole_blob) g->stage_bytes = std::max<int64_t>(g->stage_bytes, align_up(g->lay.total, kAioAlignment));
   }
   for (CopyLane* ln : {&g->demand, &g->prefetch}) {
@@ -549,7 +560,8 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   Slot& s = g->slots[slot];
   if (!n.ready) HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
   if (!n.ready1) HIPCHK(hipEventCreateWithFlags(&n.ready1, hipEventDisableTiming));
-  hipEvent_t start = get_event(g), stop = get_event(g);
+  // link-busy timers: the pull form times itself inside its kernels (no queue packets); the SDMA forms bracket the copies with events
+  hipEvent_t start = g->h2d_pull ? nullptr : get_event(g), stop = g->h2d_pull ? nullptr : get_event(g);
   if (start && stop) HIPCHK(hipEventRecord(start, ln.copy));
   int order[4];
   const int n1 = copy_order(g->cfg.expert_type, order);
@@ -557,25 +569,81 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   // ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence);
   // (b) the previous tenant's OWN transfer may still be in flight on another lane (a prefetched expert is
   // evictable from the moment its copy is issued): write-after-write on the slot
-  auto order_first_write = [&]() -> int {
+  auto order_first_write_on = [&](hipStream_t ws) -> int {
     if (s.last_use_seq > 0) {
       const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
       hipEvent_t fe = g->fence_ev[fs % kFenceRing];
       if (hipEventQuery(fe) != hipSuccess) {
         (void)hipGetLastError();
-        HIPCHK(hipStreamWaitEvent(ln.retile, fe, 0));
+        HIPCHK(hipStreamWaitEvent(ws, fe, 0));
       }
     }
     if (victim >= 0) {
       Node& vn = g->nodes[victim];
       if (!vn.ready_waited && vn.ready && hipEventQuery(vn.ready) != hipSuccess) {
         (void)hipGetLastError();
-        HIPCHK(hipStreamWaitEvent(ln.retile, vn.ready, 0));
+        HIPCHK(hipStreamWaitEvent(ws, vn.ready, 0));
       }
       vn.ready_waited = true; vn.waited1 = true;
     }
     return MOEINF_OK;
   };
+  auto order_first_write = [&]() -> int { return order_first_write_on(ln.retile); };
+  if (g->h2d_pull) {
+    // PULL (kernels.hip: pull_retile_kernel): the copy stream's own kernel reads the pinned host blob and writes the tiled slot.
+    // Small experts: one launch for the whole blob; big ones: the stage-1 tensors first (ready1), then the rest.
+    CHK(order_first_write_on(ln.copy));
+    unsigned long long* ts = nullptr;
+    int ts_slot = -1;
+    if (g->d_copy_ts) {
+      if (g->copy_ts_head - g->copy_ts_tail >= (uint64_t)kCopyTsRing) g->copy_ts_tail = g->copy_ts_head - kCopyTsRing + 1;  // overflow: the oldest records are given up
+      ts_slot = (int)(g->copy_ts_head % kCopyTsRing);
+      ts = g->d_copy_ts + (size_t)ts_slot * 4;
+    }
+    int launches = 0;
+    auto pull = [&](int k0, int k1) -> int {
+      RetileBlob rb;
+      memset(&rb, 0, sizeof rb);
+      rb.src = n.host; rb.dst = s.dev; rb.n = 0;
+      for (int k = k0; k < k1; ++k) {
+        const int i = order[k], j = rb.n++;
+        rb.src_off[j] = g->lay.off[i]; rb.dst_off[j] = g->dlay.off[i];
+        rb.K[j] = g->dlay.K[i];
+        rb.R[j] = g->dlay.K[i] > 0 ? g->dlay.R[i] : (int)(g->dlay.size[i] / 16);
+      }
+      HIPCHK(launch_pull_retile(rb, g->dt, g->h2d_pull_wgs, ln.copy, ts, launches == 0 ? 1 : 0));
+      launches += 1;
+      return MOEINF_OK;
+    };
+    bool one_event = false;
+    if (g->whole_blob || n1 >= g->lay.n) {
+      CHK(pull(0, g->lay.n));
+      one_event = true;  // stage 1 and stage 2 wait for the same point of the stream: ONE event record serves both
+    } else {
+      CHK(pull(0, n1));
+      HIPCHK(hipEventRecord(n.ready1, ln.copy));
+      CHK(pull(n1, g->lay.n));
+    }
+    if (ts_slot >= 0) {
+      g->copy_ts_expect[ts_slot] += (uint64_t)launches * (uint64_t)g->h2d_pull_wgs;
+      g->copy_ts_head += 1;
+    }
+    HIPCHK(hipEventRecord(n.ready, ln.copy));
+    n.ready1_is_ready = one_event;
+    n.slot = slot;
+    n.ready_waited = false;
+    n.waited1 = false;
+    n.copy_inflight = true;
+    n.copy_seq = ++g->copy_seq; n.copy_lane = (&ln == &g->prefetch) ? 1 : 0;
+    n.host_clock = ++g->host_clock;
+    s.node = idx;
+    g->pol[idx].resident = true;
+    g->st.slots_used += 1;
+    g->st.h2d_bytes += g->lay.total;
+    queue_poke(g, idx % g->L, idx / g->L, (uint64_t)s.dev);
+    return MOEINF_OK;
+  }
+  bool sdma_one_event = false;
   if (g->whole_blob) {
     StageBuf& b = ln.ring[ln.next];
     ln.next = (ln.next + 1) % kStageRing;
@@ -595,7 +663,7 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
     HIPCHK(launch_retile_blob(rb, g->dt, ln.retile));
     HIPCHK(hipEventRecord(b.freed, ln.retile));
     b.used = true;
-    HIPCHK(hipEventRecord(n.ready1, ln.retile));
+    sdma_one_event = true;  // (`ready`, recorded below at the same point of the re-tile stream, serves for both)
   } else
   for (int k = 0; k < g->lay.n; ++k) {
     const int i = order[k];
@@ -616,10 +684,12 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
     g->copy_timers.push_back({start, stop});
   }
   HIPCHK(hipEventRecord(n.ready, ln.retile));
+  n.ready1_is_ready = sdma_one_event;
   n.slot = slot;
   n.ready_waited = false;
   n.waited1 = false;
   n.copy_inflight = true;
+  n.copy_seq = ++g->copy_seq; n.copy_lane = (&ln == &g->prefetch) ? 1 : 0;
   n.host_clock = ++g->host_clock;
   s.node = idx;
   g->pol[idx].resident = true;
@@ -629,7 +699,32 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   return MOEINF_OK;
 }
 
+// the pull form's timing records (pull_retile_kernel): finished copies' [start, end] ticks (100 MHz) merged into the link-busy time
+static void settle_copy_ticks(moeinf_engine* g, bool wait) {
+  if (!g->d_copy_ts || g->copy_ts_tail == g->copy_ts_head) return;
+  if (wait) { hipStreamSynchronize(g->demand.copy); hipStreamSynchronize(g->prefetch.copy); }
+  const uint64_t n = g->copy_ts_head - g->copy_ts_tail;
+  std::vector<unsigned long long> rec((size_t)n * 4);
+  const uint64_t t0 = g->copy_ts_tail % kCopyTsRing, first = std::min<uint64_t>(n, kCopyTsRing - t0);
+  if (hipMemcpy(rec.data(), g->d_copy_ts + t0 * 4, first * 32, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (n > first && hipMemcpy(rec.data() + first * 4, g->d_copy_ts, (n - first) * 32, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+  uint64_t done = 0;
+  for (; done < n; ++done) {  // in issue order; stop at the first copy that has not finished
+    const int slot = (int)((g->copy_ts_tail + done) % kCopyTsRing);
+    if (rec[done * 4 + 2] < g->copy_ts_expect[slot]) break;
+    if (rec[done * 4 + 1] > rec[done * 4]) iv.push_back({rec[done * 4], rec[done * 4 + 1]});
+  }
+  g->copy_ts_tail += done;
+  std::sort(iv.begin(), iv.end());
+  for (auto& p : iv) {  // union over the lanes: only what extends beyond the accounted time counts
+    const unsigned long long lo = std::max(p.first, g->copy_busy_until);
+    if (p.second > lo) { g->st.h2d_busy_ms += (double)(p.second - lo) * 1e-5; g->copy_busy_until = p.second; }
+  }
+}
+
 static void settle_copy_timers(moeinf_engine* g, bool wait) {
+  settle_copy_ticks(g, wait);
   size_t keep = 0;
   // link-busy time = the UNION of the lanes' copy intervals (the demand lane and the speculative lane run side by side: a
   // plain sum would count the shared link twice).  Intervals settle in issue order; `busy_mark` is the stop event of the
@@ -1049,6 +1144,7 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) { const Node& n = g->nodes[node_index(g, layer, e)]; if (n.slot < 0 || !n.waited1) will_wait = true; } }
   hipEvent_t w0 = nullptr, w1 = nullptr;
   if (will_wait) { w0 = get_event(g); w1 = get_event(g); if (w0 && w1) record_timing(w0, st); }
+  std::vector<int> need_one;
   for (int i = a0; i < na && rc == MOEINF_OK; ++i) {
     const int e = active[i];
     if (e >= g->E) continue;  // shared pseudo-expert
@@ -1071,16 +1167,33 @@ static int ensure_resident(moeinf_engine* g, int layer, hipStream_t st, std::vec
       if (rc != MOEINF_OK) break;
       g->demand_inflight.push_back(idx);
     }
-    if (!n.waited1) {
-      hipError_t he = hipStreamWaitEvent(st, n.ready1, 0);
-      if (he != hipSuccess) { rc = fail(MOEINF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(he)); break; }
-      n.waited1 = true;
+    if (!n.waited1 && n.ready1_is_ready) {
+      // the whole blob arrives with ONE event (pull form / whole-blob copies): waited for below, once per copy lane — the lane's
+      // copies complete in issue order, so its latest one covers the others — and nothing is left for wait_late
+      need_one.push_back(idx);
+    } else {
+      if (!n.waited1) {
+        hipError_t he = hipStreamWaitEvent(st, n.ready1, 0);
+        if (he != hipSuccess) { rc = fail(MOEINF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(he)); break; }
+        n.waited1 = true;
+      }
+      if (!n.ready_waited) late.push_back(idx);
     }
-    if (!n.ready_waited) late.push_back(idx);
     g->pol[idx].incache += 1;  // incache_visit_count += 1 on every dispatch (expert_dispatcher.cpp:263)
     g->pol[idx].last_access = ++g->clock;
     n.host_clock = ++g->host_clock;
     g->slots[n.slot].last_use_seq = g->seq + 1;
+  }
+  if (rc == MOEINF_OK && !need_one.empty()) {
+    int last[2] = {-1, -1};
+    for (int idx : need_one) { const Node& n = g->nodes[idx]; const int ln = n.copy_lane & 1; if (last[ln] < 0 || n.copy_seq > g->nodes[last[ln]].copy_seq) last[ln] = idx; }
+    for (int ln = 0; ln < 2 && rc == MOEINF_OK; ++ln)
+      if (last[ln] >= 0) {
+        hipError_t he = hipStreamWaitEvent(st, g->nodes[last[ln]].ready, 0);
+        if (he != hipSuccess) rc = fail(MOEINF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(he));
+      }
+    if (rc == MOEINF_OK)
+      for (int idx : need_one) { Node& n = g->nodes[idx]; n.waited1 = true; if (!n.ready_waited) { n.ready_waited = true; g->resident_per_layer[layer] += 1; } }
   }
   for (int i = a0; i < na; ++i) { const int e = active[i]; if (e < g->E) g->pol[node_index(g, layer, e)].pinned = false; }
   if (w0 && w1) { record_timing(w1, st); g->wait_timers.push_back({w0, w1}); }

@@ -154,6 +154,9 @@ struct Node {
   void* host = nullptr;        // pinned arena blob (reference layout); nullptr + store != nullptr: on disk only
   int slot = -1;
   hipEvent_t ready1 = nullptr; // recorded once the tensors FFN stage 1 reads are in the slot
+  uint64_t copy_seq = 0;        // issue number of the node's latest transfer (per engine, grows)
+  int8_t copy_lane = 0;         // 0 demand, 1 speculative
+  bool ready1_is_ready = false; // the whole blob arrives with one launch: `ready` serves for both (one event record less per copy)
   hipEvent_t ready = nullptr;  // recorded once the whole expert is in the slot
   bool waited1 = true;         // compute stream already ordered after `ready1`
   bool ready_waited = true;    // compute stream already ordered after `ready`
@@ -188,6 +191,7 @@ struct StageBuf {
   hipEvent_t filled = nullptr, freed = nullptr;
   bool used = false;
 };
+constexpr int kCopyTsRing = 8192;
 constexpr int kStageRing = 4;  // staging buffers per lane: the link never waits for a re-tile launch two copies back
 struct CopyLane {
   hipStream_t copy = nullptr, retile = nullptr;
@@ -208,6 +212,13 @@ struct moeinf_engine {
   // model_topology.cpp:102-119) into a staging buffer sized for an expert, re-tiled by one launch; big ones (Mixtral: 336 MiB)
   // tensor by tensor, so FFN stage 1 can start while the down projection is still on the link.
   bool whole_blob = false;
+  unsigned long long* d_copy_ts = nullptr;  // [kCopyTsRing][4] timing records of the pull form (kernels.hip: pull_retile_kernel)
+  std::vector<uint64_t> copy_ts_expect;     // per ring slot: finished-workgroup count that means "this use of the slot is complete" (grows)
+  uint64_t copy_ts_head = 0, copy_ts_tail = 0;
+  uint64_t copy_seq = 0;
+  unsigned long long copy_busy_until = 0;   // tick up to which link-busy time has been accounted
+  bool h2d_pull = false;   // experts are PULLED by a kernel of the copy stream straight from the pinned host blob into the tiled slot
+  int h2d_pull_wgs = 16;
   // next-layer gate lookahead (moeinf_set_lookahead)
   std::vector<const void*> la_gates;   // [L] borrowed device pointers; empty: off
   int la_max = 0;

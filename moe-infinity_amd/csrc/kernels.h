@@ -181,6 +181,9 @@ struct RetileBlob {
   int R[4], K[4];
 };
 hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st);
+// the same from PINNED HOST memory (b.src = device-visible host pointer): the tier mover's pull form, `workgroups` x 256 threads
+// ts: nullptr, or a 4 x u64 timing record in device memory {start tick of the copy's first launch (written when first != 0), max end tick, finished workgroups, -}
+hipError_t launch_pull_retile(const RetileBlob& b, int dtype, int workgroups, hipStream_t st, unsigned long long* ts = nullptr, int first = 1);
 inline int64_t tiled_bytes(int64_t R, int64_t K, int dtype) { const int64_t ept = dtype == DT_F32 ? 16 : 32; return ((R + 15) / 16) * ((K + ept - 1) / ept) * 1024; }
 
 struct RouteArgs {

@@ -89,6 +89,99 @@ hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st) {
   else hipLaunchKernelGGL(retile_blob_kernel<float>, grid, dim3(256), 0, st, b);
   return hipGetLastError();
 }
+// PULL form of the tier mover (round 6): the GPU fetches an expert blob from PINNED HOST memory itself and writes it straight into
+// the tiled slot — no SDMA copy, no staging buffer, no re-tile launch.  Measured (tools/pcie_read.hip,
+// profiles/r06_pcie_pull_kernel_vs_hipmemcpy.txt): 8-16 workgroups with four 16-byte loads per lane in flight pull 56.5 GB/s
+// from a hipHostMalloc arena — the link's rate — while a hipMemcpyAsync that has an event recorded in front of and behind it
+// (every expert copy of the engine had: staging-buffer hand-over, ready events, timers) pays ~60 us of SDMA <-> queue hand-overs
+// on top of its bytes (16.5 MiB DeepSeek experts: 46-52 GB/s; 112 MiB Mixtral pieces: 54.6).  A kernel on the copy stream orders
+// against events inside ONE hardware queue.
+// Work unit = 16 rows x 1 KiB (one row group, sixteen k-tiles): every wave reads four ROWS, 1 KiB CONTIGUOUS each (a first form
+// that read the 64-byte row pieces of a tile directly pulled 21-35 GB/s: sixteen 64-byte requests per wave-load to sixteen
+// different pages; contiguous KiBs reach the link's 56), the rows cross through LDS, and the workgroup writes sixteen 1-KiB tiles.
+// The loads of unit i+1 are in flight while unit i leaves LDS.  A bias vector is copied in 16-KiB units.
+template <typename T>
+__global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned long long* ts, int first) {
+  // link-busy timing WITHOUT queue packets (an event record between two kernels of a stream costs ~10 us, and the engine's timers
+  // were two per copy: -5.5 % ms/token on the DeepSeek offload leg): ts[0] = start tick of the copy's first launch, ts[1] = max
+  // end tick over its workgroups, ts[2] = workgroups that have finished (all three only ever grow: no re-initialisation)
+  if (ts && first && blockIdx.x == 0 && threadIdx.x == 0) ts[0] = (unsigned long long)wall_clock64();
+  constexpr int EPV = DT<T>::EPV;          // elements per 16 bytes
+  constexpr int EPT = 4 * EPV;             // k elements per tile (64 bytes of a row)
+  constexpr int CK = 64 * EPV;             // k elements per unit (1 KiB of a row)
+  constexpr int LROW = 1024 + 16;          // LDS bytes per row (padded: the tile reads walk sixteen rows)
+  __shared__ __attribute__((aligned(16))) char lds[16 * LROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nunit[4], kcs[4], total = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    kcs[t] = (t < b.n && b.K[t] > 0) ? (b.K[t] + CK - 1) / CK : 1;
+    nunit[t] = t < b.n ? (b.K[t] > 0 ? ((b.R[t] + 15) / 16) * kcs[t] : (b.R[t] + 1023) / 1024) : 0;  // vector: R = 16-byte pieces, 1024 per unit
+    total += nunit[t];
+  }
+  u32x4 v[4];
+  auto decode = [&](int i, int& t, int& rg, int& kc) {
+    t = 0;
+    while (t < 3 && i >= nunit[t]) { i -= nunit[t]; ++t; }
+    rg = i / kcs[t]; kc = i - rg * kcs[t];
+  };
+  auto load = [&](int i) {
+    int t, rg, kc;
+    decode(i, t, rg, kc);
+    const char* src = reinterpret_cast<const char*>(b.src) + b.src_off[t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = u32x4{0u, 0u, 0u, 0u};
+      if (b.K[t] > 0) {
+        const int row = rg * 16 + wave * 4 + j, k = kc * CK + lane * EPV;
+        if (row < b.R[t] && k < b.K[t]) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(src) + (size_t)row * b.K[t] + k));
+      } else {
+        const int piece = rg * 1024 + (wave * 4 + j) * 64 + lane;  // (kcs = 1: rg = the unit)
+        if (piece < b.R[t]) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + piece);
+      }
+    }
+  };
+  int i = blockIdx.x;
+  if (i < total) load(i);
+  for (; i < total; i += gridDim.x) {
+    int t, rg, kc;
+    decode(i, t, rg, kc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(lds + (wave * 4 + j) * LROW + lane * 16) = v[j];
+    __syncthreads();
+    if (i + (int)gridDim.x < total) load(i + gridDim.x);  // in flight while this unit leaves through LDS
+    char* dst = reinterpret_cast<char*>(b.dst) + b.dst_off[t];
+    if (b.K[t] > 0) {
+      const int KB = (b.K[t] + EPT - 1) / EPT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kbl = wave * 4 + j, kb = kc * 16 + kbl;  // tile of this unit: row lane & 15, 16-byte piece lane >> 4
+        if (kb < KB) {
+          const u32x4 w = *reinterpret_cast<const u32x4*>(lds + (lane & 15) * LROW + kbl * 64 + (lane >> 4) * 16);
+          *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int piece = rg * 1024 + (wave * 4 + j) * 64 + lane;
+        if (piece < b.R[t]) *reinterpret_cast<u32x4*>(dst + (size_t)piece * 16) = *reinterpret_cast<const u32x4*>(lds + (wave * 4 + j) * LROW + lane * 16);
+      }
+    }
+    __syncthreads();
+  }
+  if (ts && threadIdx.x == 0) {
+    atomicMax(&ts[1], (unsigned long long)wall_clock64());
+    __threadfence();
+    atomicAdd(&ts[2], 1ull);
+  }
+}
+hipError_t launch_pull_retile(const RetileBlob& b, int dtype, int workgroups, hipStream_t st, unsigned long long* ts, int first) {
+  const dim3 grid(workgroups < 1 ? 1 : workgroups);
+  if (dtype != DT_F32) hipLaunchKernelGGL((pull_retile_kernel<uint16_t>), grid, dim3(256), 0, st, b, ts, first);
+  else hipLaunchKernelGGL((pull_retile_kernel<float>), grid, dim3(256), 0, st, b, ts, first);
+  return hipGetLastError();
+}
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st) {
   const int ept = dtype == DT_F32 ? 16 : 32;
   dim3 grid(((K + ept - 1) / ept + 3) / 4, (R + 15) / 16);
