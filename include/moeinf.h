@@ -56,6 +56,9 @@ enum {
   MOEINF_ROUTER_DEEPSEEK = 1, /* models/modeling_deepseek/modeling_deepseek.py:463-512 (MoEGate) */
   MOEINF_ROUTER_SWITCH = 2,   /* HF SwitchTransformersTop1Router @ models/switch_transformers.py:76 */
   MOEINF_ROUTER_NLLB = 3,     /* HF NllbMoeTop2Router @ models/nllb_moe.py:53 */
+  MOEINF_ROUTER_DEEPSEEK_V3 = 5,  /* DeepSeek-V3's MoEGate: sigmoid scores + e_score_correction_bias, groups ranked by the sum of their two best, weights normalised
+                                   * then scaled (models/modeling_deepseek_v3/modeling_deepseek.py:466-528); n_group / topk_group / norm_topk_prob /
+                                   * routed_scaling_factor as for DeepSeek; the per-layer bias: moeinf_set_gate_bias */
   MOEINF_ROUTER_SOFTMAX_TOPK = 4 /* Grok / Arctic: softmax -> top-k, NO renormalisation (models/grok.py:38-45, arctic.py:39-45); otherwise Mixtral's */
 };
 
@@ -348,6 +351,10 @@ int moeinf_set_predictor(moeinf_engine* eng, moeinf_tracer* tr, int64_t seq_id, 
  * n_layers == 0 turns it off.  The reference has no counterpart: its prefetcher predicts from the EAM history only
  * (moe_infinity/memory/expert_prefetcher.py:28-59) and is dormant for these models (mixtral.py:69-85 commented out). */
 int moeinf_set_lookahead(moeinf_engine* eng, const void* const* gate_w_dev, int n_layers, int max_experts);
+/* MOEINF_ROUTER_DEEPSEEK_V3 only: layer `layer`'s e_score_correction_bias — num_experts fp32 values in device memory, borrowed
+ * (modeling_deepseek_v3/modeling_deepseek.py:455-458,484-487: added to the sigmoid scores for the CHOICE of experts, not to their
+ * weights).  NULL = zeros.  Takes effect with the next forward of that layer. */
+int moeinf_set_gate_bias(moeinf_engine* eng, int layer, const float* bias_dev);
 
 /* ---- disk tier: the reference's offload directory (host only) ----------------
  * Reads and writes `<offload_path>/archer_index` + `archer_param_<n>` in the reference's own format

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "moeinf_tracer_get_eam": (C.c_int, [_P, C.c_int64, _F64P]),
     "moeinf_set_predictor": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_int]),
     "moeinf_set_lookahead": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "moeinf_set_gate_bias": (C.c_int, [_P, C.c_int, _P]),
     "moeinf_store_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "moeinf_store_close": (C.c_int, [_P]),
     "moeinf_store_put": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _I64P, C.c_int, C.c_int]),

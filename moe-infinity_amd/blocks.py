@@ -121,23 +121,38 @@ class DeepseekMoEBlock(_MoeBlockBase):
         # MoEGate.weight (modeling_deepseek.py:452-455)
         self.gate = nn.Module()
         self.gate.weight = nn.Parameter(torch.empty((config.n_routed_experts, config.hidden_size)))
+        if getattr(config, "topk_method", "greedy") == "noaux_tc":  # DeepSeek-V3's MoEGate (modeling_deepseek_v3/modeling_deepseek.py:455-458)
+            self.gate.e_score_correction_bias = nn.Parameter(torch.empty((config.n_routed_experts,)))
+        self._bias_f32 = None
 
     def _gate_weight(self):
         return self.gate.weight
 
     def forward(self, hidden_states):
+        b = getattr(self.gate, "e_score_correction_bias", None)
+        if b is not None and (self._bias_f32 is None or self._bias_src != b.data_ptr()):
+            # the engine reads the bias as fp32 (the gate adds it to fp32 scores; a bf16 parameter is promoted: same values)
+            self._bias_f32 = b.detach().to(device=self.engine.device, dtype=torch.float32).contiguous()
+            self._bias_src = b.data_ptr()
+            self.engine.set_gate_bias(self.layer_id, self._bias_f32)
         return self._run(hidden_states)
 
     @staticmethod
     def engine_config(config, num_layers, **kw) -> Cf.EngineConfig:
         # DeepSeek-V3's gate (sigmoid scores + e_score_correction_bias + top-2-sum group selection,
-        # moe_infinity/models/modeling_deepseek_v3/modeling_deepseek.py:443-483) is NOT one of the fused routers: refuse loudly
-        # instead of routing with V2's softmax rule.  Such a model runs through the dense-mask path (its own Python MoEGate +
-        # prefetch_op.expert_dispatcher / moeinf_dispatch_mask), which does not look at the gate at all.
-        if getattr(config, "scoring_func", "softmax") != "softmax" or getattr(config, "topk_method", "greedy") == "noaux_tc":
-            raise NotImplementedError("DeepSeek-V3 gate (scoring_func=%r, topk_method=%r) is not a fused router of this engine: keep the model's "
-                                      "Python MoEGate and dispatch through prefetch_op.expert_dispatcher (moeinf_dispatch_mask)"
-                                      % (getattr(config, "scoring_func", None), getattr(config, "topk_method", None)))
+        # moe_infinity/models/modeling_deepseek_v3/modeling_deepseek.py:466-528) is a fused router since round 6; any OTHER
+        # combination of scoring function and top-k method is refused loudly instead of being routed with V2's softmax rule (such a
+        # model runs through the dense-mask path: its own Python gate + prefetch_op.expert_dispatcher / moeinf_dispatch_mask).
+        scoring, method = getattr(config, "scoring_func", "softmax"), getattr(config, "topk_method", "greedy")
+        if scoring == "sigmoid" and method == "noaux_tc":  # DeepSeek-V3 (round 6: MOEINF_ROUTER_DEEPSEEK_V3; the bias: attach_engine)
+            return Cf.EngineConfig(num_layers=num_layers, num_experts=config.n_routed_experts, expert_type=Cf.EXPERT_DEEPSEEK,
+                                   hidden=config.hidden_size, inter=config.moe_intermediate_size, top_k=config.num_experts_per_tok,
+                                   router_kind=Cf.ROUTER_DEEPSEEK_V3, shared_inter=(config.n_shared_experts or 0) * config.moe_intermediate_size,
+                                   norm_topk_prob=bool(config.norm_topk_prob), routed_scaling_factor=float(config.routed_scaling_factor),
+                                   n_group=int(config.n_group), topk_group=int(config.topk_group), **kw)
+        if scoring != "softmax" or method == "noaux_tc":
+            raise NotImplementedError("gate (scoring_func=%r, topk_method=%r) is not a fused router of this engine: keep the model's "
+                                      "Python MoEGate and dispatch through prefetch_op.expert_dispatcher (moeinf_dispatch_mask)" % (scoring, method))
         grouped = getattr(config, "topk_method", "greedy") == "group_limited_greedy"
         return Cf.EngineConfig(num_layers=num_layers, num_experts=config.n_routed_experts, expert_type=Cf.EXPERT_DEEPSEEK,
                                hidden=config.hidden_size, inter=config.moe_intermediate_size,

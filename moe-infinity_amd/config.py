@@ -12,7 +12,7 @@ from typing import Optional
 # ids shared with include/moeinf.h (and core/parallel/expert_module.h in the reference)
 DTYPE_BF16, DTYPE_F32, DTYPE_F16 = 0, 1, 2
 EXPERT_SWITCH, EXPERT_SWITCH_GATED, EXPERT_NLLB, EXPERT_FSGPT, EXPERT_MIXTRAL, EXPERT_DEEPSEEK = 0, 1, 2, 3, 4, 5
-ROUTER_MIXTRAL, ROUTER_DEEPSEEK, ROUTER_SWITCH, ROUTER_NLLB, ROUTER_SOFTMAX_TOPK = 0, 1, 2, 3, 4
+ROUTER_MIXTRAL, ROUTER_DEEPSEEK, ROUTER_SWITCH, ROUTER_NLLB, ROUTER_SOFTMAX_TOPK, ROUTER_DEEPSEEK_V3 = 0, 1, 2, 3, 4, 5
 POLICY_LFU_INCACHE, POLICY_LRU = 0, 1
 
 # moe_infinity/common/constants.py:29-37 (MODEL_MAPPING_TYPES)

@@ -91,7 +91,9 @@ static int validate(const moeinf_config* c) {
   if (c->hidden <= 0 || c->inter <= 0 || c->hidden % ev || c->inter % ev) return fail(MOEINF_ERR_INVALID, "hidden/inter must be positive multiples of %d", ev);
   if (c->shared_inter < 0 || c->shared_inter % ev) return fail(MOEINF_ERR_INVALID, "shared_inter must be a multiple of %d", ev);
   if (c->top_k <= 0 || c->top_k > 8 || c->top_k > c->num_experts) return fail(MOEINF_ERR_INVALID, "top_k must be in 1..min(8,E)");
-  if (c->router_kind < 0 || c->router_kind > MOEINF_ROUTER_SOFTMAX_TOPK) return fail(MOEINF_ERR_INVALID, "router_kind");
+  if (c->router_kind < 0 || c->router_kind > MOEINF_ROUTER_DEEPSEEK_V3) return fail(MOEINF_ERR_INVALID, "router_kind");
+  if (c->router_kind == MOEINF_ROUTER_DEEPSEEK_V3 && (c->n_group <= 0 || c->num_experts % c->n_group || c->n_group > 64 || c->topk_group <= 0 || c->topk_group > c->n_group || c->num_experts / c->n_group < 2))
+    return fail(MOEINF_ERR_INVALID, "DeepSeek-V3 gate: n_group must divide num_experts into groups of at least two, 1 <= topk_group <= n_group <= 64");
   if (c->router_kind == MOEINF_ROUTER_SWITCH && c->top_k != 1) return fail(MOEINF_ERR_INVALID, "switch router is top-1");
   if (c->router_kind == MOEINF_ROUTER_NLLB && c->top_k != 2) return fail(MOEINF_ERR_INVALID, "nllb router is top-2");
   if (c->router_kind == MOEINF_ROUTER_DEEPSEEK && c->n_group > 1) {
@@ -227,6 +229,9 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   // kind — bf16 gate logits, selection, dispatch, combine, which kernels run — is Mixtral's: the engine keeps ONE kind for it
   // and a flag for the weights.
   if (g->cfg.router_kind == MOEINF_ROUTER_SOFTMAX_TOPK) { g->route_no_renorm = true; g->cfg.router_kind = MOEINF_ROUTER_MIXTRAL; }
+  // DeepSeek-V3's gate (modeling_deepseek_v3 MoEGate): DeepSeek's block in everything but the router arithmetic — one kind, a flag;
+  // the per-layer e_score_correction_bias comes through moeinf_set_gate_bias
+  if (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK_V3) { g->route_v3 = true; g->cfg.router_kind = MOEINF_ROUTER_DEEPSEEK; g->gate_bias.assign((size_t)g->cfg.num_layers, nullptr); }
   memset(&g->st, 0, sizeof g->st);
   memset(&g->prof, 0, sizeof g->prof);
   memset(&g->ep_prof, 0, sizeof g->ep_prof);
@@ -1426,6 +1431,7 @@ void make_route_args(const moeinf_engine* g, const void* x_dev, const void* gate
   ra.x_dtype = g->dt; ra.gate_dtype = g->cfg.gate_dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : (g->cfg.gate_dtype == MOEINF_DTYPE_F16 ? DT_F16 : DT_F32);
   ra.kind = g->cfg.router_kind; ra.norm_topk_prob = g->cfg.norm_topk_prob; ra.scale = g->cfg.routed_scaling_factor;
   ra.no_renorm = g->route_no_renorm ? 1 : 0;
+  ra.v3 = g->route_v3 ? 1 : 0;  // (e_bias: per layer, set by the callers that know the layer)
   ra.n_group = g->cfg.n_group; ra.topk_group = g->cfg.topk_group;
   ra.topk_idx = g->d_topk_idx; ra.topk_w = g->d_topk_w; ra.pair_valid = g->d_pair_valid; ra.pair_order = g->d_pair_order;
   ra.router_prob = g->d_router_prob;
@@ -1499,6 +1505,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
 
   RouteArgs ra;
   make_route_args(g, x_dev, gate_w_dev, T, ra);
+  if (g->route_v3) ra.e_bias = g->gate_bias[layer];
   moeinf_engine::ProfRec pr;
   const bool prof = g->profiling && !route_only;
   if (prof) { for (int i = 0; i < 6; ++i) { pr.ev[i] = get_event(g); if (!pr.ev[i]) return fail(MOEINF_ERR_HIP, "hipEventCreate failed"); } HIPCHK(hipEventRecord(pr.ev[0], st)); }
@@ -1520,7 +1527,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   static const bool selfroute_env = getenv("MOEINF_SELFROUTE") ? atoi(getenv("MOEINF_SELFROUTE")) != 0 : true;
   const int et_ = g->cfg.expert_type;
   const bool sr_gated = g->dt != DT_F32 &&
-                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
+                        (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1 && !g->route_v3)) &&
                         (et_ == MOEINF_EXPERT_MIXTRAL || et_ == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || hide_shared);
   // (round 4) Switch: top-1, plain ReLU experts, bf16 or fp32; a single token can never exceed the per-row capacity
   const bool sr_switch = g->cfg.router_kind == MOEINF_ROUTER_SWITCH && et_ == MOEINF_EXPERT_SWITCH && K == 1 && !g->has_shared &&
@@ -1584,6 +1591,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
       g->resident_per_layer[layer + 1] < g->owned_experts) {
     RouteArgs la = ra;
     la.gate_w = g->la_gates[layer + 1];
+    if (g->route_v3) la.e_bias = g->gate_bias[layer + 1];
     la.logits = g->d_la_f; la.router_prob = g->d_la_f + (size_t)kLaTokens * g->E;
     la.topk_idx = g->h_la_idx; la.topk_w = g->h_la_w;
     la.pair_valid = g->d_la_i; la.pair_order = g->d_la_i + (size_t)kLaTokens * g->K;
@@ -1934,6 +1942,14 @@ extern "C" int moeinf_prefetch(moeinf_engine* g, int layer, const int32_t* exper
     g->st.prefetch_cancelled += g->pq.enqueue(idx, layer, priority_from_score(scores, i));
   }
   return pump_prefetch(g);
+}
+
+extern "C" int moeinf_set_gate_bias(moeinf_engine* g, int layer, const float* bias_dev) {
+  if (!g) return fail(MOEINF_ERR_INVALID, "engine is NULL");
+  if (!g->route_v3) return fail(MOEINF_ERR_STATE, "moeinf_set_gate_bias: the engine's router is not MOEINF_ROUTER_DEEPSEEK_V3");
+  if (layer < 0 || layer >= g->L) return fail(MOEINF_ERR_INVALID, "layer %d out of range", layer);
+  g->gate_bias[layer] = bias_dev;  // borrowed; NULL = zeros
+  return MOEINF_OK;
 }
 
 extern "C" int moeinf_set_lookahead(moeinf_engine* g, const void* const* gate_w_dev, int n_layers, int max_experts) {

@@ -97,6 +97,7 @@ static int ep_route_pack_impl(moeinf_engine* g, int layer, const void* x_dev, in
   CHK(ep_alloc(g, cap_rows));
   RouteArgs ra;
   make_route_args(g, x_dev, gate_w_dev, T, ra);
+  if (g->route_v3) ra.e_bias = g->gate_bias[layer];
   IndexArgs ia;
   make_index_args(g, T, batch_rows, nullptr, ia);
   ia.shared = 0;  // the owner-side index is built from the received rows; the shared expert never crosses the fabric
@@ -549,7 +550,7 @@ static bool ep_bcast_eligible(const moeinf_engine* g, int tokens) {
   const int et = g->cfg.expert_type;
   // consumer kernels must poll for themselves (the broadcast rides in FFN stage 1: no room for a wait kernel in front of it)
   return env && g->ep_uniform && tokens == 1 && g->ep_peer_poll && g->K <= 8 && g->E <= 64 && g->dt != DT_F32 &&
-         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1)) &&
+         (g->cfg.router_kind == MOEINF_ROUTER_MIXTRAL || (g->cfg.router_kind == MOEINF_ROUTER_DEEPSEEK && g->cfg.n_group <= 1 && !g->route_v3)) &&
          (et == MOEINF_EXPERT_MIXTRAL || et == MOEINF_EXPERT_DEEPSEEK) && (!g->has_shared || can_hide_shared(g, 1));
 }
 
@@ -575,6 +576,7 @@ static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev,
   ep_peer_view(g, &pv);
   RouteArgs ra;
   make_route_args(g, x_dev, gate_w_dev, 1, ra);
+  if (g->route_v3) ra.e_bias = g->gate_bias[layer];
   drop_stale_prefetches(g, layer);
   MirrorPlan mp;
   CHK(plan_mirror(g, layer, mp));

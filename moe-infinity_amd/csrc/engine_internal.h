@@ -230,6 +230,8 @@ struct moeinf_engine {
   std::vector<int> la_list;            // node indices predicted for the next layer, best first
   int num_cus = 0;                     // of THIS engine's device
   int layer1_switch_wgs_per_cu = -1;   // occupancy of the one-launch Switch kernel (asked once per engine)
+  bool route_v3 = false;               // MOEINF_ROUTER_DEEPSEEK_V3: cfg.router_kind is stored as DEEPSEEK
+  std::vector<const float*> gate_bias; // ... per layer: e_score_correction_bias (borrowed device pointers)
   bool route_no_renorm = false;        // MOEINF_ROUTER_SOFTMAX_TOPK (Grok / Arctic): cfg.router_kind is stored as MIXTRAL
   uint8_t* h_keep = nullptr;           // moeinf_dispatch_mask_subset: pinned byte per expert
   hipEvent_t busy_mark = nullptr;  // stop event of the latest-ending copy interval accounted so far (union of the lanes' busy time)

@@ -796,6 +796,10 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
   ssum = wave_sum(ssum);
 #pragma unroll
   for (int j = 0; j < 4; ++j) p[j] = p[j] / ssum;
+  if (a.kind == 1 && a.v3) {  // DeepSeek-V3 (modeling_deepseek_v3 MoEGate, :478-479): scores = sigmoid(logits), no softmax
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int e = lane + 64 * j; p[j] = (e < E) ? 1.0f / (1.0f + expf(-l[j])) : 0.f; }
+  }
 
   const int xdt = a.x_dtype;  // the model dtype: quantities the reference keeps in it are rounded to it
   int sel[8];
@@ -805,11 +809,58 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
   for (int k = 0; k < 8; ++k) { sel[k] = -1; val[k] = 0.f; valid[k] = 1; }
   uint32_t taken = 0;
 
-  if (a.kind == 0 /*MIXTRAL*/ || (a.kind == 1 /*DEEPSEEK*/ && a.n_group <= 1)) {
+  if (a.kind == 0 /*MIXTRAL*/ || (a.kind == 1 /*DEEPSEEK*/ && a.n_group <= 1 && !a.v3)) {
     for (int k = 0; k < K; ++k) {
       float bv; int bi;
       pick_best(p, taken, lane, E, bv, bi);
       sel[k] = bi; val[k] = bv;
+      if (bi >= 0 && (bi & 63) == lane) taken |= 1u << (bi >> 6);
+    }
+  } else if (a.kind == 1 && a.v3) {  // noaux_tc (modeling_deepseek_v3/modeling_deepseek.py:484-512)
+    const int gs = E / a.n_group;
+    float sfc[4];  // scores_for_choice = scores + e_score_correction_bias
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int e = lane + 64 * j; sfc[j] = (e < E) ? p[j] + (a.e_bias ? a.e_bias[e] : 0.f) : -INFINITY; }
+    // group score = the sum of the group's two best scores_for_choice; lane g (< n_group) ends up holding group g's
+    float gscore = -INFINITY;
+    for (int g = 0; g < a.n_group; ++g) {
+      float s2 = 0.f;
+      uint32_t tk = 0;  // (per lane: which of its four columns are taken inside this group's top-2 search)
+      for (int r = 0; r < 2; ++r) {
+        float bv = -INFINITY; int bi = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = lane + 64 * j;
+          if (e < E && e / gs == g && !((tk >> j) & 1u) && (bi < 0 || sfc[j] > bv)) { bv = sfc[j]; bi = e; }
+        }
+        wave_argmax(bv, bi);
+        if (bi >= 0) { s2 += bv; if ((bi & 63) == lane) tk |= 1u << (bi >> 6); }
+      }
+      if (lane == g) gscore = s2;
+    }
+    uint64_t gmask = 0;
+    bool gtaken = false;
+    for (int k = 0; k < a.topk_group; ++k) {
+      float bv = gscore; int bi = (lane < a.n_group && !gtaken) ? lane : -1;
+      wave_argmax(bv, bi);
+      if (bi == lane) gtaken = true;
+      if (bi >= 0) gmask |= 1ull << bi;
+    }
+    float pm[4];  // masked_fill(~score_mask, 0.0) of scores_for_choice
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j;
+      pm[j] = (e < E && ((gmask >> (e / gs)) & 1ull)) ? sfc[j] : 0.f;
+    }
+    for (int k = 0; k < K; ++k) {
+      float bv; int bi;
+      pick_best(pm, taken, lane, E, bv, bi);
+      sel[k] = bi;
+      // the WEIGHT is the un-biased score of the chosen expert (scores.gather, :513)
+      float sc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (lane + 64 * j == bi) sc = p[j];
+      val[k] = wave_sum(sc);
       if (bi >= 0 && (bi & 63) == lane) taken |= 1u << (bi >> 6);
     }
   } else if (a.kind == 1) {  // group_limited_greedy (modeling_deepseek.py:484-503)
@@ -883,7 +934,11 @@ __device__ __forceinline__ void route_core(const RouteArgs& a, const int t, cons
     if (a.no_renorm) den = 1.f;  // Grok / Arctic: the softmax probabilities themselves, cast to the model dtype (x / 1.0f is exact)
     for (int k = 0; k < K; ++k) w[k] = round_model(xdt, val[k] / den);
   } else if (a.kind == 1) {
-    if (K > 1 && a.norm_topk_prob) {
+    if (a.v3) {  // V3: normalise (if asked), then ALWAYS the scaling factor (:519-524)
+      float den = 1.f;
+      if (K > 1 && a.norm_topk_prob) { den = 0.f; for (int k = 0; k < K; ++k) den += val[k]; den += 1e-20f; }
+      for (int k = 0; k < K; ++k) w[k] = (K > 1 && a.norm_topk_prob ? val[k] / den : val[k]) * a.scale;
+    } else if (K > 1 && a.norm_topk_prob) {
       float den = 0.f;
       for (int k = 0; k < K; ++k) den += val[k];
       den += 1e-20f;

@@ -201,6 +201,8 @@ struct RouteArgs {
   int32_t* pair_valid;  // [T,K]
   int32_t* pair_order;  // [T,K] k-indices sorted by ascending expert id
   float* router_prob;   // [T] (Switch: max prob)
+  int v3;               // kind DEEPSEEK only: 1 = DeepSeek-V3's gate (sigmoid scores, e_score_correction_bias, top-2-sum groups; modeling_deepseek_v3 MoEGate)
+  const float* e_bias;  // ... its e_score_correction_bias [E] (fp32, device), or nullptr = zeros
   int no_renorm;        // kind MIXTRAL only: 1 = the top-k probabilities are NOT renormalised (Grok / Arctic, grok.py:38-45)
 };
 hipError_t launch_gate_logits(const RouteArgs& a, hipStream_t st);

@@ -306,6 +306,17 @@ class MoEEngine:
         check(self.lib.moeinf_set_predictor(self._h, tracer._h if tracer is not None else None, int(seq_id), int(lookahead_layers),
                                             float(min_share), int(max_experts)))
 
+    def set_gate_bias(self, layer: int, bias: Optional[torch.Tensor]):
+        """DeepSeek-V3's e_score_correction_bias of one layer (moeinf_set_gate_bias): [num_experts] fp32 on the engine's device,
+        borrowed (kept alive here); None = zeros"""
+        if bias is not None:
+            if bias.device != self.device or bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != self.cfg.num_experts:
+                raise ValueError("set_gate_bias: a contiguous fp32 [num_experts] tensor on the engine's device")
+        if not hasattr(self, "_gate_bias"):
+            self._gate_bias = {}
+        self._gate_bias[int(layer)] = bias
+        check(self.lib.moeinf_set_gate_bias(self._h, int(layer), None if bias is None else C.c_void_p(bias.data_ptr())))
+
     def set_lookahead(self, gates: Optional[Sequence[torch.Tensor]], max_experts: int = 0):
         """next-layer gate lookahead (moeinf_set_lookahead): ``gates`` = every layer's gate weight [E, H] on this engine's
         device, in layer order (borrowed: keep them alive); None turns it off.  ``max_experts``: predictions issued per

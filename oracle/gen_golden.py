@@ -246,6 +246,44 @@ def gen_deepseek(mods, name, b, s, h, f, e, k, n_shared, seed, topk_method="gree
     print(name, "ok", out.float().abs().mean().item())
 
 
+def gen_deepseek_v3(mods, name, b, s, h, f, e, k, n_shared, seed, n_group, topk_group, norm_topk_prob=True, scaling=2.5, dtype=torch.bfloat16):
+    """DeepseekMoEBlock with the V3 gate (deepseek.py:22-26: MoEGate of modeling_deepseek_v3, sigmoid scores + e_score_correction_bias
+    + top-2-sum group selection, modeling_deepseek_v3/modeling_deepseek.py:466-528).  The bias is seeded N(0, 0.1^2) fp32 (it is a
+    learned parameter; the model dtype cast of the block turns it into bf16 like every parameter: the golden stores what the gate used)."""
+    import importlib
+
+    importlib.import_module("moe_infinity.models.modeling_deepseek_v3")
+    from moe_infinity.models.modeling_deepseek_v3.configuration_deepseek import DeepseekV3Config
+
+    cfg = DeepseekV3Config(hidden_size=h, moe_intermediate_size=f, n_routed_experts=e, num_experts_per_tok=k, n_shared_experts=n_shared,
+                           n_group=n_group, topk_group=topk_group, norm_topk_prob=norm_topk_prob, routed_scaling_factor=scaling,
+                           num_hidden_layers=1, vocab_size=32, bos_token_id=None, eos_token_id=None)
+    assert cfg.model_type == "deepseek_v3" and cfg.scoring_func == "sigmoid" and cfg.topk_method == "noaux_tc"
+    blk = mods["deepseek"].DeepseekMoEBlock(cfg).to(dtype).eval()
+    gate, experts, shared = make_weights("deepseek", h, f, e, seed, dtype, n_shared=n_shared or 0)
+    g = torch.Generator().manual_seed(9000 + seed)
+    bias = (torch.randn(e, generator=g) * 0.1).to(dtype)  # the block's parameters are in the model dtype
+    with torch.no_grad():
+        blk.gate.weight.copy_(gate)
+        blk.gate.e_score_correction_bias.copy_(bias)
+        mlps = list(blk.experts) + ([blk.shared_experts] if n_shared else [])
+        for ex, (g_, u_, d_) in zip(mlps, experts + ([shared] if n_shared else [])):
+            ex.gate_proj.weight.copy_(g_)
+            ex.up_proj.weight.copy_(u_)
+            ex.down_proj.weight.copy_(d_)
+    blk.layer_id = 0
+    blk.expert_executor = make_executor(mods, FakeDispatcher(lambda i: blk.experts[i]))
+    x = acts(b * s, h, dtype, 2024 + seed).reshape(b, s, h)
+    with torch.no_grad():
+        out = blk(x)
+        gi, gw = blk.gate(x)[:2]
+    np.savez_compressed(os.path.join(OUT, name), x=npf(x), out=npf(out), topk_idx=npf(gi), topk_w=npf(gw), e_bias=npf(blk.gate.e_score_correction_bias),
+                        meta=np.array([b, s, h, f, e, k, n_shared or 0, seed]),
+                        cfg=np.array(["noaux_tc", str(n_group), str(topk_group), str(int(norm_topk_prob)), str(scaling)]),
+                        wsum=checksum(gate, experts, shared))
+    print(name, "ok", out.float().abs().mean().item())
+
+
 class _NoCuda:
     """The Switch/NLLB blocks ship router stats to "cuda:0" (switch_transformers.py:110-113,
     nllb_moe.py:106-109); on the CPU-only build box those .to() calls become no-ops."""
@@ -433,6 +471,9 @@ def main():
     gen_deepseek(mods, "deepseek_prefill_t40.npz", 2, 20, 256, 176, 64, 6, 2, seed=5)
     gen_deepseek(mods, "deepseek_group_t16.npz", 1, 16, 256, 176, 64, 6, 2, seed=6, topk_method="group_limited_greedy",
                  n_group=8, topk_group=3, norm_topk_prob=True, scaling=16.0)
+    gen_deepseek_v3(mods, "deepseekv3_decode_b1.npz", 1, 1, 256, 176, 64, 6, 1, seed=15, n_group=8, topk_group=4)
+    gen_deepseek_v3(mods, "deepseekv3_prefill_t40.npz", 2, 20, 256, 176, 64, 6, 1, seed=16, n_group=8, topk_group=4)
+    gen_deepseek_v3(mods, "deepseekv3_e256_t24.npz", 1, 24, 256, 176, 256, 8, 1, seed=17, n_group=8, topk_group=4)
     gen_switch(mods, "switch_decode_b1.npz", 1, 1, 192, 384, 8, 64, seed=7)
     gen_switch(mods, "switch_prefill_cap.npz", 2, 40, 192, 384, 8, 6, seed=8)
     gen_nllb(mods, "nllb_decode_b8.npz", 8, 1, 256, 512, 16, seed=9)

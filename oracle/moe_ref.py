@@ -136,6 +136,32 @@ def route_deepseek(
     return topk_idx, topk_weight, logits
 
 
+def route_deepseek_v3(x2d: torch.Tensor, wg: torch.Tensor, top_k: int, e_bias: torch.Tensor, n_group: int, topk_group: int,
+                      norm_topk_prob: bool = True, routed_scaling_factor: float = 1.0):
+    """moe_infinity/models/modeling_deepseek_v3/modeling_deepseek.py:466-528 (MoEGate.forward, scoring_func "sigmoid",
+    topk_method "noaux_tc").  Everything in fp32: scores = sigmoid(logits); scores_for_choice = scores +
+    e_score_correction_bias; a group's score = the sum of its two best scores_for_choice; the topk_group best groups stay,
+    the others' candidates are filled with 0.0; top-k over that; the WEIGHTS are the un-biased scores of the chosen experts,
+    normalised (sum + 1e-20) if norm_topk_prob and ALWAYS multiplied by routed_scaling_factor.  ``sorted=False`` in the
+    reference: only the per-token set (idx -> weight) is defined; this returns descending order of scores_for_choice."""
+    n = x2d.shape[0]
+    logits = gate_logits(x2d.float(), wg.float(), torch.float32)
+    scores = logits.sigmoid()
+    sfc = scores + e_bias.float().unsqueeze(0)
+    group_scores = sfc.view(n, n_group, -1).topk(2, dim=-1)[0].sum(dim=-1)
+    group_idx = topk_lowest_index(group_scores, topk_group)[1]
+    group_mask = torch.zeros_like(group_scores)
+    group_mask.scatter_(1, group_idx, 1)
+    score_mask = group_mask.unsqueeze(-1).expand(n, n_group, scores.shape[1] // n_group).reshape(n, -1)
+    tmp_scores = sfc.masked_fill(~score_mask.bool(), 0.0)
+    _, topk_idx = topk_lowest_index(tmp_scores, top_k)
+    topk_weight = scores.gather(1, topk_idx)
+    if top_k > 1 and norm_topk_prob:
+        topk_weight = topk_weight / (topk_weight.sum(dim=-1, keepdim=True) + 1e-20)
+    topk_weight = topk_weight * routed_scaling_factor
+    return topk_idx, topk_weight, logits
+
+
 def route_switch(x3d: torch.Tensor, wg: torch.Tensor, expert_capacity: int, router_dtype=torch.float32):
     """HF ``SwitchTransformersTop1Router`` (transformers 4.37-era semantics the reference
     expects: returns ``(expert_index one-hot, router_probs, router_logits)``), called at
@@ -347,7 +373,10 @@ def block_deepseek(x3d, wg, experts, top_k, shared=None, layer_id=0, **gate_kw) 
     always-resident shared expert [gate_proj, up_proj, down_proj] (deepseek.py:133-136)."""
     b, s, h = x3d.shape
     x = x3d.reshape(-1, h)
-    idx, w, logits = route_deepseek(x, wg, top_k, **gate_kw)
+    if "e_bias" in gate_kw:  # DeepSeek-V3's gate (deepseek.py:22-26 picks MoEGate of modeling_deepseek_v3); the block is the same
+        idx, w, logits = route_deepseek_v3(x, wg, top_k, **gate_kw)
+    else:
+        idx, w, logits = route_deepseek(x, wg, top_k, **gate_kw)
     router_mask, weights_mask = masks_from_topk(idx, w, wg.shape[0])
     final = torch.zeros((b * s, h), dtype=x.dtype)
     res = dispatch_local(x, router_mask, layer_id, experts, DEEPSEEK_DENSE_ACT_DENSE)

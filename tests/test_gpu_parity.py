@@ -57,6 +57,44 @@ def test_mixtral_golden(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["deepseekv3_decode_b1.npz", "deepseekv3_prefill_t40.npz", "deepseekv3_e256_t24.npz"])
+def test_deepseek_v3_gate_golden(name):
+    """MOEINF_ROUTER_DEEPSEEK_V3 (round 6): sigmoid scores + e_score_correction_bias, groups ranked by the sum of their two best,
+    weights normalised then scaled (modeling_deepseek_v3/modeling_deepseek.py:466-528) — against the reference block's own routing
+    and output (oracle/gen_golden.py gen_deepseek_v3; 64 experts in 8 groups, and DeepSeek-V3's own 256 experts / top-8)."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    z = load_golden(name)
+    b, s, h, f, e, k, n_shared, seed = [int(v) for v in z["meta"]]
+    _method, n_group, topk_group, norm, scaling = [str(v) for v in z["cfg"]]
+    gate, experts, shared = make_weights("deepseek", h, f, e, seed, torch.bfloat16, n_shared=n_shared)
+    np.testing.assert_array_equal(checksum(gate, experts, shared), z["wsum"])
+    eng = MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=Cf.EXPERT_DEEPSEEK, hidden=h, inter=f, top_k=k,
+                                    router_kind=Cf.ROUTER_DEEPSEEK_V3, shared_inter=f * n_shared, norm_topk_prob=bool(int(norm)),
+                                    routed_scaling_factor=float(scaling), n_group=int(n_group), topk_group=int(topk_group),
+                                    device_memory_ratio=0.5, max_tokens=b * s))
+    register_all(eng, experts, shared)
+    bias = tt(z["e_bias"], torch.float32).to(DEV)
+    eng.set_gate_bias(0, bias)
+    x = tt(z["x"], torch.bfloat16)
+    ref = R.block_deepseek(x, gate, experts, k, shared=shared, e_bias=bias.cpu(), n_group=int(n_group), topk_group=int(topk_group),
+                           norm_topk_prob=bool(int(norm)), routed_scaling_factor=float(scaling))
+    want_sets = np.sort(z["topk_idx"].astype(np.int64), axis=-1)
+    for rnd in range(2):  # decision path, then the sync-free path
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        r = eng.routing()
+        assert np.array_equal(np.sort(r["topk_idx"].astype(np.int64), axis=-1), want_sets), f"round {rnd}: routing sets vs the reference's gate"
+        got = np.zeros((b * s, e), np.float32)
+        np.put_along_axis(got, r["topk_idx"].astype(np.int64), r["topk_w"], axis=1)
+        want = np.zeros((b * s, e), np.float32)
+        np.put_along_axis(want, z["topk_idx"].astype(np.int64), z["topk_w"].astype(np.float32), axis=1)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+        assert_block_close(out, ref, torch.bfloat16, f"round {rnd}: block output vs oracle")
+        assert_block_close(out, ref, torch.bfloat16, f"round {rnd}: block output vs reference golden", golden=tt(z["out"], torch.float32))
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["grok_decode_b1.npz", "grok_prefill_t40.npz"])
 def test_grok_golden(name):
     """MOEINF_ROUTER_SOFTMAX_TOPK (round 6): the Grok / Arctic router — softmax -> top-k, NO renormalisation

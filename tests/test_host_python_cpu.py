@@ -187,9 +187,10 @@ def test_reference_expert_prefetcher_drives_the_adapter_unmodified():
     assert flat(ref_eng.calls)[1] == [(2, 3), (1, 0), (1, 2), (2, 1)], "descending predicted share"
 
 
-def test_the_deepseek_v3_gate_is_refused_not_misrouted():
-    """modeling_deepseek_v3/modeling_deepseek.py:443-483 scores with a sigmoid plus a correction bias and picks groups by
-    their top-2 sum; the fused DeepSeek router implements V2's softmax rule only, so a V3 config must fail loudly."""
+def test_the_deepseek_v3_gate_is_its_own_router_kind_and_other_mixes_are_refused():
+    """modeling_deepseek_v3/modeling_deepseek.py:466-528 scores with a sigmoid plus a correction bias and picks groups by their
+    top-2 sum: MOEINF_ROUTER_DEEPSEEK_V3 since round 6.  Any other mix of scoring function and top-k method (a sigmoid with V2's
+    greedy rule, noaux_tc over softmax scores) must still fail loudly instead of being routed with V2's softmax rule."""
     import types
 
     from moe_infinity_amd.blocks import DeepseekMoEBlock
@@ -197,8 +198,10 @@ def test_the_deepseek_v3_gate_is_refused_not_misrouted():
                 norm_topk_prob=False, routed_scaling_factor=1.0, n_group=None, topk_group=None)
     ok = DeepseekMoEBlock.engine_config(types.SimpleNamespace(topk_method="greedy", **base), 1, max_tokens=4)
     assert ok.router_kind == Cf.ROUTER_DEEPSEEK and ok.num_experts == 8
-    for bad in (dict(topk_method="noaux_tc", scoring_func="sigmoid"), dict(topk_method="greedy", scoring_func="sigmoid"),
-                dict(topk_method="noaux_tc")):
+    v3 = DeepseekMoEBlock.engine_config(types.SimpleNamespace(**{**base, "topk_method": "noaux_tc", "scoring_func": "sigmoid", "n_group": 4, "topk_group": 2,
+                                                                  "norm_topk_prob": True, "routed_scaling_factor": 2.5}), 1, max_tokens=4)
+    assert v3.router_kind == Cf.ROUTER_DEEPSEEK_V3 and (v3.n_group, v3.topk_group, v3.norm_topk_prob, v3.routed_scaling_factor) == (4, 2, True, 2.5)
+    for bad in (dict(topk_method="greedy", scoring_func="sigmoid"), dict(topk_method="noaux_tc")):
         with pytest.raises(NotImplementedError, match="expert_dispatcher"):
             DeepseekMoEBlock.engine_config(types.SimpleNamespace(**{**base, **bad}), 1, max_tokens=4)
 

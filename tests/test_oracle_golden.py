@@ -91,6 +91,28 @@ def test_deepseek_block_matches_reference(name):
     assert_close_model_dtype(r.out, t(z["out"], torch.float32), torch.bfloat16, "out")
 
 
+@pytest.mark.parametrize("name", ["deepseekv3_decode_b1.npz", "deepseekv3_prefill_t40.npz", "deepseekv3_e256_t24.npz"])
+def test_deepseek_v3_gate_block_matches_reference(name):
+    """DeepseekMoEBlock with the V3 gate (modeling_deepseek_v3 MoEGate: sigmoid scores, e_score_correction_bias, top-2-sum group
+    selection, weights normalised then scaled): the reference block's own output and routing (oracle/gen_golden.py gen_deepseek_v3)."""
+    z = load(name)
+    b, s, h, f, e, k, n_shared, seed = [int(v) for v in z["meta"]]
+    method, n_group, topk_group, norm, scaling = [str(v) for v in z["cfg"]]
+    assert method == "noaux_tc"
+    gate, experts, shared = make_weights("deepseek", h, f, e, seed, torch.bfloat16, n_shared=n_shared)
+    np.testing.assert_allclose(checksum(gate, experts, shared), z["wsum"], rtol=0, atol=0)
+    x = t(z["x"], torch.bfloat16)
+    r = R.block_deepseek(x, gate, experts, k, shared=shared, e_bias=t(z["e_bias"], torch.float32), n_group=int(n_group), topk_group=int(topk_group),
+                         norm_topk_prob=bool(int(norm)), routed_scaling_factor=float(scaling))
+    ref_idx = t(z["topk_idx"], torch.int64)
+    assert torch.equal(r.topk_idx.sort(-1).values, ref_idx.sort(-1).values), "routing sets must be bit-exact"
+    # weights: compare as idx -> weight maps (sorted=False in the reference)
+    got = torch.zeros(ref_idx.shape[0], e).scatter_(1, r.topk_idx, r.topk_w.float())
+    want = torch.zeros(ref_idx.shape[0], e).scatter_(1, ref_idx, t(z["topk_w"], torch.float32))
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert_close_model_dtype(r.out, t(z["out"], torch.float32), torch.bfloat16, "out")
+
+
 @pytest.mark.parametrize("name", ["switch_decode_b1.npz", "switch_prefill_cap.npz"])
 def test_switch_block_matches_reference(name):
     z = load(name)
