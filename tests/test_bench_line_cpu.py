@@ -87,3 +87,13 @@ def test_the_offload_leg_gets_every_local_it_needs_from_run_workload():
             local.add((n.asname or n.name).split(".")[0])
     missing = [k for k in offload.NEEDS if k not in local]
     assert not missing, missing
+
+
+def test_every_tool_and_bench_leg_compiles():
+    """tools/*.py and bench_legs/*.py only run on the GPU box: a syntax error there costs a GPU lease"""
+    import glob
+
+    files = glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "bench_legs", "*.py")) + [os.path.join(ROOT, "bench.py")]
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, "exec")
