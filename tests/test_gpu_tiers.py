@@ -346,3 +346,21 @@ def test_next_layer_gate_lookahead_issues_the_next_layers_experts_and_changes_no
             e2.set_lookahead(gates[:2])
         finally:
             e2.close()
+
+
+@pytest.mark.parametrize("env", [{"MOEINF_H2D_PULL": "0"}, {"MOEINF_H2D_PULL": "0", "MOEINF_H2D_WHOLE_BLOB_MB": "0"}],
+                         ids=["sdma_whole_blob_copies", "sdma_tensor_by_tensor"])
+def test_the_sdma_forms_of_the_tier_mover_stay_parity_green(env):
+    """The pull form is the default tier mover (round 6); the SDMA forms behind MOEINF_H2D_PULL=0 — whole-blob copies + one re-tile
+    launch, or tensor by tensor with stage-1-first order (MOEINF_H2D_WHOLE_BLOB_MB=0: the round-5 form) — remain the fallback for
+    blobs whose vectors are not 16-byte multiples and the A/B baseline.  The miss-path tests and the golden-vector tests in a child
+    process with the knobs set (the engine reads them once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_tiers.py"), os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-k",
+                        "demand_misses or overtakes or budget_can_shrink or lookahead or mixtral_golden or deepseek_golden or nllb_golden or switch_golden"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
