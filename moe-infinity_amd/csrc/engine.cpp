@@ -1682,6 +1682,7 @@ extern "C" int moeinf_dispatch_mask_subset(moeinf_engine* g, int layer, const vo
   }
   if (counts_host) memcpy(counts_host, g->h_mirror + 1, (size_t)E * sizeof(int32_t));
   // the shared pseudo-expert is not part of a mask dispatch (the reference runs it in Python, deepseek.py:133-136)
+  g->la_list.clear();  // (gate-lookahead predictions belong to the fused forward that made them)
   CHK(run_experts(g, layer, x_dev, st, nullptr, nullptr, nullptr));
   if (rows > 0) HIPCHK(hipMemcpyAsync(y_dev, g->d_y, (size_t)rows * g->H * g->es, hipMemcpyDeviceToDevice, st));
   g->last_T = tokens; g->last_layer = layer; g->last_stream = st;
