@@ -84,7 +84,9 @@ def fill_experts(eng, cfg, rank, world, dev, seed=1234):
     g = torch.Generator(device=dev)
     off, siz, tot = eng.expert_layout(0)
     dt = eng.dtype
+    hd = eng.host_dtype  # (fp8 experts: e4m3fn bytes in the host tier, N(0, 0.02^2) drawn in bf16 and cast)
     es = 4 if dt == torch.float32 else 2
+    hes = 1 if hd != dt else es
     t0 = time.time()
     n = 0
     for l in range(cfg.num_layers):
@@ -92,8 +94,8 @@ def fill_experts(eng, cfg, rank, world, dev, seed=1234):
             if e % world != rank:
                 continue
             eng.register_expert(l, e, None)
-            host = eng.expert_host_view(l, e).view(dt)
-            host.copy_(expert_blob(g, l, e, tot // es, dt, dev, seed))
+            host = eng.expert_host_view(l, e).view(hd)
+            host.copy_(expert_blob(g, l, e, tot // hes, dt, dev, seed).to(hd))
             n += 1
     shared_host = {}
     if cfg.shared_inter:
@@ -102,9 +104,9 @@ def fill_experts(eng, cfg, rank, world, dev, seed=1234):
             g.manual_seed(seed + l * 1000 + 999)
             parts = []
             for s in sizs:
-                t = torch.empty(s // es, dtype=dt, device=dev)
+                t = torch.empty(s // hes, dtype=dt, device=dev)
                 t.normal_(0.0, 0.02, generator=g)
-                parts.append(t.cpu())
+                parts.append(t.cpu().to(hd).to(dt))  # (what the engine holds after its up-cast: the oracle's weights)
             eng.register_shared(l, parts)
             shared_host[l] = parts
     torch.cuda.synchronize(dev)
@@ -119,8 +121,8 @@ def host_expert_tensors(eng, cfg, layer, expert, owned=True, dev=None):
     if owned:
         raw = eng.expert_host_view(layer, expert)
     else:
-        es = 4 if eng.dtype == torch.float32 else 2
-        raw = expert_blob(torch.Generator(device=dev), layer, expert, tot // es, eng.dtype, dev).cpu().view(torch.uint8)
+        hes = 1 if eng.host_dtype != eng.dtype else (4 if eng.dtype == torch.float32 else 2)
+        raw = expert_blob(torch.Generator(device=dev), layer, expert, tot // hes, eng.dtype, dev).to(eng.host_dtype).cpu().view(torch.uint8)
     H, F = cfg.hidden, cfg.inter
     from moe_infinity_amd import config as Cf
 
@@ -132,7 +134,9 @@ def host_expert_tensors(eng, cfg, layer, expert, owned=True, dev=None):
         shapes = [(F, H), (H, F)]
     else:
         shapes = [(F, H), (F,), (H, F), (H,)]
-    return [raw[o:o + s].view(eng.dtype).reshape(sh) for o, s, sh in zip(off, siz, shapes)]
+    # (fp8 experts: the oracle runs on the UP-CAST weights — y = FFN(x; W.to(bf16)) is what the engine computes)
+    return [raw[o:o + s].view(eng.host_dtype).reshape(sh).to(eng.dtype) if eng.host_dtype != eng.dtype else raw[o:o + s].view(eng.dtype).reshape(sh)
+            for o, s, sh in zip(off, siz, shapes)]
 
 
 def latest_pmc_traffic(workload_key, kernel_substr):
@@ -204,7 +208,7 @@ def measure_traffic_live(workload, kernel_substr, timeout_s=170):
                                 f"this workload, mean of {vals['FETCH_SIZE'][1]} launches; FETCH_SIZE x2 (gfx950 correction), KiB units")
 
 
-def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, dist, dtype_id=None, sample=None):
+def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, dist, dtype_id=None, sample=None, force_offload=False):
     """One workload end to end.  main=True: every leg; main=False (other_configs): timing + roofline + parity.
     dtype_id: expert dtype override (config.DTYPE_F16: the fp16 legs); sample = (layers, steps) of the CPU / parity sample."""
     from moe_infinity_amd import MoEEngine
@@ -717,6 +721,8 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
     # ---- offload regime (BASELINE configs 2 and 3): bench_legs/offload.py
     from bench_legs import offload as _offload
 
+    offload_frac = args.miss_heavy_frac if (main or force_offload) else (args.offload_frac_other if family == "deepseek" else 0.0)
+
     miss = _offload.offload_regime(types.SimpleNamespace(**{k: v for k, v in locals().items() if k in _offload.NEEDS}))
     res = {"label": label, "family": family, "cfg": cfg, "L": L, "E": E, "K": K, "H": H, "B": B, "dt": dt,
            "tokens_per_s": tokens_per_s, "ms_per_step": ms_per_step, "windows_ms": [round(w * 1e3 / steps, 4) for w in windows],
@@ -786,7 +792,7 @@ def main():
     ap.add_argument("--offload-attn-us", type=float, default=270.1, help="that leg's attention stand-in per layer (profiles/r04_attention_block_time_stock_pytorch.jsonl: DeepSeek-V2-Lite batch 1, context 2048)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short DeepSeek-V2-Lite / NLLB-MoE-54B legs")
     ap.add_argument("--no-fp16-legs", action="store_true", help="skip the fp16-expert legs of other_configs")
-    ap.add_argument("--dtype", default="model", choices=["model", "fp16"], help="fp16: the main leg with fp16 experts (the reference's dtype id 2) instead of the model's own dtype (profiling the fp16 kernels on their own)")
+    ap.add_argument("--dtype", default="model", choices=["model", "fp16", "fp8"], help="fp16: the main leg with fp16 experts (the reference's dtype id 2) instead of the model's own dtype (profiling the fp16 kernels on their own)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the path through prefetch_op.expert_dispatcher as the reference's dispatch_local drives it, timed beside the fused path)")
     ap.add_argument("--dropin-layers", type=int, default=8, help="full-size MoE layers of the drop-in leg (its offload directory holds every expert of them: 8 Mixtral layers = 21 GiB)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic pass (two rocprofv3 --pmc child runs, ~1 min): roofline.traffic then comes from profiles/ (static)")
@@ -828,10 +834,10 @@ def main():
         dist.barrier()
 
     main_dtype = None
-    if args.dtype == "fp16":
+    if args.dtype != "model":
         from moe_infinity_amd import config as Cf_
 
-        main_dtype = Cf_.DTYPE_F16
+        main_dtype = Cf_.DTYPE_F16 if args.dtype == "fp16" else Cf_.DTYPE_F8E4M3
     r = run_workload(args, args.workload, args.batch, world, rank, local_rank, dev, use_ep, True, dist, dtype_id=main_dtype)
     # roofline.traffic measured in THIS run (the main engine is closed: its HBM and pinned memory are free for the children)
     if rank == 0 and world == 1 and not use_ep and not args.no_traffic and r.get("roof"):
@@ -916,6 +922,20 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 log(f"drop-in leg {wl} failed: {ex!r}")
                 dropin[wl] = {"error": repr(ex)}
+
+    # fp8 experts (the reference's dtype id 3, expert_module.h:23): e4m3fn bytes in the host tier and on the link, up-cast to bf16 in the
+    # slot.  Resident decode is bf16's (same slots); what changes is the price of a miss — the offload regime with half the bytes.
+    if rank == 0 and world == 1 and not use_ep and default_main and not args.no_other_configs and not args.no_fp16_legs and not args.no_cpu_baseline:
+        from moe_infinity_amd import config as Cf
+
+        try:
+            o = run_workload(args, "mixtral-8x7b", 1, world, rank, local_rank, dev, False, False, dist, dtype_id=Cf.DTYPE_F8E4M3, sample=(2, 2), force_offload=True)
+            others.append({"workload": f"{o['label']} MoE layers with fp8 (e4m3fn) experts in the host tier (dtype id 3): L={o['L']} E={o['E']} K={o['K']} H={o['H']} F={o['cfg'].inter}, decode batch 1",
+                           "dtype": "fp8->bf16", "batch": 1, "ms_per_step": round(o["ms_per_step"], 4), "tokens_per_s": round(o["tokens_per_s"], 2), "windows_ms": o["windows_ms"],
+                           "parity": o["parity"], "parity_is": "against the oracle on the UP-CAST weights: y = FFN(x; W.to(bf16))", "offload_regime": o.get("miss")})
+        except Exception as ex:  # noqa: BLE001
+            log(f"fp8 leg failed: {ex!r}")
+            others.append({"workload": "mixtral-8x7b fp8", "error": repr(ex)})
 
     parity_ok = True
     if rank == 0:

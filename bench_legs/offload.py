@@ -9,11 +9,11 @@ import torch
 
 HBM_PEAK_GBS = 8000.0
 PCIE_GBS = 63.0
-NEEDS = ('B', 'Cf', 'E', 'H', 'K', 'L', 'args', 'batch_rows', 'dev', 'dt', 'eng', 'family', 'gates', 'label', 'main', 'ms_per_step', 'nsteps', 'out', 'rank', 'st', 'steps', 'use_ep', 'warmup', 'world', 'xs')
+NEEDS = ('offload_frac', 'B', 'Cf', 'E', 'H', 'K', 'L', 'args', 'batch_rows', 'dev', 'dt', 'eng', 'family', 'gates', 'label', 'main', 'ms_per_step', 'nsteps', 'out', 'rank', 'st', 'steps', 'use_ep', 'warmup', 'world', 'xs')
 
 
 def offload_regime(c):
-    B, Cf, E, H, K, L, args, batch_rows, dev, dt, eng, family, gates, label, main, ms_per_step, nsteps, out, rank, st, steps, use_ep, warmup, world, xs = c.B, c.Cf, c.E, c.H, c.K, c.L, c.args, c.batch_rows, c.dev, c.dt, c.eng, c.family, c.gates, c.label, c.main, c.ms_per_step, c.nsteps, c.out, c.rank, c.st, c.steps, c.use_ep, c.warmup, c.world, c.xs
+    offload_frac, B, Cf, E, H, K, L, args, batch_rows, dev, dt, eng, family, gates, label, main, ms_per_step, nsteps, out, rank, st, steps, use_ep, warmup, world, xs = c.offload_frac, c.B, c.Cf, c.E, c.H, c.K, c.L, c.args, c.batch_rows, c.dev, c.dt, c.eng, c.family, c.gates, c.label, c.main, c.ms_per_step, c.nsteps, c.out, c.rank, c.st, c.steps, c.use_ep, c.warmup, c.world, c.xs
     # ---- offload regime (BASELINE configs 2 and 3): the same engine with the expert cache cut to a byte budget.
     # One sub-leg = (routing, replacement policy, attention stand-in, speculation): cache flushed, two settling steps, counters
     # reset, `msteps` decode steps timed.  Routing "natural" = what the random gate produces (uniform over experts: the hit
@@ -21,7 +21,6 @@ def offload_regime(c):
     # (fixed seed) and adds -1.2 ln(rank) to their logits (coordinate 0 of every activation is a constant 4, the gate's column
     # 0 carries the bias / 4), so a few experts per layer are hot — where LFU-in-cache and LRU can differ.
     miss = None
-    offload_frac = args.miss_heavy_frac if main else (args.offload_frac_other if family == "deepseek" else 0.0)
     if rank == 0 and world == 1 and not use_ep and offload_frac > 0 and not args.budget_gib:
         import numpy as np
 
@@ -169,7 +168,8 @@ def offload_regime(c):
         eng.set_cache_budget(budget)
         base = offload_leg("natural", args.policy, False, False, msteps)
         mel, ms_, misses, link = base.pop("_raw")
-        bound_ms = misses * slot / (56.0e9) * 1e3 / msteps  # every miss crosses the link once at the measured 56 GB/s
+        link_bytes = ms_["h2d_bytes"] / max(1, misses)  # bytes one miss moves over the link (= the host blob: half a slot for fp8 experts)
+        bound_ms = misses * link_bytes / (56.0e9) * 1e3 / msteps  # every miss crosses the link once at the measured 56 GB/s
         miss = {"what": f"{label}, expert cache = {offload_frac:.0%} of the expert bytes ({budget / 2**30:.1f} GiB, "
                         f"{ms_['slots_total']} of {L * E} experts), on-demand fetches only, natural routing, {args.policy}",
                 **{k: v for k, v in base.items() if k not in ("routing", "policy", "speculation", "attention_standin_us_per_layer", "moe_ms_per_token_without_the_standin")},
@@ -179,9 +179,9 @@ def offload_regime(c):
                 # why `overlap` is what it is: one miss is `copy_ms_per_miss` of link time, the compute stream has
                 # `compute_ms_per_layer` of MoE work per layer to put beside it (measured above, every expert cached), and on
                 # demand the copy can only start once the layer has routed — the layer waits for the rest of it
-                "copy_ms_per_miss": None if link is None else round(slot / (link * 1e9) * 1e3, 3),
+                "copy_ms_per_miss": None if link is None else round(link_bytes / (link * 1e9) * 1e3, 3),
                 "compute_ms_per_layer": round(ms_per_step / L, 4),
-                "overlap_ceiling_on_demand": None if link is None else round(min(1.0, (ms_per_step / L) / max(1e-9, (misses / msteps / L) * slot / (link * 1e9) * 1e3)), 4),
+                "overlap_ceiling_on_demand": None if link is None else round(min(1.0, (ms_per_step / L) / max(1e-9, (misses / msteps / L) * link_bytes / (link * 1e9) * 1e3)), 4),
                 "physics": "on-demand: a miss is issued when its layer routes and the layer's FFN needs it at once, so at most "
                            "compute_ms_per_layer of every (misses_per_layer x copy_ms_per_miss) can overlap (overlap_ceiling_on_demand); "
                            "hiding more needs copies issued LAYERS ahead (speculation: the sub-legs below / profiles/r04_prefetch_study_*)"}

@@ -38,7 +38,11 @@ enum {
 };
 
 /* dtype ids: core/parallel/expert_module.h:20-23 (DTYPE_BFLOAT16 0, DTYPE_FLOAT32 1, DTYPE_FLOAT16 2) */
-enum { MOEINF_DTYPE_BF16 = 0, MOEINF_DTYPE_F32 = 1, MOEINF_DTYPE_F16 = 2 };
+enum { MOEINF_DTYPE_BF16 = 0, MOEINF_DTYPE_F32 = 1, MOEINF_DTYPE_F16 = 2,
+       /* the reference's id 3 (core/parallel/expert_module.h:23,118-119 -> torch::kFloat8_e4m3fn): expert blobs are e4m3fn bytes in
+        * the HOST tier and on the link (half of bf16's: half the copy time of every miss), up-cast to bf16 when pulled into their HBM
+        * slot; activations, gate and arithmetic are bf16 — y = FFN(x; W.to(bf16)) (round 6) */
+       MOEINF_DTYPE_F8E4M3 = 3 };
 
 /* expert_type ids: core/parallel/expert_module.h:13-18, moe_infinity/common/constants.py:29-37 */
 enum {

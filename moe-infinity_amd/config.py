@@ -11,6 +11,7 @@ from typing import Optional
 
 # ids shared with include/moeinf.h (and core/parallel/expert_module.h in the reference)
 DTYPE_BF16, DTYPE_F32, DTYPE_F16 = 0, 1, 2
+DTYPE_F8E4M3 = 3  # fp8 (e4m3fn) experts in the host tier, up-cast to bf16 in their HBM slot; activations / gate / arithmetic bf16
 EXPERT_SWITCH, EXPERT_SWITCH_GATED, EXPERT_NLLB, EXPERT_FSGPT, EXPERT_MIXTRAL, EXPERT_DEEPSEEK = 0, 1, 2, 3, 4, 5
 ROUTER_MIXTRAL, ROUTER_DEEPSEEK, ROUTER_SWITCH, ROUTER_NLLB, ROUTER_SOFTMAX_TOPK, ROUTER_DEEPSEEK_V3 = 0, 1, 2, 3, 4, 5
 POLICY_LFU_INCACHE, POLICY_LRU = 0, 1

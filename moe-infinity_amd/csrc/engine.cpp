@@ -11,6 +11,8 @@
 // on a copy and a slot is never recycled while a kernel may still read it.
 #include "engine_internal.h"
 
+#include <math.h>
+
 // ---- host arena ----------------------------------------------------------------------------
 static int arena_alloc(moeinf_engine* g, int64_t bytes, void** out) {
   bytes = align_up(bytes, kAioAlignment);
@@ -72,6 +74,19 @@ extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R
                                                  moeinf::Ring2Knobs::from_env());
   out5[0] = f.ntb; out5[1] = f.tail; out5[2] = f.nblk; out5[3] = f.split; out5[4] = f.blocks;
   return MOEINF_OK;
+}
+
+// OCP e4m3fn (torch.float8_e4m3fn: 1-4-3, bias 7, no infinities, S.1111.111 = NaN) -> bf16 bits; exact (3 mantissa bits)
+static inline uint16_t f8e4m3_to_bf16_bits(uint8_t v) {
+  const uint32_t s = v >> 7, ex = (v >> 3) & 15, m = v & 7;
+  float f;
+  if (ex == 15 && m == 7) f = NAN;
+  else if (ex == 0) f = ldexpf((float)m, -9);
+  else f = ldexpf(1.0f + (float)m * 0.125f, (int)ex - 7);
+  if (s) f = -f;
+  uint32_t bits;
+  memcpy(&bits, &f, 4);
+  return (uint16_t)(bits >> 16);
 }
 
 static int validate(const moeinf_config* c) {
@@ -218,6 +233,16 @@ static void prealloc_slots(moeinf_engine* g);
 extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   if (!out) return fail(MOEINF_ERR_INVALID, "out is NULL");
   *out = nullptr;
+  // fp8 experts (the reference's dtype id 3, core/parallel/expert_module.h:23,118-119): e4m3fn bytes in the HOST tier and on the link,
+  // up-cast to bf16 when an expert is pulled into its HBM slot; activations, gate and all arithmetic are bf16 — y = FFN(x; W.to(bf16)),
+  // what torch::linear over up-cast weights computes.  Everything behind the tier mover sees a bf16 engine.
+  moeinf_config cfg_local;
+  bool host_f8 = false;
+  if (cfg && cfg->dtype == MOEINF_DTYPE_F8E4M3) {
+    cfg_local = *cfg; cfg_local.dtype = MOEINF_DTYPE_BF16; host_f8 = true;
+    if (cfg_local.gate_dtype == MOEINF_DTYPE_F8E4M3) cfg_local.gate_dtype = MOEINF_DTYPE_BF16;
+    cfg = &cfg_local;
+  }
   CHK(validate(cfg));
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -240,8 +265,10 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   g->has_shared = cfg->shared_inter > 0;
   g->dt = cfg->dtype == MOEINF_DTYPE_BF16 ? DT_BF16 : (cfg->dtype == MOEINF_DTYPE_F16 ? DT_F16 : DT_F32);
   g->es = dt_bytes(g->dt);
-  g->lay = make_layout(cfg->expert_type, g->H, g->F, g->es);
-  if (g->has_shared) g->lay_sh = make_layout(cfg->expert_type, g->H, g->Fs, g->es);
+  g->host_f8 = host_f8;
+  g->host_es = host_f8 ? 1 : g->es;
+  g->lay = make_layout(cfg->expert_type, g->H, g->F, g->host_es);
+  if (g->has_shared) g->lay_sh = make_layout(cfg->expert_type, g->H, g->Fs, g->host_es);
   g->dlay = make_dev_layout(cfg->expert_type, g->H, g->F, g->dt, g->es);
   if (g->has_shared) g->dlay_sh = make_dev_layout(cfg->expert_type, g->H, g->Fs, g->dt, g->es);
   g->slot_bytes = g->dlay.total;
@@ -305,7 +332,7 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     TRYHIP(hipMalloc(&g->d_h_sh, (size_t)kHideSharedMaxTokens * g->Fs * g->es));
     TRYHIP(hipMalloc(&g->d_y_sh, (size_t)kHideSharedMaxTokens * g->H * g->es));
   }
-  for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i], kAioAlignment)));
+  for (int i = 0; i < 4; ++i) g->stage_bytes = std::max<int64_t>(g->stage_bytes, std::max(align_up(g->lay.size[i], kAioAlignment), align_up(g->lay_sh.size[i] * (g->host_f8 ? 2 : 1), kAioAlignment)));
   {
     // whole-blob transfers for experts up to MOEINF_H2D_WHOLE_BLOB_MB (64; 0 = always tensor by tensor): DeepSeek-V2-Lite's
     // 16.5 MiB expert was three 5.5 MiB copies with an event pair and a re-tile launch each: 46 GB/s against the 54.5 that
@@ -319,7 +346,15 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     const char* pe = getenv("MOEINF_H2D_PULL");
     g->h2d_pull = (pe ? atoi(pe) != 0 : true) && vec_ok;
     const char* pw = getenv("MOEINF_H2D_PULL_WGS");
-    g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : 16;
+    // 16 workgroups pull bf16 / fp16 / fp32 blobs at the link's rate; an fp8 blob's workgroup also up-casts and writes twice what it
+    // reads, so it takes 32 to keep the link busy (Mixtral miss-heavy leg, 16 layers: 37 GB/s with 16, 55-56 with 32)
+    g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : (g->host_f8 ? 32 : 16);
+    if (g->host_f8) {  // the fp8 pull loads 16 source bytes (sixteen elements) per lane
+      bool ok16 = true;
+      for (int i = 0; i < g->dlay.n; ++i) ok16 = ok16 && (g->dlay.K[i] > 0 ? g->dlay.K[i] % 16 == 0 : g->dlay.size[i] % 32 == 0);
+      if (!ok16) { fail(MOEINF_ERR_UNSUPPORTED, "fp8 experts (dtype 3): hidden / inter (and bias lengths) must be multiples of 16"); return bail(MOEINF_ERR_UNSUPPORTED); }
+    }
+    if (g->host_f8 && !g->h2d_pull) { fail(MOEINF_ERR_UNSUPPORTED, "fp8 experts (dtype 3) are up-cast by the PULL tier mover: not with MOEINF_H2D_PULL=0, nor with bias vectors that are not 16-byte multiples"); return bail(MOEINF_ERR_UNSUPPORTED); }
     if (g->h2d_pull) {
       TRYHIP(hipMalloc((void**)&g->d_copy_ts, (size_t)kCopyTsRing * 32));
       TRYHIP(hipMemset(g->d_copy_ts, 0, (size_t)kCopyTsRing * 32));
@@ -419,8 +454,16 @@ extern "C" int moeinf_register_shared(moeinf_engine* g, int layer, const void* b
   // one-off, synchronous: tensor by tensor through the demand lane's first staging buffer
   HIPCHK(hipStreamSynchronize(g->demand.copy));
   HIPCHK(hipStreamSynchronize(g->demand.retile));
+  std::vector<uint16_t> up;  // fp8 host tier: the (always resident) shared expert is up-cast on the host, once
   for (int i = 0; i < g->dlay_sh.n; ++i) {
-    HIPCHK(hipMemcpyAsync(g->demand.ring[0].dev, (const char*)blob + g->lay_sh.off[i], (size_t)g->lay_sh.size[i], hipMemcpyHostToDevice, g->demand.copy));
+    const void* src = (const char*)blob + g->lay_sh.off[i];
+    size_t bytes = (size_t)g->lay_sh.size[i];
+    if (g->host_f8) {
+      up.resize(bytes);
+      for (size_t j = 0; j < bytes; ++j) up[j] = f8e4m3_to_bf16_bits(((const uint8_t*)src)[j]);
+      src = up.data(); bytes *= 2;
+    }
+    HIPCHK(hipMemcpyAsync(g->demand.ring[0].dev, src, bytes, hipMemcpyHostToDevice, g->demand.copy));
     CHK(retile_tensor(g, g->dlay_sh, i, g->demand.ring[0].dev, g->shared_dev[layer], g->demand.copy));
     HIPCHK(hipStreamSynchronize(g->demand.copy));
   }
@@ -609,7 +652,7 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
     auto pull = [&](int k0, int k1) -> int {
       RetileBlob rb;
       memset(&rb, 0, sizeof rb);
-      rb.src = n.host; rb.dst = s.dev; rb.n = 0;
+      rb.src = n.host; rb.dst = s.dev; rb.n = 0; rb.src_f8 = g->host_f8 ? 1 : 0;
       for (int k = k0; k < k1; ++k) {
         const int i = order[k], j = rb.n++;
         rb.src_off[j] = g->lay.off[i]; rb.dst_off[j] = g->dlay.off[i];

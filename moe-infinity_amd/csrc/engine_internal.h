@@ -230,6 +230,8 @@ struct moeinf_engine {
   std::vector<int> la_list;            // node indices predicted for the next layer, best first
   int num_cus = 0;                     // of THIS engine's device
   int layer1_switch_wgs_per_cu = -1;   // occupancy of the one-launch Switch kernel (asked once per engine)
+  bool host_f8 = false;                // dtype id 3: fp8 (e4m3fn) experts in the host tier, bf16 slots and arithmetic
+  int64_t host_es = 2;                 // bytes per element of the HOST blob (1 with host_f8, else es)
   bool route_v3 = false;               // MOEINF_ROUTER_DEEPSEEK_V3: cfg.router_kind is stored as DEEPSEEK
   std::vector<const float*> gate_bias; // ... per layer: e_score_correction_bias (borrowed device pointers)
   bool route_no_renorm = false;        // MOEINF_ROUTER_SOFTMAX_TOPK (Grok / Arctic): cfg.router_kind is stored as MIXTRAL

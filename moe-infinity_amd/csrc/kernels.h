@@ -179,6 +179,7 @@ struct RetileBlob {
   int n;
   int64_t src_off[4], dst_off[4];
   int R[4], K[4];
+  int src_f8;  // pull form only: the source blob holds fp8 (e4m3fn) elements, the slot bf16 (1 source byte per destination element)
 };
 hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st);
 // the same from PINNED HOST memory (b.src = device-visible host pointer): the tier mover's pull form, `workgroups` x 256 threads

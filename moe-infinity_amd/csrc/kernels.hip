@@ -100,26 +100,54 @@ hipError_t launch_retile_blob(const RetileBlob& b, int dtype, hipStream_t st) {
 // that read the 64-byte row pieces of a tile directly pulled 21-35 GB/s: sixteen 64-byte requests per wave-load to sixteen
 // different pages; contiguous KiBs reach the link's 56), the rows cross through LDS, and the workgroup writes sixteen 1-KiB tiles.
 // The loads of unit i+1 are in flight while unit i leaves LDS.  A bias vector is copied in 16-KiB units.
-template <typename T>
+template <typename T, bool F8>  // F8: the host blob holds fp8 (e4m3fn) elements — half the bytes on the link —, up-cast to bf16 (T) on the way in
 __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned long long* ts, int first) {
   // link-busy timing WITHOUT queue packets (an event record between two kernels of a stream costs ~10 us, and the engine's timers
   // were two per copy: -5.5 % ms/token on the DeepSeek offload leg): ts[0] = start tick of the copy's first launch, ts[1] = max
   // end tick over its workgroups, ts[2] = workgroups that have finished (all three only ever grow: no re-initialisation)
   if (ts && first && blockIdx.x == 0 && threadIdx.x == 0) ts[0] = (unsigned long long)wall_clock64();
-  constexpr int EPV = DT<T>::EPV;          // elements per 16 bytes
+  constexpr int EPV = DT<T>::EPV;          // elements per 16 bytes of the SLOT's dtype
   constexpr int EPT = 4 * EPV;             // k elements per tile (64 bytes of a row)
-  constexpr int CK = 64 * EPV;             // k elements per unit (1 KiB of a row)
-  constexpr int LROW = 1024 + 16;          // LDS bytes per row (padded: the tile reads walk sixteen rows)
+  constexpr int W = F8 ? 2 : 1;            // 16-byte pieces of the slot a lane produces per load (a lane always LOADS 16 source bytes)
+  constexpr int CK = 64 * EPV * W;         // k elements per unit (1 KiB of a SOURCE row)
+  constexpr int LROW = 1024 * W + 16;      // LDS bytes per row (padded: the tile reads walk sixteen rows)
   __shared__ __attribute__((aligned(16))) char lds[16 * LROW];
+  __shared__ uint16_t lut[F8 ? 256 : 1];  // e4m3fn byte -> bf16 bits (exact: three mantissa bits)
+  if (F8) {
+    const uint32_t v8 = threadIdx.x, sg = v8 >> 7, ex = (v8 >> 3) & 15, m = v8 & 7;
+    float f = (ex == 15 && m == 7) ? __builtin_nanf("") : (ex == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + (float)m * 0.125f, (int)ex - 7));
+    if (sg) f = -f;
+    lut[v8 & (F8 ? 255 : 0)] = (uint16_t)(__float_as_uint(f) >> 16);
+    __syncthreads();
+  }
+  // 16 source bytes starting at element `elem` of the source tensor -> W pieces of 16 slot bytes
+  auto ld_src = [&](const char* src, size_t elem, u32x4 (&o)[W]) {
+    if constexpr (F8) {
+      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + elem));  // 16 fp8 bytes
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        uint32_t r4[4];
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) {
+          const uint32_t ww = qq[w * 2 + (h2 >> 1)], sh = (h2 & 1) * 16;
+          r4[h2] = (uint32_t)lut[(ww >> sh) & 255] | ((uint32_t)lut[(ww >> (sh + 8)) & 255] << 16);
+        }
+        o[w] = u32x4{r4[0], r4[1], r4[2], r4[3]};
+      }
+    } else {
+      o[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(src) + elem));
+    }
+  };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nunit[4], kcs[4], total = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     kcs[t] = (t < b.n && b.K[t] > 0) ? (b.K[t] + CK - 1) / CK : 1;
-    nunit[t] = t < b.n ? (b.K[t] > 0 ? ((b.R[t] + 15) / 16) * kcs[t] : (b.R[t] + 1023) / 1024) : 0;  // vector: R = 16-byte pieces, 1024 per unit
+    nunit[t] = t < b.n ? (b.K[t] > 0 ? ((b.R[t] + 15) / 16) * kcs[t] : (b.R[t] + 1024 * W - 1) / (1024 * W)) : 0;  // vector: R = 16-byte pieces, 1024 W per unit
     total += nunit[t];
   }
-  u32x4 v[4];
+  u32x4 v[4][W];
   auto decode = [&](int i, int& t, int& rg, int& kc) {
     t = 0;
     while (t < 3 && i >= nunit[t]) { i -= nunit[t]; ++t; }
@@ -131,13 +159,14 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     const char* src = reinterpret_cast<const char*>(b.src) + b.src_off[t];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int w = 0; w < W; ++w) v[j][w] = u32x4{0u, 0u, 0u, 0u};
       if (b.K[t] > 0) {
-        const int row = rg * 16 + wave * 4 + j, k = kc * CK + lane * EPV;
-        if (row < b.R[t] && k < b.K[t]) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(src) + (size_t)row * b.K[t] + k));
+        const int row = rg * 16 + wave * 4 + j, k = kc * CK + lane * EPV * W;  // (K % (EPV * W) == 0: checked by the engine for fp8 blobs)
+        if (row < b.R[t] && k < b.K[t]) ld_src(src, (size_t)row * b.K[t] + k, v[j]);
       } else {
-        const int piece = rg * 1024 + (wave * 4 + j) * 64 + lane;  // (kcs = 1: rg = the unit)
-        if (piece < b.R[t]) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + piece);
+        const int piece = (rg * 1024 + (wave * 4 + j) * 64 + lane) * W;  // (kcs = 1: rg = the unit); W consecutive pieces per lane
+        if (piece < b.R[t]) ld_src(src, (size_t)piece * EPV, v[j]);       // (R % W == 0 for fp8 blobs)
       }
     }
   };
@@ -147,26 +176,30 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     int t, rg, kc;
     decode(i, t, rg, kc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(lds + (wave * 4 + j) * LROW + lane * 16) = v[j];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int w = 0; w < W; ++w) *reinterpret_cast<u32x4*>(lds + (wave * 4 + j) * LROW + (lane * W + w) * 16) = v[j][w];
     __syncthreads();
     if (i + (int)gridDim.x < total) load(i + gridDim.x);  // in flight while this unit leaves through LDS
     char* dst = reinterpret_cast<char*>(b.dst) + b.dst_off[t];
     if (b.K[t] > 0) {
       const int KB = (b.K[t] + EPT - 1) / EPT;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kbl = wave * 4 + j, kb = kc * 16 + kbl;  // tile of this unit: row lane & 15, 16-byte piece lane >> 4
+      for (int j = 0; j < 4 * W; ++j) {
+        const int kbl = wave * 4 * W + j, kb = kc * 16 * W + kbl;  // tile of this unit: row lane & 15, 16-byte piece lane >> 4
         if (kb < KB) {
-          const u32x4 w = *reinterpret_cast<const u32x4*>(lds + (lane & 15) * LROW + kbl * 64 + (lane >> 4) * 16);
-          *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = w;
+          const u32x4 w4 = *reinterpret_cast<const u32x4*>(lds + (lane & 15) * LROW + kbl * 64 + (lane >> 4) * 16);
+          *reinterpret_cast<u32x4*>(dst + ((size_t)rg * KB + kb) * 1024 + lane * 16) = w4;
         }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int piece = rg * 1024 + (wave * 4 + j) * 64 + lane;
-        if (piece < b.R[t]) *reinterpret_cast<u32x4*>(dst + (size_t)piece * 16) = *reinterpret_cast<const u32x4*>(lds + (wave * 4 + j) * LROW + lane * 16);
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const int piece = (rg * 1024 + (wave * 4 + j) * 64 + lane) * W + w;
+          if (piece < b.R[t]) *reinterpret_cast<u32x4*>(dst + (size_t)piece * 16) = *reinterpret_cast<const u32x4*>(lds + (wave * 4 + j) * LROW + (lane * W + w) * 16);
+        }
     }
     __syncthreads();
   }
@@ -178,8 +211,11 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
 }
 hipError_t launch_pull_retile(const RetileBlob& b, int dtype, int workgroups, hipStream_t st, unsigned long long* ts, int first) {
   const dim3 grid(workgroups < 1 ? 1 : workgroups);
-  if (dtype != DT_F32) hipLaunchKernelGGL((pull_retile_kernel<uint16_t>), grid, dim3(256), 0, st, b, ts, first);
-  else hipLaunchKernelGGL((pull_retile_kernel<float>), grid, dim3(256), 0, st, b, ts, first);
+  if (b.src_f8) {
+    if (dtype != DT_BF16) return hipErrorInvalidValue;  // fp8 host blobs are up-cast to bf16 slots only
+    hipLaunchKernelGGL((pull_retile_kernel<uint16_t, true>), grid, dim3(256), 0, st, b, ts, first);
+  } else if (dtype != DT_F32) hipLaunchKernelGGL((pull_retile_kernel<uint16_t, false>), grid, dim3(256), 0, st, b, ts, first);
+  else hipLaunchKernelGGL((pull_retile_kernel<float, false>), grid, dim3(256), 0, st, b, ts, first);
   return hipGetLastError();
 }
 hipError_t launch_retile(const void* src, void* dst, int R, int K, int dtype, hipStream_t st) {

@@ -14,10 +14,10 @@ import torch
 
 from . import _lib
 from ._lib import Config, EpProfile, MoeInfError, Profile, Stats, check, load_library
-from .config import DTYPE_BF16, DTYPE_F16, DTYPE_F32, EngineConfig
+from .config import DTYPE_BF16, DTYPE_F16, DTYPE_F32, DTYPE_F8E4M3, EngineConfig
 
 FWD_DEFAULT, FWD_ROUTE_ONLY, FWD_NO_COMBINE = 0, 1, 2
-_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32, DTYPE_F16: torch.float16}
+_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32, DTYPE_F16: torch.float16, DTYPE_F8E4M3: torch.bfloat16}  # (activations)
 _ALIGN = 4096
 
 
@@ -65,6 +65,8 @@ class MoEEngine:
             setattr(c, name, v)
         check(self.lib.moeinf_create(C.byref(c), C.byref(self._h)))
         self.dtype = _TORCH_DTYPE[cfg.dtype]
+        # dtype of the expert blobs in the HOST tier (pack_expert): fp8 experts travel as e4m3fn bytes and are up-cast to bf16 in their slot
+        self.host_dtype = torch.float8_e4m3fn if cfg.dtype == DTYPE_F8E4M3 else self.dtype
         self.gate_dtype = _TORCH_DTYPE[cfg.dtype if cfg.gate_dtype is None else cfg.gate_dtype]
         self.device = torch.device("cuda", cfg.device_id)
         self._H, self._gate_shape = cfg.hidden, torch.Size((cfg.num_experts, cfg.hidden))
@@ -101,7 +103,7 @@ class MoEEngine:
             raise ValueError(f"expected {len(off)} tensors, got {len(tensors)}")
         blob = torch.zeros(tot, dtype=torch.uint8)
         for t, o, s in zip(tensors, off, siz):
-            t = t.detach().to("cpu", self.dtype).contiguous()
+            t = t.detach().to("cpu", self.host_dtype).contiguous()
             if t.numel() * t.element_size() != s:
                 raise ValueError(f"tensor of {t.numel() * t.element_size()} bytes where the layout needs {s}")
             blob[o:o + s] = t.view(torch.uint8).reshape(-1)

@@ -10,7 +10,8 @@ from ._lib import check, load_library
 
 # c10::ScalarType codes (the dtype byte of the index's options block)
 SCALAR_TYPE = {torch.uint8: 0, torch.int8: 1, torch.int16: 2, torch.int32: 3, torch.int64: 4, torch.float16: 5,
-               torch.float32: 6, torch.float64: 7, torch.bool: 11, torch.bfloat16: 15}
+               torch.float32: 6, torch.float64: 7, torch.bool: 11, torch.bfloat16: 15,
+               torch.float8_e5m2: 23, torch.float8_e4m3fn: 24}  # (c10/core/ScalarType.h: Float8_e5m2 = 23, Float8_e4m3fn = 24)
 TORCH_DTYPE = {v: k for k, v in SCALAR_TYPE.items()}
 
 

@@ -57,6 +57,57 @@ def test_mixtral_golden(name):
     eng.close()
 
 
+@pytest.mark.parametrize("family,h,f,e,k,n_shared,t", [("mixtral", 256, 512, 8, 2, 0, 1), ("mixtral", 256, 512, 8, 2, 0, 40), ("deepseek", 256, 176, 16, 4, 2, 5),
+                                                      ("nllb", 256, 512, 16, 2, 0, 8)],
+                         ids=["mixtral_decode_b1", "mixtral_t40", "deepseek_with_shared_expert", "nllb_with_bias_vectors"])
+def test_fp8_experts_in_the_host_tier_equal_the_oracle_on_upcast_weights(family, h, f, e, k, n_shared, t):
+    """Expert dtype id 3 (core/parallel/expert_module.h:23,118-119 -> torch::kFloat8_e4m3fn; round 6): the blobs are e4m3fn bytes in
+    the host tier and on the link, up-cast to bf16 when pulled into their slot; activations, gate and arithmetic are bf16.  So the
+    block must equal the ORACLE RUN ON THE UP-CAST WEIGHTS (y = FFN(x; W.to(bf16))) under the usual bars, routing bit-exact, and a
+    miss moves half the bytes."""
+    from moe_infinity_amd import MoEEngine
+    from moe_infinity_amd import config as Cf
+
+    gate, experts, shared = make_weights(family, h, f, e, 7700 + t, torch.bfloat16, n_shared=n_shared)
+    q = lambda ts: [w.to(torch.float8_e4m3fn) for w in ts]  # noqa: E731
+    ex8 = [q(ts) for ts in experts]
+    sh8 = q(shared) if shared else None
+    up = lambda ts: [w.to(torch.bfloat16) for w in ts]  # noqa: E731
+    et = {"mixtral": Cf.EXPERT_MIXTRAL, "deepseek": Cf.EXPERT_DEEPSEEK, "nllb": Cf.EXPERT_NLLB}[family]
+    rk = {"mixtral": Cf.ROUTER_MIXTRAL, "deepseek": Cf.ROUTER_DEEPSEEK, "nllb": Cf.ROUTER_NLLB}[family]
+    mk = lambda dt: MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=e, expert_type=et, hidden=h, inter=f, top_k=k, router_kind=rk, dtype=dt,  # noqa: E731
+                                              gate_dtype=Cf.DTYPE_BF16, shared_inter=f * n_shared, device_memory_ratio=0.5, max_tokens=t))
+    eng = mk(Cf.DTYPE_F8E4M3)
+    assert eng.dtype == torch.bfloat16 and eng.host_dtype == torch.float8_e4m3fn
+    register_all(eng, ex8, sh8)
+    x = acts(t, h, torch.bfloat16, 7800 + t)
+    if family == "mixtral":
+        ref = R.block_mixtral(x[None], gate, [up(ts) for ts in ex8], top_k=k)
+    elif family == "deepseek":
+        ref = R.block_deepseek(x[None], gate, [up(ts) for ts in ex8], k, shared=up(sh8))
+    else:
+        ref = R.block_nllb(x[None], gate, [up(ts) for ts in ex8])
+    for rnd in range(2):  # misses (the pull kernel up-casts), then hits
+        out = eng.forward(0, x.to(DEV), gate.to(DEV))
+        if family == "nllb":
+            _check_dispatch_index(eng.routing(), ref)  # (the NLLB oracle keeps masks, not a top-k list)
+        else:
+            _check_routing_exact(eng, ref)
+        assert_block_close(out, ref, torch.bfloat16, f"round {rnd}: fp8 experts vs the oracle on up-cast weights")
+    rows = oracle_expert_rows(ref, e)
+    assert_model_close(eng.expert_outputs(rows.shape[0]), rows, torch.bfloat16, "expert FFN outputs")
+    st8 = eng.stats()
+    eng.close()
+    eng16 = mk(Cf.DTYPE_BF16)  # the same experts as bf16 blobs: twice the bytes per miss, the same slots
+    register_all(eng16, [up(ts) for ts in ex8], up(sh8) if sh8 else None)
+    out16 = eng16.forward(0, x.to(DEV), gate.to(DEV))
+    st16 = eng16.stats()
+    eng16.close()
+    assert torch.equal(out.cpu(), out16.cpu()), "up-cast in the pull kernel == up-cast on the host: the same slot contents, the same bits"
+    assert st8["slot_bytes"] == st16["slot_bytes"] and st8["expert_misses"] == st16["expert_misses"] > 0
+    assert st8["h2d_bytes"] * 2 <= st16["h2d_bytes"] + 4096 * 4 * st16["expert_misses"], (st8["h2d_bytes"], st16["h2d_bytes"])  # (4 KiB tensor alignment)
+
+
 @pytest.mark.parametrize("name", ["deepseekv3_decode_b1.npz", "deepseekv3_prefill_t40.npz", "deepseekv3_e256_t24.npz"])
 def test_deepseek_v3_gate_golden(name):
     """MOEINF_ROUTER_DEEPSEEK_V3 (round 6): sigmoid scores + e_score_correction_bias, groups ranked by the sum of their two best,
@@ -322,9 +373,9 @@ def test_error_paths_do_not_abort():
 
     with pytest.raises(MoeInfError):  # not one of expert_module.h:13-18 (every one of those is built since round 5)
         MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=7, hidden=256, inter=512, top_k=1, router_kind=Cf.ROUTER_SWITCH))
-    with pytest.raises(MoeInfError):  # the fp8 expert dtype (id 3) is declared by the reference and not built here: refused, not mis-read
+    with pytest.raises(MoeInfError):  # a dtype id the reference does not have (its ids are 0..3, expert_module.h:20-23; 3 = fp8 is built since round 6)
         MoEEngine(Cf.EngineConfig(num_layers=1, num_experts=8, expert_type=Cf.EXPERT_MIXTRAL, hidden=256, inter=512, top_k=2,
-                                  router_kind=Cf.ROUTER_MIXTRAL, dtype=3))
+                                  router_kind=Cf.ROUTER_MIXTRAL, dtype=4))
     eng = engine_for("mixtral", 256, 512, 8, 2, torch.bfloat16, max_tokens=4)
     gate = torch.zeros(8, 256, dtype=torch.bfloat16, device=DEV)
     x = torch.zeros(2, 256, dtype=torch.bfloat16, device=DEV)

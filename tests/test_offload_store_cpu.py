@@ -17,6 +17,7 @@ def _tensors():
         1: torch.randn(64, 64, generator=g),                        # 16 KiB exactly aligned
         40: torch.randn(5000, generator=g).to(torch.float16),
         3: torch.arange(12, dtype=torch.int64).reshape(3, 4),
+        9: torch.randn(40, 24, generator=g).to(torch.float8_e4m3fn),  # the reference's expert dtype id 3 (ScalarType 24)
     }
 
 
