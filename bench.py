@@ -962,7 +962,7 @@ def main():
             "cpu_baseline": r["cpu"],
             "kernels": r["kernels"],
             "prefetch_stream": None if warm["h2d_busy_ms"] <= 0 else {
-                "what": "cache warm-up: every owned expert streamed host(pinned)->HBM through the speculative lane (hipMemcpyAsync tensor by tensor, double-buffered staging + device re-tile)",
+                "what": "cache warm-up: every owned expert streamed host(pinned)->HBM through the speculative lane (pull form: a kernel of the copy stream reads the pinned blob and writes the tiled slot; MOEINF_H2D_PULL=0: SDMA copies + re-tile)",
                 "GiB": round(warm["h2d_bytes"] / 2**30, 2), "link_busy_ms": round(warm["h2d_busy_ms"], 1),
                 "GBps": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6, 2),
                 "frac_of_pcie5_x16_63GBps": round(warm["h2d_bytes"] / warm["h2d_busy_ms"] / 1e6 / PCIE_GBS, 3),
