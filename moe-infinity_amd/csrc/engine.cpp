@@ -346,9 +346,9 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     const char* pe = getenv("MOEINF_H2D_PULL");
     g->h2d_pull = (pe ? atoi(pe) != 0 : true) && vec_ok;
     const char* pw = getenv("MOEINF_H2D_PULL_WGS");
-    // 16 workgroups pull bf16 / fp16 / fp32 blobs at the link's rate; an fp8 blob's workgroup also up-casts and writes twice what it
-    // reads, so it takes 32 to keep the link busy (Mixtral miss-heavy leg, 16 layers: 37 GB/s with 16, 55-56 with 32)
-    g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : (g->host_f8 ? 32 : 16);
+    // 16 workgroups with four 16-byte loads per lane in flight pull at the link's rate, fp8 blobs included (8: -3 %, 32: -2...6 %;
+    // profiles/r06_tier_mover_pull_vs_sdma_ab.txt)
+    g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : 16;
     if (g->host_f8) {  // the fp8 pull loads 16 source bytes (sixteen elements) per lane
       bool ok16 = true;
       for (int i = 0; i < g->dlay.n; ++i) ok16 = ok16 && (g->dlay.K[i] > 0 ? g->dlay.K[i] % 16 == 0 : g->dlay.size[i] % 32 == 0);

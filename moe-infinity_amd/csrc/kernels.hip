@@ -120,10 +120,9 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     lut[v8 & (F8 ? 255 : 0)] = (uint16_t)(__float_as_uint(f) >> 16);
     __syncthreads();
   }
-  // 16 source bytes starting at element `elem` of the source tensor -> W pieces of 16 slot bytes
-  auto ld_src = [&](const char* src, size_t elem, u32x4 (&o)[W]) {
+  // 16 RAW source bytes -> W pieces of 16 slot bytes (fp8: the up-cast; else the bytes themselves)
+  auto widen = [&](const u32x4 q, u32x4 (&o)[W]) {
     if constexpr (F8) {
-      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + elem));  // 16 fp8 bytes
       const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
         o[w] = u32x4{r4[0], r4[1], r4[2], r4[3]};
       }
     } else {
-      o[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(src) + elem));
+      o[0] = q;
     }
   };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,7 +146,13 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     nunit[t] = t < b.n ? (b.K[t] > 0 ? ((b.R[t] + 15) / 16) * kcs[t] : (b.R[t] + 1024 * W - 1) / (1024 * W)) : 0;  // vector: R = 16-byte pieces, 1024 W per unit
     total += nunit[t];
   }
-  u32x4 v[4][W];
+  // The four loads of a unit are issued UNCONDITIONALLY from clamped (always valid) addresses and the lanes that are out of range
+  // are zeroed when the data is USED: a register that is zeroed before a predicated load makes the compiler wait for every load
+  // in flight first (vmcnt(0) in front of each load: one request per lane in flight instead of four — the link at 42 GB/s with 16
+  // workgroups instead of 56).
+  u32x4 raw[4];
+  uint32_t okmask = 0;  // bit j: this lane's j-th load of the unit in flight is in range
+  constexpr int SRC_EPL = F8 ? 16 : EPV;  // source elements per lane-load (16 bytes)
   auto decode = [&](int i, int& t, int& rg, int& kc) {
     t = 0;
     while (t < 3 && i >= nunit[t]) { i -= nunit[t]; ++t; }
@@ -157,17 +162,23 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     int t, rg, kc;
     decode(i, t, rg, kc);
     const char* src = reinterpret_cast<const char*>(b.src) + b.src_off[t];
+    constexpr int SRC_ES = F8 ? 1 : (int)sizeof(T);
+    okmask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int w = 0; w < W; ++w) v[j][w] = u32x4{0u, 0u, 0u, 0u};
+      size_t elem;
+      bool ok;
       if (b.K[t] > 0) {
-        const int row = rg * 16 + wave * 4 + j, k = kc * CK + lane * EPV * W;  // (K % (EPV * W) == 0: checked by the engine for fp8 blobs)
-        if (row < b.R[t] && k < b.K[t]) ld_src(src, (size_t)row * b.K[t] + k, v[j]);
+        const int row = rg * 16 + wave * 4 + j, k = kc * CK + lane * SRC_EPL;  // (K % SRC_EPL == 0: checked by the engine)
+        ok = row < b.R[t] && k < b.K[t];
+        elem = (size_t)min(row, b.R[t] - 1) * b.K[t] + min(k, b.K[t] - SRC_EPL);
       } else {
-        const int piece = (rg * 1024 + (wave * 4 + j) * 64 + lane) * W;  // (kcs = 1: rg = the unit); W consecutive pieces per lane
-        if (piece < b.R[t]) ld_src(src, (size_t)piece * EPV, v[j]);       // (R % W == 0 for fp8 blobs)
+        const int piece = (rg * 1024 + (wave * 4 + j) * 64 + lane) * W;  // (kcs = 1: rg = the unit); W consecutive 16-byte pieces of the slot per lane
+        ok = piece < b.R[t];
+        elem = (size_t)min(piece, b.R[t] - W) * EPV;  // (R % W == 0 and R >= W for fp8 blobs)
       }
+      raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + elem * SRC_ES));
+      okmask |= (ok ? 1u : 0u) << j;
     }
   };
   int i = blockIdx.x;
@@ -176,9 +187,15 @@ __global__ __launch_bounds__(256) void pull_retile_kernel(RetileBlob b, unsigned
     int t, rg, kc;
     decode(i, t, rg, kc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      u32x4 o[W];
+      widen(raw[j], o);
 #pragma unroll
-      for (int w = 0; w < W; ++w) *reinterpret_cast<u32x4*>(lds + (wave * 4 + j) * LROW + (lane * W + w) * 16) = v[j][w];
+      for (int w = 0; w < W; ++w) {
+        if (!((okmask >> j) & 1u)) o[w] = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(lds + (wave * 4 + j) * LROW + (lane * W + w) * 16) = o[w];
+      }
+    }
     __syncthreads();
     if (i + (int)gridDim.x < total) load(i + gridDim.x);  // in flight while this unit leaves through LDS
     char* dst = reinterpret_cast<char*>(b.dst) + b.dst_off[t];
