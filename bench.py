@@ -794,7 +794,7 @@ def main():
     ap.add_argument("--no-fp16-legs", action="store_true", help="skip the fp16-expert legs of other_configs")
     ap.add_argument("--dtype", default="model", choices=["model", "fp16", "fp8"], help="fp16: the main leg with fp16 experts (the reference's dtype id 2) instead of the model's own dtype (profiling the fp16 kernels on their own)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the path through prefetch_op.expert_dispatcher as the reference's dispatch_local drives it, timed beside the fused path)")
-    ap.add_argument("--dropin-layers", type=int, default=8, help="full-size MoE layers of the drop-in leg (its offload directory holds every expert of them: 8 Mixtral layers = 21 GiB)")
+    ap.add_argument("--dropin-layers", type=int, default=4, help="full-size MoE layers of the drop-in leg (its offload directory holds every expert of them: 8 Mixtral layers = 21 GiB)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic pass (two rocprofv3 --pmc child runs, ~1 min): roofline.traffic then comes from profiles/ (static)")
     args = ap.parse_args()
 
@@ -917,7 +917,7 @@ def main():
         for wl in ("mixtral-8x7b", "deepseek-v2-lite"):
             try:
                 t0 = time.time()
-                dropin[wl] = dmod.measure(wl, layers=args.dropin_layers, steps=10, warmup=2, log=log)
+                dropin[wl] = dmod.measure(wl, layers=args.dropin_layers, steps=8, warmup=2, log=log)
                 log(f"drop-in leg {wl}: {dropin[wl]['ms_per_token']} ms/token, {dropin[wl]['over_fused']} x the fused path ({time.time() - t0:.0f}s)")
             except Exception as ex:  # noqa: BLE001
                 log(f"drop-in leg {wl} failed: {ex!r}")
