@@ -349,6 +349,9 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
     // 16 workgroups with four 16-byte loads per lane in flight pull at the link's rate, fp8 blobs included (8: -3 %, 32: -2...6 %;
     // profiles/r06_tier_mover_pull_vs_sdma_ab.txt)
     g->h2d_pull_wgs = pw ? std::max(1, atoi(pw)) : 16;
+    // MOEINF_FENCE_EVERY (default 16; 1 = a fence behind every forward): how often a sync-free forward records its fence
+    const char* fe = getenv("MOEINF_FENCE_EVERY");
+    g->fence_every = fe ? std::min(std::max(1, atoi(fe)), kMirrorPool / 4) : 16;
     if (g->host_f8) {  // the fp8 pull loads 16 source bytes (sixteen elements) per lane
       bool ok16 = true;
       for (int i = 0; i < g->dlay.n; ++i) ok16 = ok16 && (g->dlay.K[i] > 0 ? g->dlay.K[i] % 16 == 0 : g->dlay.size[i] % 32 == 0);
@@ -372,9 +375,9 @@ extern "C" int moeinf_create(const moeinf_config* cfg, moeinf_engine** out) {
   TRYHIP(hipHostMalloc((void**)&g->h_mirror, (1 + 2 * E1) * sizeof(int32_t), hipHostMallocDefault));
   {
     const size_t per = ((size_t)(1 + 2 * E1) + 15) / 16 * 16;  // ints per mirror, 64-byte aligned
-    TRYHIP(hipHostMalloc((void**)&g->mirror_slab, per * kFenceRing * sizeof(int32_t), hipHostMallocDefault));
-    memset(g->mirror_slab, 0, per * kFenceRing * sizeof(int32_t));
-    for (int i = 0; i < kFenceRing; ++i) g->mirror_pool.push_back(g->mirror_slab + per * i);
+    TRYHIP(hipHostMalloc((void**)&g->mirror_slab, per * kMirrorPool * sizeof(int32_t), hipHostMallocDefault));
+    memset(g->mirror_slab, 0, per * kMirrorPool * sizeof(int32_t));
+    for (int i = 0; i < kMirrorPool; ++i) g->mirror_pool.push_back(g->mirror_slab + per * i);
   }
   TRYHIP(hipHostMalloc((void**)&g->h_miss, sizeof(int32_t), hipHostMallocDefault));
   *g->h_miss = 0;
@@ -613,14 +616,14 @@ static int issue_copy(moeinf_engine* g, int idx, CopyLane& ln, bool allow_protec
   if (start && stop) HIPCHK(hipEventRecord(start, ln.copy));
   int order[4];
   const int n1 = copy_order(g->cfg.expert_type, order);
-  // first write into the slot.  (a) kernels of forward #last_use_seq may still read the previous tenant (fence
-  // ring entries older than kFenceRing forwards have been overwritten: fall back to the newest fence);
+  // first write into the slot.  (a) kernels of forward #last_use_seq may still read the previous tenant: wait for a fence
+  // that covers it (fence_for records one if the sync-free forwards since have not);
   // (b) the previous tenant's OWN transfer may still be in flight on another lane (a prefetched expert is
   // evictable from the moment its copy is issued): write-after-write on the slot
   auto order_first_write_on = [&](hipStream_t ws) -> int {
     if (s.last_use_seq > 0) {
-      const uint64_t fs = (s.last_use_seq + kFenceRing > g->seq) ? s.last_use_seq : g->seq;
-      hipEvent_t fe = g->fence_ev[fs % kFenceRing];
+      hipEvent_t fe = nullptr;
+      CHK(fence_for(g, std::min(s.last_use_seq, g->seq), &fe));
       if (hipEventQuery(fe) != hipSuccess) {
         (void)hipGetLastError();
         HIPCHK(hipStreamWaitEvent(ws, fe, 0));
@@ -1106,11 +1109,14 @@ static int predictor_observe(moeinf_engine* g, int layer, const int32_t* mirror,
 static void drain_mirrors(moeinf_engine* g, size_t max_pending) {
   while (!g->pend.empty()) {
     auto& pm = g->pend.front();
-    // the forward's fence; ring entries older than kFenceRing forwards have been re-recorded by a later forward
-    const uint64_t fs = (pm.seq + kFenceRing > g->seq) ? pm.seq : g->seq;
-    hipEvent_t ev = g->fence_ev[fs % kFenceRing];
+    // a fence that covers the forward: sync-free forwards record one every fence_every-th time, so a mirror is applied up to
+    // that many forwards late; only a drain that has to wait records one of its own
+    hipEvent_t ev = covering_fence(g, pm.seq);
     if (g->pend.size() > max_pending) {
+      if (!ev && fence_for(g, pm.seq, &ev) != MOEINF_OK) break;
       hipEventSynchronize(ev);
+    } else if (!ev) {
+      break;
     } else if (hipEventQuery(ev) != hipSuccess) {
       (void)hipGetLastError();
       break;
@@ -1144,8 +1150,8 @@ int plan_mirror(moeinf_engine* g, int layer, MirrorPlan& mp) {
   settle_ready(g, layer);
   mp.fast = g->resident_per_layer[layer] == g->owned_experts;
   if (mp.fast) {
-    drain_mirrors(g, (size_t)(kFenceRing - 4));  // a mirror must be applied before its fence leaves the ring twice
-    // at most kFenceRing - 4 mirrors are pending, and the pool was carved out of one pinned slab at creation
+    drain_mirrors(g, (size_t)(kMirrorPool - 4));
+    // at most kMirrorPool - 4 mirrors are pending, and the pool was carved out of one pinned slab at creation
     // (hipHostMalloc on the forward path stalls the device for milliseconds)
     if (g->mirror_pool.empty()) return fail(MOEINF_ERR_STATE, "routing-mirror pool exhausted");
     mp.target = g->mirror_pool.back();
@@ -1341,10 +1347,7 @@ static int run_experts(moeinf_engine* g, int layer, const void* x_in, hipStream_
     HIPCHK(launch_ffn_stage(s2, b - a, max_rows, st));
     if (la_now && !la_early) CHK(lookahead_issue(g, layer));
     a = b;
-    if (a < na) {
-      g->seq += 1;
-      HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
-    }
+    if (a < na) CHK(end_forward(g, st, true));
   }
   if (na == 0 && ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
   if (ev_after) HIPCHK(hipEventRecord(ev_after, st));
@@ -1673,8 +1676,7 @@ extern "C" int moeinf_moe_forward(moeinf_engine* g, int layer, const void* x_dev
   if (want_combine && !fused) HIPCHK(launch_combine(ca, st));
   if (prof) { HIPCHK(hipEventRecord(pr.ev[5], st)); g->prof_pending.push_back(pr); }
   // fence: slots used by this forward may be recycled only after this point of the stream
-  g->seq += 1;
-  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  CHK(end_forward(g, st, !mp.fast));
   strace.mark("combine_fence");
   return pump_if_pending(g);  // the host is idle until the next layer: serve the speculative queue now
 }
@@ -1730,8 +1732,7 @@ extern "C" int moeinf_dispatch_mask_subset(moeinf_engine* g, int layer, const vo
   if (rows > 0) HIPCHK(hipMemcpyAsync(y_dev, g->d_y, (size_t)rows * g->H * g->es, hipMemcpyDeviceToDevice, st));
   g->last_T = tokens; g->last_layer = layer; g->last_stream = st;
   g->st.forwards += 1;
-  g->seq += 1;
-  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  CHK(end_forward(g, st, true));
   return pump_if_pending(g);
 }
 

@@ -234,8 +234,7 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
     HIPCHK(launch_ffn_ep_stage(s2, o, st));
     if (prof) { record_timing(pr.ev[4], st); record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
     g->st.forwards += 1;
-    g->seq += 1;
-    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+    CHK(end_forward(g, st, false));  // (the sync-free branch)
     return pump_if_pending(g);
   }
   ia.pair_slot = g->d_pair_slot; ia.slot_token = g->d_slot_token; ia.slot_pair = g->d_slot_pair; ia.mirror = mp.target;
@@ -261,8 +260,7 @@ static int ep_expert_ffn_rows(moeinf_engine* g, int layer, const void* recv_dev,
   if (pv) HIPCHK(launch_ep_push(y_dev, recv_dev, ld, g->H, g->dt, *pv, st));  // ... and send their outputs home behind them
   if (prof) { record_timing(pr.ev[5], st); g->prof_pending.push_back(pr); }
   g->st.forwards += 1;
-  g->seq += 1;
-  HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+  CHK(end_forward(g, st, !mp.fast));
   return pump_if_pending(g);
 }
 
@@ -615,8 +613,7 @@ static int ep_peer_forward_bcast(moeinf_engine* g, int layer, const void* x_dev,
     o.stage = 2; o.max_active = max_active; o.rec = g->d_ep_rec; o.peers = pv; o.tile_done = g->d_arrive;
     HIPCHK(launch_ffn_ep_stage(s2, o, st));
     g->st.forwards += 2;  // (home routing + owner FFN, as the routed form counts them)
-    g->seq += 1;
-    HIPCHK(hipEventRecord(g->fence_ev[g->seq % kFenceRing], st));
+    CHK(end_forward(g, st, false));  // (the sync-free branch)
     mark(3);
   } else {
     // plan_mirror handed out the engine's own mirror (nothing pooled to give back); the generic owner path plans again

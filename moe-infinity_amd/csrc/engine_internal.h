@@ -180,6 +180,7 @@ struct Slot {
 };
 
 static constexpr int kFenceRing = 64;
+static constexpr int kMirrorPool = 128;  // pooled pinned routing mirrors of sync-free forwards not yet applied to the counters
 static constexpr int kHideSharedMaxTokens = 16;  // forwards up to this many tokens hide the shared expert under the router
 
 // One H2D lane = a copy stream (hipMemcpyAsync, served by an SDMA engine) + a re-tile stream (kernels) + a ring of two
@@ -276,7 +277,16 @@ struct moeinf_engine {
 
   // streams / events
   hipEvent_t route_ev = nullptr;
+  // fences: an event on the compute stream after forward #fence_seq[i].  Recorded after EVERY forward that took the decision path
+  // (copies follow, and they should wait for no more compute than they must) but only after every fence_every-th sync-free
+  // forward (a record between two kernels costs the stream 2.7-4 us: profiles/r06_fence_every.md); whoever needs a forward that
+  // no fence covers yet records one then (fence_for)
   hipEvent_t fence_ev[kFenceRing];
+  uint64_t fence_seq[kFenceRing] = {};
+  uint64_t fence_head = 0;   // fences recorded so far (ring position = fence_head % kFenceRing)
+  uint64_t fenced_seq = 0;   // the newest forward a recorded fence covers
+  hipStream_t unfenced_stream = nullptr;  // the stream the forwards after fenced_seq were launched on
+  int fence_every = 16;
   uint64_t seq = 0;  // forwards issued
   std::vector<std::pair<hipEvent_t, hipEvent_t>> copy_timers;  // (start, end) pairs not yet accumulated
   std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_timers;  // compute-stream stalls on copies
@@ -381,6 +391,43 @@ struct moeinf_engine {
 // linger in the runtime's sticky last-error slot either.
 static inline void record_timing(hipEvent_t ev, hipStream_t st) {
   if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError();
+}
+
+// ---- fences (the fields are described in moeinf_engine) ----
+static inline int record_fence(moeinf_engine* g, hipStream_t st) {
+  const int i = (int)(g->fence_head % kFenceRing);
+  HIPCHK(hipEventRecord(g->fence_ev[i], st));
+  g->fence_seq[i] = g->seq;
+  g->fence_head += 1;
+  g->fenced_seq = g->seq;
+  return MOEINF_OK;
+}
+// the oldest recorded fence that covers forward #s (an entry that left the ring is covered by every entry still in it), or null
+static inline hipEvent_t covering_fence(const moeinf_engine* g, uint64_t s) {
+  if (s > g->fenced_seq || g->fence_head == 0) return nullptr;
+  const uint64_t lo = g->fence_head > (uint64_t)kFenceRing ? g->fence_head - kFenceRing : 0;
+  uint64_t i = g->fence_head;  // newest first: the covering entries are a suffix of the ring
+  while (i > lo && g->fence_seq[(i - 1) % kFenceRing] >= s) --i;
+  return g->fence_ev[i % kFenceRing];
+}
+// a fence for forward #s (already launched: s <= seq); one is recorded now, behind everything launched so far, if none covers it
+static inline int fence_for(moeinf_engine* g, uint64_t s, hipEvent_t* out) {
+  if (s > g->fenced_seq) {
+    if (s > g->seq) return fail(MOEINF_ERR_STATE, "fence for forward %llu asked before it was launched (%llu)",
+                                (unsigned long long)s, (unsigned long long)g->seq);
+    CHK(record_fence(g, g->unfenced_stream));
+  }
+  *out = covering_fence(g, s);
+  return MOEINF_OK;
+}
+// the end of a forward (or of one chunk of it) launched on st.  must: the decision path, whose copies should see the tightest fence
+static inline int end_forward(moeinf_engine* g, hipStream_t st, bool must) {
+  // forwards on another stream are still unfenced: close them there first (a fence on st says nothing about them)
+  if (g->fenced_seq < g->seq && g->unfenced_stream != st) CHK(record_fence(g, g->unfenced_stream));
+  g->seq += 1;
+  g->unfenced_stream = st;
+  if (must || g->seq - g->fenced_seq >= (uint64_t)g->fence_every) CHK(record_fence(g, st));
+  return MOEINF_OK;
 }
 
 static int node_index(const moeinf_engine* g, int layer, int expert) { return expert * g->L + layer; }

@@ -348,6 +348,62 @@ def test_next_layer_gate_lookahead_issues_the_next_layers_experts_and_changes_no
             e2.close()
 
 
+@pytest.mark.parametrize("two_streams", [False, True], ids=["one_stream", "evicting_forward_on_another_stream"])
+def test_a_copy_waits_for_sync_free_forwards_that_recorded_no_fence(two_streams):
+    """Round 6: a sync-free forward records its fence only every MOEINF_FENCE_EVERY-th time (default 16; an event record between
+    two kernels costs the stream 2.7-4 us, profiles/r06_fence_every.md).  A copy that recycles a slot read by such an UNFENCED
+    forward must still wait for it — the engine records the missing fence when the copy is issued, on the stream the unfenced
+    forwards were launched on.  Queue six prefill-sized layer-0 forwards (every expert cached: sync-free, none fenced) and, with
+    the GPU still busy on them, a layer-1 forward whose misses take layer 0's slots: every queued output must equal the oracle."""
+    h, f, e, k, t, L = 1024, 2048, 8, 2, 512, 2
+    ws = [make_weights("mixtral", h, f, e, 4100 + l, torch.bfloat16) for l in range(L)]
+    eng = _mixtral_engine(L, e, h, f, k, e + 1, t)
+    for l in range(L):
+        register_all(eng, ws[l][1], layer=l)
+    gates = [w[0].to(DEV) for w in ws]
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    xs = [acts(t, h, torch.bfloat16, 4200 + i) for i in range(7)]
+    xd = [x.to(DEV) for x in xs]
+    outs = [torch.empty(t, h, dtype=torch.bfloat16, device=DEV) for _ in range(7)]
+    eng.forward(0, xd[0], gates[0], out=outs[0])  # (the first forward after the copies settles them: decision path, fenced)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream() if two_streams else None
+    for i in range(1, 7):
+        eng.forward(0, xd[i], gates[0], out=outs[i])
+    out1 = torch.empty(t, h, dtype=torch.bfloat16, device=DEV)
+    if side is not None:
+        with torch.cuda.stream(side):
+            eng.forward(1, xd[0], gates[1], out=out1)
+    else:
+        eng.forward(1, xd[0], gates[1], out=out1)
+    torch.cuda.synchronize()
+    for i in range(7):
+        assert_block_close(outs[i], R.block_mixtral(xs[i][None], ws[0][0], ws[0][1], top_k=k), torch.bfloat16, f"queued layer-0 forward {i}")
+    assert_block_close(out1, R.block_mixtral(xs[0][None], ws[1][0], ws[1][1], top_k=k), torch.bfloat16, "the evicting layer-1 forward")
+    st = eng.stats()
+    assert st["evictions"] >= e - 1 and st["expert_misses"] >= e, st
+    # ... and back: layer 0's experts come in again over layer 1's, behind the layer-1 forward's own (decision-path) fence
+    out0 = eng.forward(0, xd[3], gates[0])
+    assert_block_close(out0, R.block_mixtral(xs[3][None], ws[0][0], ws[0][1], top_k=k), torch.bfloat16, "layer 0 again")
+    eng.close()
+
+
+@pytest.mark.parametrize("every", ["1", "32"])
+def test_the_fence_cadence_changes_no_result(every):
+    """MOEINF_FENCE_EVERY=1 is the round-5 form (a fence behind every forward), 32 the sparsest allowed: the miss-path tests and a
+    golden vector in a child process with the knob set (the engine reads it once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_tiers.py"), os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-k",
+                        "demand_misses or budget_can_shrink or recorded_no_fence or lookahead or mixtral_golden or deepseek_golden"],
+                       env=dict(os.environ, MOEINF_FENCE_EVERY=every), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("env", [{"MOEINF_H2D_PULL": "0"}, {"MOEINF_H2D_PULL": "0", "MOEINF_H2D_WHOLE_BLOB_MB": "0"}],
                          ids=["sdma_whole_blob_copies", "sdma_tensor_by_tensor"])
 def test_the_sdma_forms_of_the_tier_mover_stay_parity_green(env):
