@@ -187,7 +187,11 @@ int moeinf_register_shared(moeinf_engine* eng, int layer, const void* blob, int6
  * per-row capacity uses it; pass 1 otherwise).  gate_w_dev: [E, H] (cfg.gate_dtype).
  * out_dev: [tokens, H] (cfg.dtype).  stream: hipStream_t the caller's work is ordered on.
  * The call enqueues work and returns; it blocks the host only to read the routing counts
- * when a residency decision is needed. */
+ * when a residency decision is needed.
+ * Stream lifetime: the engine keeps the handle of the stream its last forwards ran on (moeinf_sync waits on it; a later
+ * copy that recycles one of their slots, or the first forward on a different stream, records an event on it): do not
+ * destroy a stream that has carried a forward until moeinf_sync (or moeinf_destroy) has returned or the engine has run a
+ * forward on another stream. */
 #define MOEINF_FWD_DEFAULT 0u
 #define MOEINF_FWD_ROUTE_ONLY 1u  /* stop after router + dispatch-index (parity tests) */
 #define MOEINF_FWD_NO_COMBINE 2u  /* stop after the expert FFN (parity tests) */
