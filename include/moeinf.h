@@ -148,6 +148,13 @@ int moeinf_abi_version(void);
 /* the row estimate moeinf_moe_forward passes to the FFN launchers when every expert of the layer is resident (sync-free path) */
 int moeinf_rows_estimate(int tokens, int top_k, int num_experts);
 int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5);
+/* The fence ring (csrc/engine_internal.h): sync-free forwards record a fence event only every MOEINF_FENCE_EVERY-th time; a copy
+ * that recycles a slot waits for the OLDEST recorded fence that covers the slot's last reader.  moeinf_fence_ring: entries in the
+ * ring; moeinf_fence_cover_pos: the ring position that lookup returns (-1: no recorded fence covers `forward` yet) for
+ * fence_seq[ring] = the forward each entry was recorded behind and `recorded` = fences recorded so far (entry i at i % ring).
+ * Pure host logic, exported so that the wrap-around cases are tested without a GPU. */
+int moeinf_fence_ring(void);
+int moeinf_fence_cover_pos(const uint64_t* fence_seq, uint64_t recorded, uint64_t forward);
 
 /* ---- lifecycle: prefetch_handle.__init__ / clean_up_resources ------------------------------
  * (core/prefetch/archer_prefetch_handle.cpp:18-64,73-81) */

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "moeinf_ffn_ring2_form": (C.c_int, [C.c_int] * 8 + [_I32P]),
     "moeinf_set_cache_policy": (C.c_int, [_P, C.c_int]),
     "moeinf_rows_estimate": (C.c_int, [C.c_int] * 3),
+    "moeinf_fence_ring": (C.c_int, []),
+    "moeinf_fence_cover_pos": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64]),
     "moeinf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "moeinf_destroy": (C.c_int, [_P]),
     "moeinf_expert_layout": (C.c_int, [_P, C.c_int, _I64P, _I64P, _I32P, _I64P]),

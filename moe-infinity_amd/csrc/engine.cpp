@@ -66,6 +66,10 @@ extern "C" int moeinf_abi_version(void) { return MOEINF_ABI_VERSION; }
 // at most T.  Picks the FORM of the FFN kernels only; an expert with more rows takes more passes.
 static inline int rows_estimate(int T, int K, int E) { return (int)std::min<int64_t>(T, ((int64_t)T * K * 3) / (2 * std::max(1, E)) + 1); }
 extern "C" int moeinf_rows_estimate(int tokens, int top_k, int num_experts) { return rows_estimate(tokens, top_k, num_experts); }
+extern "C" int moeinf_fence_ring(void) { return kFenceRing; }
+extern "C" int moeinf_fence_cover_pos(const uint64_t* fence_seq, uint64_t recorded, uint64_t forward) {
+  return fence_seq ? fence_cover_pos(fence_seq, recorded, forward) : -1;
+}
 
 extern "C" int moeinf_ffn_ring2_form(int dtype, int nmat, int K, int K_sh, int R, int active, int max_rows, int num_cus, int32_t* out5) {
   if (!out5 || (nmat != 1 && nmat != 2) || K <= 0 || R <= 0 || active <= 0) return fail(MOEINF_ERR_INVALID, "moeinf_ffn_ring2_form: bad arguments");

@@ -402,13 +402,19 @@ static inline int record_fence(moeinf_engine* g, hipStream_t st) {
   g->fenced_seq = g->seq;
   return MOEINF_OK;
 }
-// the oldest recorded fence that covers forward #s (an entry that left the ring is covered by every entry still in it), or null
+// ring position of the oldest recorded fence that covers forward #s, -1 if none does.  fence_seq[kFenceRing]: the forward each
+// ring entry was recorded behind, head: fences recorded so far (entry i lives at i % kFenceRing; an entry that left the ring is
+// covered by every entry still in it).  Pure: tests/test_kernel_selection_cpu.py drives it through moeinf_fence_cover_pos
+static inline int fence_cover_pos(const uint64_t* fence_seq, uint64_t head, uint64_t s) {
+  if (head == 0 || fence_seq[(head - 1) % kFenceRing] < s) return -1;
+  const uint64_t lo = head > (uint64_t)kFenceRing ? head - kFenceRing : 0;
+  uint64_t i = head;  // newest first: the covering entries are a suffix of the ring
+  while (i > lo && fence_seq[(i - 1) % kFenceRing] >= s) --i;
+  return (int)(i % kFenceRing);
+}
 static inline hipEvent_t covering_fence(const moeinf_engine* g, uint64_t s) {
-  if (s > g->fenced_seq || g->fence_head == 0) return nullptr;
-  const uint64_t lo = g->fence_head > (uint64_t)kFenceRing ? g->fence_head - kFenceRing : 0;
-  uint64_t i = g->fence_head;  // newest first: the covering entries are a suffix of the ring
-  while (i > lo && g->fence_seq[(i - 1) % kFenceRing] >= s) --i;
-  return g->fence_ev[i % kFenceRing];
+  const int pos = fence_cover_pos(g->fence_seq, g->fence_head, s);
+  return pos < 0 ? nullptr : g->fence_ev[pos];
 }
 // a fence for forward #s (already launched: s <= seq); one is recorded now, behind everything launched so far, if none covers it
 static inline int fence_for(moeinf_engine* g, uint64_t s, hipEvent_t* out) {

@@ -107,3 +107,30 @@ def test_environment_knobs_are_honoured(monkeypatch):
     assert form(BF16, 2, 4096, 14336, 8, 193)[:2] == (12, 0)
     monkeypatch.setenv("MOEINF_RING2_MAX_ROWS", "256")
     assert form(BF16, 2, 4096, 14336, 8, 257)[0] == 0
+
+
+def test_the_fence_ring_returns_the_oldest_recorded_fence_that_covers_a_forward():
+    """Round 6: sync-free forwards record a fence only every MOEINF_FENCE_EVERY-th time, the decision path after every forward, a
+    copy on demand — so the ring holds fences at IRREGULAR forward numbers, and a slot-recycling copy must wait for the oldest
+    entry that covers the slot's last reader (csrc/engine_internal.h fence_cover_pos; a younger one is correct but makes the copy
+    wait for more compute, an older one is a write under a running kernel).  Against a brute-force model, across wrap-around."""
+    import random
+
+    lib = load_library()
+    ring = lib.moeinf_fence_ring()
+    assert ring >= 16
+    rng = random.Random(7)
+    seqs = (C.c_uint64 * ring)()
+    history = []  # (record index, forward) of every fence ever recorded
+    forward = 0
+    assert lib.moeinf_fence_cover_pos(seqs, 0, 1) == -1  # nothing recorded yet
+    for rec in range(5 * ring):
+        forward += rng.choice([1, 1, 1, 2, 16, 16, 32])  # decision-path forwards, on-demand fences, the sync-free cadence
+        seqs[rec % ring] = forward
+        history.append((rec, forward))
+        live = history[-ring:]
+        for s in [1, live[0][1] - 1, live[0][1], live[len(live) // 2][1], live[len(live) // 2][1] + 1, forward - 1, forward, forward + 1]:
+            if s < 1:
+                continue
+            want = next((r % ring for r, f in live if f >= s), -1)
+            assert lib.moeinf_fence_cover_pos(seqs, rec + 1, s) == want, (rec, s, forward)
