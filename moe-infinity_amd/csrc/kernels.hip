@@ -986,86 +986,10 @@ __global__ __launch_bounds__(2 * NWE * 64) void ffn2_decode1_pair_kernel(FfnStag
   }
 }
 
-// The same idea for K = 3..8 (DeepSeek: 6 routed experts + the hidden shared expert): ONE workgroup owns output columns
-// for EVERY chosen expert and combines inside the workgroup.  16 columns x 6 experts would be 264 KB per workgroup and
-// only H/16 = 128 workgroups (half the CUs idle), so a workgroup owns EIGHT columns: rows [8*half, 8*half+8) of a
-// 16-row tile are the lanes with (lane & 15) >> 3 == half — four 128-byte segments of each 1-KiB tile — and the MFMA runs
-// with the other eight A rows zero.  H/8 = 256 workgroups x KX*NWE waves, every weight byte still read exactly once; no
-// write-through stores, no store-ack wait, no arrival counter, no coherent row loads (the 3.5 us tail of the
-// arrival-counter form, tools/ffn_micro.hip).  Wave group g streams expert slot g's half tiles (k-tiles interleaved over
-// its NWE waves), partial sums meet in LDS in wave order, y is rounded once, and the combine (ascending expert id, the
-// shared expert's row — written by the PREVIOUS launch — added last) runs on 8 threads.  Requires K % 32 == 0, T == 1.
-template <int KX, int NWE, int U>
-__global__ __launch_bounds__(KX * NWE * 64) void ffn2_decode1_half_kernel(FfnStage s) {
-  typedef uint16_t T;
-  constexpr int EPT = 32, EPV = 8;
-  __shared__ float red[KX][NWE][8];
-  __shared__ float yv[KX][8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = wave / NWE, wl = wave - g * NWE;
-  const int n = lane & 15, q = lane >> 4;
-  const int rg = blockIdx.x >> 1, half = blockIdx.x & 1, r0 = rg * 16 + half * 8;
-  const char* W = reinterpret_cast<const char*>(s.dec_w[g]);
-  const float cw = s.dec_cw[min(tid, KX - 1)];  // thread g < KX keeps combine weight g (read at kernel start)
-  if (W == nullptr) {  // never on the sync-free path
-    if (tid == 0 && blockIdx.x == 0) atomicExch(s.miss_flag, 1);
-    return;
-  }
-  const int KB = s.K / EPT;
-  const bool mine = (n >> 3) == half;  // this lane's weight row belongs to the workgroup's eight
-  const char* a0 = W + s.off_a + (size_t)rg * KB * 1024 + lane * 16;
-  const T* xr = reinterpret_cast<const T*>(s.in) + (size_t)g * s.ld_in + q * EPV;  // T == 1: h row of slot g
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const u32x4 z = {0u, 0u, 0u, 0u};
-  for (int kb = wl; kb < KB; kb += U * NWE) {
-    u32x4 av[U], xv[U];
-#pragma unroll
-    for (int i = 0; i < U; ++i) {
-      av[i] = z;
-      if (kb + i * NWE < KB) {
-        if (mine) av[i] = ld16_nt(a0 + (size_t)(kb + i * NWE) * 1024);
-        xv[i] = ld16(xr + (size_t)(kb + i * NWE) * EPT);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < U; ++i)
-      if (kb + i * NWE < KB) mma16<T>(acc, av[i], xv[i]);
-  }
-  // every token column of the accumulator holds the same token: lanes n == 0 carry rows q*4 .. q*4+3
-  if (n == 0 && (q >> 1) == half) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[g][wl][(q & 1) * 4 + j] = acc[j];
-  }
-  __syncthreads();
-  if (tid < KX * 8) {  // (expert slot, row): sum the K split in wave order, round once, publish y
-    const int gg = tid >> 3, row = tid & 7;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWE; ++w) v += red[gg][w][row];
-    v = DT<T>::round(v);
-    yv[gg][row] = v;
-    if (r0 + row < s.R) DT<T>::store(reinterpret_cast<T*>(s.out) + (size_t)gg * s.ld_out + r0 + row, v);
-  }
-  __shared__ float cws[KX];
-  if (tid < KX) cws[tid] = cw;
-  __syncthreads();
-  if (tid < 8 && r0 + tid < s.R) {  // combine_apply for one column: ascending expert id, then the shared expert
-    const bool ds = s.comb.kind == 1;
-    float o = 0.f;
-#pragma unroll
-    for (int gg = 0; gg < KX; ++gg) {
-      float p = yv[gg][tid] * cws[gg];
-      if (!ds) p = DT<T>::round(p);
-      o = DT<T>::round(o + p);
-    }
-    if (ds && s.comb.y_shared) {
-      const int row0 = s.comb.shared_offsets ? s.comb.shared_offsets[s.comb.shared_E] : 0;
-      o = DT<T>::round(o + DT<T>::load(reinterpret_cast<const T*>(s.comb.y_shared) + (size_t)row0 * s.comb.H + r0 + tid));
-    }
-    DT<T>::store(reinterpret_cast<T*>(s.comb.out) + r0 + tid, o);
-  }
-}
-
+// (K = 3..8 — DeepSeek: six routed experts + the hidden shared expert — keeps the arrival-counter form.  ONE workgroup per column
+// block with every chosen expert and the combine inside it was built twice: on half tiles, eight columns, 256 workgroups (round 3)
+// and on whole tiles, 128 workgroups of twelve waves (round 6); both measured slower than the tail they remove — 33.3 / 33.0-33.5
+// against 32.5 us per DeepSeek-V2-Lite layer, profiles/r06_deepseek_stage2_group_forms_rejected.txt — and both are deleted.)
 hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
   static const int pair_env = env_int("MOEINF_DEC1_PAIR", 1);  // 0: always the arrival-counter form; 4 / 8: waves per expert
   if (pair_env && (s2.dtype == DT_BF16 || s2.dtype == DT_F16) && s2.comb.K == 2 && (s2.K % 32) == 0 && !(s2.comb.kind == 1 && s2.comb.y_shared) && s2.comb.kind <= 1) {
@@ -1078,29 +1002,6 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
     else if (pu == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 8>), g1, dim3(512), 0, st, s2);
     else if (pu == 2) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 2>), g1, dim3(512), 0, st, s2);
     else hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 4>), g1, dim3(512), 0, st, s2);
-    return hipGetLastError();
-  }
-  // K = 3..8: eight columns per workgroup, every expert and the combine inside it (MOEINF_DEC1_HALF=0: arrival-counter form)
-  // Measured (profiles/r03_deepseek_decode_variants.txt): 1.035 ms/token vs 1.037 for the arrival-counter form — the tail it
-  // removes is paid back by the half-tile loads (32 active lanes, 128-byte segments per instruction): opt-in only.
-  static const int half_env = env_int("MOEINF_DEC1_HALF", 0);
-  // y_shared of a hidden shared expert is written by the previous launch (stage 1 carries its stage 2); a NON-hidden one
-  // (shared_offsets set: its rows are produced by THIS stage) cannot be combined inside the workgroup
-  if (half_env && s2.dtype == DT_BF16 && s2.comb.K >= 3 && s2.comb.K <= 8 && (s2.K % 32) == 0 && s2.comb.kind <= 1 && !s2.comb.shared_offsets) {
-    const dim3 g2(2 * ((s2.R + 15) / 16));
-    static const int hu = env_int("MOEINF_DEC1_HALF_U", 8);
-    // (the 12-tiles-per-batch variants spilled 144 bytes per thread and were never faster: removed in round 4)
-#define HALF(KX, NWE) do { if (hu == 4) hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 4>), g2, dim3(KX * NWE * 64), 0, st, s2); \
-                           else hipLaunchKernelGGL((ffn2_decode1_half_kernel<KX, NWE, 8>), g2, dim3(KX * NWE * 64), 0, st, s2); } while (0)
-    switch (s2.comb.K) {
-      case 3: HALF(3, 4); break;
-      case 4: HALF(4, 4); break;
-      case 5: HALF(5, 3); break;
-      case 6: HALF(6, 2); break;
-      case 7: HALF(7, 2); break;
-      default: HALF(8, 2); break;
-    }
-#undef HALF
     return hipGetLastError();
   }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
