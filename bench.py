@@ -536,18 +536,27 @@ def run_workload(args, workload, B, world, rank, local_rank, dev, use_ep, main, 
                 ev_cost = gaps[len(gaps) // 2]
             except Exception:
                 pass
+            # batch-1 decode launchers carry the timing events on the kernel's own dispatch packet (hipExtLaunchKernel start / stop,
+            # csrc/kernels.h arm_kernel_timer): the interval is then the kernel's begin..end, as rocprofv3 reports it
+            kernel_timed = bool(p.get("kernel_timed_launches")) and p["kernel_timed_launches"] >= p["ffn1_launches"] + p["ffn2_launches"]
             roof = {"bound": "hbm", "kernel": kname + (f"; rank 0 of {world}, owner-side launches" if use_ep else ""),
                     "achieved": k1["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac_of_hbm_peak"],
                     "traffic": traffic,
                     "traffic_source": (f"static: {traffic_src} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, NOT measured in this run)"
                                        if traffic_src else None),
                     "avg_launch_us": k1["avg_launch_us"], "bytes_per_launch": k1["bytes_per_launch"],
+                    "timed_by": ("HIP start/stop events on the kernel's own dispatch packet (hipExtLaunchKernel), on the launch stream"
+                                 if kernel_timed else "HIP events recorded in front of and behind the launch, on the launch stream"),
                     "empty_event_interval_us": None if ev_cost is None else round(ev_cost, 3),
-                    "frac_minus_empty_event_interval": (None if ev_cost is None or k1["avg_launch_us"] <= ev_cost else
+                    "frac_minus_empty_event_interval": (None if kernel_timed or ev_cost is None or k1["avg_launch_us"] <= ev_cost else
                                                         round(k1["bytes_per_launch"] / ((k1["avg_launch_us"] - ev_cost) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)),
-                    "note": "frac = algorithmic bytes / HIP-event interval per launch; an interval with NOTHING between its two records measures "
-                            "empty_event_interval_us on this stream (median of 64, live), so the kernel alone is closer to frac_minus_empty_event_interval "
-                            "— the rocprofv3 kernel-trace average under profiles/ is the kernel's own duration"}
+                    "note": ("frac = algorithmic bytes / the kernel's begin..end interval per launch (the events ride on the launch itself: no "
+                             "event-record packets inside the interval) — comparable with the rocprofv3 kernel-trace average under profiles/; "
+                             "empty_event_interval_us = what two back-to-back event RECORDS measure on this stream, the cost the earlier rounds' lines carried"
+                             if kernel_timed else
+                             "frac = algorithmic bytes / HIP-event interval per launch; an interval with NOTHING between its two records measures "
+                             "empty_event_interval_us on this stream (median of 64, live), so the kernel alone is closer to frac_minus_empty_event_interval "
+                             "— the rocprofv3 kernel-trace average under profiles/ is the kernel's own duration")}
 
     # ---- CPU baseline + full-size parity: the oracle on a bounded sample of the same workload.
     # Expert-parallel runs (world > 1 / --force-ep): EVERY rank checks the sampled (step, layer) pairs of its OWN tokens

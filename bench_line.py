@@ -20,7 +20,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_ok",
-              "avg_launch_us", "bytes_per_launch", "empty_event_interval_us", "frac_minus_empty_event_interval")
+              "avg_launch_us", "bytes_per_launch", "timed_by", "empty_event_interval_us", "frac_minus_empty_event_interval")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "ms_per_token", "host_cores", "sample")
 _REFC_KEYS = ("value", "unit", "cores", "kind", "ms_per_token")
 _PARITY_KEYS = ("ok", "routing_bit_exact", "mean_rel_err", "max_rel_err", "worst_err_over_bar", "pairs_checked", "path")

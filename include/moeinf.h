@@ -316,6 +316,9 @@ typedef struct moeinf_profile {
   double route_ms, ffn1_ms, ffn2_ms, combine_ms;
   double host_wait_ms; /* wall-clock time the host spent blocked on the routing D2H */
   int64_t fused_layers; /* forwards that ran as ONE launch (csrc/layer_fused.hip): all their bytes and time are under ffn1 */
+  int64_t kernel_timed_launches; /* ffn1 / ffn2 launches whose interval is the kernel's OWN begin..end (start / stop events on its
+                                  * dispatch packet, hipExtLaunchKernel: the batch-1 decode launchers) — no event-record packets
+                                  * of the command processor inside it, so it agrees with rocprofv3's duration */
 } moeinf_profile;
 int moeinf_set_profiling(moeinf_engine* eng, int enabled); /* bit 0: per-kernel events; bit 1: per-phase events of moeinf_ep_moe_forward */
 /* synchronises the last stream, returns the accumulated numbers and resets them */

@@ -53,7 +53,7 @@ class Profile(C.Structure):
         ("forwards", C.c_int64), ("ffn1_launches", C.c_int64), ("ffn2_launches", C.c_int64),
         ("ffn1_bytes", C.c_int64), ("ffn2_bytes", C.c_int64), ("route_bytes", C.c_int64), ("combine_bytes", C.c_int64),
         ("route_ms", C.c_double), ("ffn1_ms", C.c_double), ("ffn2_ms", C.c_double), ("combine_ms", C.c_double),
-        ("host_wait_ms", C.c_double), ("fused_layers", C.c_int64),
+        ("host_wait_ms", C.c_double), ("fused_layers", C.c_int64), ("kernel_timed_launches", C.c_int64),
     ]
 
     def as_dict(self):

@@ -1387,7 +1387,10 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
     s1.in = x_in;
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
-    if (prof) HIPCHK(hipEventRecord(pr->ev[2], st));
+    // decode launchers that carry the timer on their own dispatch packet: no event-record packets inside the interval
+    const bool kt1 = prof && sr && (sr->layer1_switch || sr->front1 || T == 1);
+    const bool kt2 = prof && sr && fuse && T == 1;
+    if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[2], st));
     if (sr && sr->layer1_switch) {
       LayerSync sy;
       memset(&sy, 0, sizeof sy);
@@ -1404,9 +1407,10 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       }
       if (!g->d_layer_part) { if (hipMalloc((void**)&g->d_layer_part, (size_t)4 * g->H * sizeof(float)) != hipSuccess) { g->d_layer_part = nullptr; (void)hipGetLastError(); } }
       sy.part = g->d_layer_part;
+      if (kt1 && fuse) arm_kernel_timer(pr->ev[2], pr->ev[3]);  // (a declined launch leaves it armed for the self-routing stage 1 below)
       if (fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, g->layer1_switch_wgs_per_cu, st)) {
         g->layer1_launches += 1;
-        if (prof) { HIPCHK(hipEventRecord(pr->ev[3], st)); HIPCHK(hipEventRecord(pr->ev[4], st)); }
+        if (prof) { HIPCHK(hipEventRecord(pr->ev[4], st)); g->prof.kernel_timed_launches += 1; }
         return MOEINF_OK;
       }
       (void)hipGetLastError();
@@ -1425,15 +1429,19 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
         sy.trace = g->d_layer_trace;
       }
       // (a physical workgroup order that evens out the bytes per CU was measured in round 6: slower, profiles/r06_deepseek_front1_balanced_order_rejected.txt)
+      if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]);
       HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
       g->layer1_launches += 1;  // only a launch that went out moves the grow-only counters' target (a failed one must not leave them out of step)
     } else if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
-    else if (sr) HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st));
+    else if (sr) { if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]); HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st)); }
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
-    if (prof) HIPCHK(hipEventRecord(pr->ev[3], st));
-    if (sr && fuse && T == 1) HIPCHK(launch_ffn2_decode1(s2, st));
-    else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
-    if (prof) HIPCHK(hipEventRecord(pr->ev[4], st));
+    if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[3], st));
+    if (sr && fuse && T == 1) {
+      if (kt2 && (pr->k2 = get_event(g))) arm_kernel_timer(pr->k2, pr->ev[4]);
+      HIPCHK(launch_ffn2_decode1(s2, st));
+    } else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
+    if (prof && !(kt2 && pr->k2)) HIPCHK(hipEventRecord(pr->ev[4], st));
+    if (prof) g->prof.kernel_timed_launches += (kt1 ? 1 : 0) + ((kt2 && pr->k2) ? 1 : 0);
   } else {
     // the index kernel wrote h_mirror itself (pinned, device-visible): wait for it, no copy
     HIPCHK(hipEventRecord(g->route_ev, st));
@@ -1804,9 +1812,10 @@ extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) g->prof.route_ms += ms;
     if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) g->prof.ffn1_ms += ms;
-    if (hipEventElapsedTime(&ms, r.ev[3], r.ev[4]) == hipSuccess) g->prof.ffn2_ms += ms;
+    if (hipEventElapsedTime(&ms, r.k2 ? r.k2 : r.ev[3], r.ev[4]) == hipSuccess) g->prof.ffn2_ms += ms;
     if (hipEventElapsedTime(&ms, r.ev[4], r.ev[5]) == hipSuccess) g->prof.combine_ms += ms;
     for (int i = 0; i < 6; ++i) g->event_pool.push_back(r.ev[i]);
+    if (r.k2) g->event_pool.push_back(r.k2);
   }
   g->prof_pending.clear();
   *out = g->prof;

@@ -381,7 +381,9 @@ struct moeinf_engine {
 
   // profiling
   bool profiling = false, ep_profiling = false;
-  struct ProfRec { hipEvent_t ev[6]; };
+  // ev[0..5]: forward start, after the router, before stage 1, between the stages, after stage 2, end.  Launchers that carry a timer
+  // (kernels.h arm_kernel_timer) get ev[2] / ev[3] as the stage-1 kernel's own begin / end and k2 / ev[4] as stage 2's
+  struct ProfRec { hipEvent_t ev[6]; hipEvent_t k2 = nullptr; };
   std::vector<ProfRec> prof_pending;
   moeinf_profile prof;
 };

@@ -5,11 +5,17 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+// a launch that carries the armed profiling timer, if there is one (kernels.h: arm_kernel_timer)
+#define KL(kern, grid, block, shm, st, ...) do { hipEvent_t ta_, tb_; \
+    if (moeinf::take_kernel_timer(&ta_, &tb_)) hipExtLaunchKernelGGL(kern, grid, block, shm, st, ta_, tb_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, shm, st, __VA_ARGS__); } while (0)
 
 namespace moeinf {
 

@@ -756,6 +756,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
   ffn_rows_item<T, NMAT, NW, U, 1>(s, rg, W, false, 1, u, red, 0);
 }
 
+static thread_local hipEvent_t t_timer_start = nullptr, t_timer_stop = nullptr;
+void arm_kernel_timer(hipEvent_t start, hipEvent_t stop) { t_timer_start = start; t_timer_stop = stop; }
+bool take_kernel_timer(hipEvent_t* start, hipEvent_t* stop) {
+  if (!t_timer_stop) return false;
+  *start = t_timer_start; *stop = t_timer_stop;
+  t_timer_start = t_timer_stop = nullptr;
+  return true;
+}
 hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st) {
   const int n_rg = (s1.R + 15) / 16;
   const int n_sh2 = sh2 ? (sh2->R_sh + 15) / 16 : 0;
@@ -773,20 +781,20 @@ hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const F
   if (s1.epi != EPI_GATED_SILU) {
     // plain experts (Switch, top-1): a grid of at most one workgroup per CU gets sixteen waves per workgroup — the whole
     // work item in flight at once (see launch_ffn_stage)
-    if (s1.dtype == DT_BF16) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
-    else if (s1.dtype == DT_F16) hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
-    else hipLaunchKernelGGL((ffn1_selfroute_kernel<float, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    if (s1.dtype == DT_BF16) KL((ffn1_selfroute_kernel<uint16_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    else if (s1.dtype == DT_F16) KL((ffn1_selfroute_kernel<half_t, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
+    else KL((ffn1_selfroute_kernel<float, 1, 16, 4>), grid, dim3(1024), 0, st, r, a, s1, s1, n_rg, 0);
     return hipGetLastError();
   }
   if (s1.dtype == DT_F16) {  // fp16 gated families: the same kernel on the f16 matrix instruction
-    if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
-    else hipLaunchKernelGGL((ffn1_selfroute_kernel<half_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+    if (sr_u == 8) KL((ffn1_selfroute_kernel<half_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
+    else KL((ffn1_selfroute_kernel<half_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2);
     return hipGetLastError();
   }
   static const int sr_order = env_int("MOEINF_SR_ORDER", 0);
   const int n_sh2_arg = (sr_order && n_sh2 > 0) ? -n_sh2 : n_sh2;
-  if (sr_u == 8) hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
-  else hipLaunchKernelGGL((ffn1_selfroute_kernel<uint16_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
+  if (sr_u == 8) KL((ffn1_selfroute_kernel<uint16_t, 2, 4, 8>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
+  else KL((ffn1_selfroute_kernel<uint16_t, 2, 4, 4>), grid, dim3(256), dyn, st, r, a, s1, sh2 ? *sh2 : s1, n_rg, n_sh2_arg);
   return hipGetLastError();
 }
 
@@ -997,11 +1005,11 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
     // 4 waves per expert (8 per CU), batches of 4 tiles: 38.9 us per Mixtral launch; 8 waves per expert 40.5; the
     // arrival-counter form 41.9
     static const int pu = env_int("MOEINF_DEC1_PAIR_U", 4);
-    if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<half_t, 4, 4>), g1, dim3(512), 0, st, s2);  // fp16: the default form only
-    else if (pair_env == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 8, 4>), g1, dim3(1024), 0, st, s2);
-    else if (pu == 8) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 8>), g1, dim3(512), 0, st, s2);
-    else if (pu == 2) hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 2>), g1, dim3(512), 0, st, s2);
-    else hipLaunchKernelGGL((ffn2_decode1_pair_kernel<uint16_t, 4, 4>), g1, dim3(512), 0, st, s2);
+    if (s2.dtype == DT_F16) KL((ffn2_decode1_pair_kernel<half_t, 4, 4>), g1, dim3(512), 0, st, s2);  // fp16: the default form only
+    else if (pair_env == 8) KL((ffn2_decode1_pair_kernel<uint16_t, 8, 4>), g1, dim3(1024), 0, st, s2);
+    else if (pu == 8) KL((ffn2_decode1_pair_kernel<uint16_t, 4, 8>), g1, dim3(512), 0, st, s2);
+    else if (pu == 2) KL((ffn2_decode1_pair_kernel<uint16_t, 4, 2>), g1, dim3(512), 0, st, s2);
+    else KL((ffn2_decode1_pair_kernel<uint16_t, 4, 4>), g1, dim3(512), 0, st, s2);
     return hipGetLastError();
   }
   const dim3 grid((s2.R + 15) / 16, s2.comb.K);
@@ -1010,27 +1018,27 @@ hipError_t launch_ffn2_decode1(const FfnStage& s2, hipStream_t st) {
     // workgroup's whole 197 KB in flight at once (MOEINF_DEC1_SWITCH_U=4: three batches of four, 10.6 us per launch)
     static const int su = env_int("MOEINF_DEC1_SWITCH_U", 12);
     if (su == 12) {
-      if (s2.dtype == DT_BF16) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 16, 12>), grid, dim3(1024), 0, st, s2);
-      else if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 16, 12>), grid, dim3(1024), 0, st, s2);
-      else hipLaunchKernelGGL((ffn2_decode1_kernel<float, 16, 12>), grid, dim3(1024), 0, st, s2);
+      if (s2.dtype == DT_BF16) KL((ffn2_decode1_kernel<uint16_t, 16, 12>), grid, dim3(1024), 0, st, s2);
+      else if (s2.dtype == DT_F16) KL((ffn2_decode1_kernel<half_t, 16, 12>), grid, dim3(1024), 0, st, s2);
+      else KL((ffn2_decode1_kernel<float, 16, 12>), grid, dim3(1024), 0, st, s2);
       return hipGetLastError();
     }
-    if (s2.dtype == DT_BF16) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 16, 4>), grid, dim3(1024), 0, st, s2);
-    else if (s2.dtype == DT_F16) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 16, 4>), grid, dim3(1024), 0, st, s2);
-    else hipLaunchKernelGGL((ffn2_decode1_kernel<float, 16, 4>), grid, dim3(1024), 0, st, s2);
+    if (s2.dtype == DT_BF16) KL((ffn2_decode1_kernel<uint16_t, 16, 4>), grid, dim3(1024), 0, st, s2);
+    else if (s2.dtype == DT_F16) KL((ffn2_decode1_kernel<half_t, 16, 4>), grid, dim3(1024), 0, st, s2);
+    else KL((ffn2_decode1_kernel<float, 16, 4>), grid, dim3(1024), 0, st, s2);
     return hipGetLastError();
   }
   if (s2.dtype == DT_F16) {  // fp16 gated families: the arrival-counter form
-    if ((size_t)s2.K * 2 >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 8, 4>), grid, dim3(512), 0, st, s2);
-    else hipLaunchKernelGGL((ffn2_decode1_kernel<half_t, 4, 4>), grid, dim3(256), 0, st, s2);
+    if ((size_t)s2.K * 2 >= 16384) KL((ffn2_decode1_kernel<half_t, 8, 4>), grid, dim3(512), 0, st, s2);
+    else KL((ffn2_decode1_kernel<half_t, 4, 4>), grid, dim3(256), 0, st, s2);
     return hipGetLastError();
   }
   const size_t kbytes = (size_t)s2.K * 2;
   static const int du = env_int("MOEINF_DEC1_U", 4);  // k-tiles per wave fetched per batch (short reductions)
-  if (kbytes >= 16384) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);
-  else if (du == 8) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 8>), grid, dim3(256), 0, st, s2);
-  else if (du == 12) hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 12>), grid, dim3(256), 0, st, s2);
-  else hipLaunchKernelGGL((ffn2_decode1_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, s2);
+  if (kbytes >= 16384) KL((ffn2_decode1_kernel<uint16_t, 8, 4>), grid, dim3(512), 0, st, s2);
+  else if (du == 8) KL((ffn2_decode1_kernel<uint16_t, 4, 8>), grid, dim3(256), 0, st, s2);
+  else if (du == 12) KL((ffn2_decode1_kernel<uint16_t, 4, 12>), grid, dim3(256), 0, st, s2);
+  else KL((ffn2_decode1_kernel<uint16_t, 4, 4>), grid, dim3(256), 0, st, s2);
   return hipGetLastError();
 }
 

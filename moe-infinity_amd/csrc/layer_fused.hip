@@ -217,7 +217,7 @@ hipError_t launch_moe_front1(const RouteArgs& r, const IndexArgs& a, const FfnSt
   const int rl = r.kind != 0 ? 0 : (r.x_dtype == DT_BF16 ? 1 : (r.x_dtype == DT_F16 ? 2 : 0));
   const FfnStage& a1 = sh1 ? *sh1 : s1;
   const FfnStage& a2 = sh2 ? *sh2 : s1;
-#define F1(TT, GW, UU) hipLaunchKernelGGL((moe_front1_kernel<TT, GW, UU>), grid, dim3(256), dyn, st, r, a, a1, a2, s1, sy, rl, n_sh1, n_sh2)
+#define F1(TT, GW, UU) KL((moe_front1_kernel<TT, GW, UU>), grid, dim3(256), dyn, st, r, a, a1, a2, s1, sy, rl, n_sh1, n_sh2)
 #define F1U(TT, GW) do { if (sr_u == 8) F1(TT, GW, 8); else F1(TT, GW, 4); } while (0)
   if (s1.dtype == DT_BF16) { if (r.gate_dtype == DT_BF16) F1U(uint16_t, uint16_t); else if (r.gate_dtype == DT_F32) F1U(uint16_t, float); else return hipErrorInvalidValue; }
   else if (s1.dtype == DT_F16) { if (r.gate_dtype == DT_F16) F1U(half_t, half_t); else if (r.gate_dtype == DT_F32) F1U(half_t, float); else return hipErrorInvalidValue; }
@@ -381,10 +381,10 @@ bool launch_moe_layer1_switch(const RouteArgs& r, const IndexArgs& a, const FfnS
   if (per_cu == 0 || (int)grid.x > per_cu * num_cus || (s2.K % (ept * KS)) != 0 || (s1.K % ept) != 0 || s2.K / ept / KS > NW * P2 || r.K != 1 || s2.dtype == DT_F16 || !sy.part) return false;
   if (s2.dtype == DT_F32) {
     if (r.gate_dtype != DT_F32) return false;
-    hipLaunchKernelGGL((moe_layer1_switch_kernel<float, float, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
+    KL((moe_layer1_switch_kernel<float, float, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
   } else {
-    if (r.gate_dtype == DT_BF16) hipLaunchKernelGGL((moe_layer1_switch_kernel<uint16_t, uint16_t, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
-    else if (r.gate_dtype == DT_F32) hipLaunchKernelGGL((moe_layer1_switch_kernel<uint16_t, float, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
+    if (r.gate_dtype == DT_BF16) KL((moe_layer1_switch_kernel<uint16_t, uint16_t, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
+    else if (r.gate_dtype == DT_F32) KL((moe_layer1_switch_kernel<uint16_t, float, P2, KS>), grid, dim3(512), 0, st, r, a, s1, s2, sy);
     else return false;
   }
   return hipGetLastError() == hipSuccess;

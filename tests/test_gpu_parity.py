@@ -1081,3 +1081,35 @@ def test_fp16_experts_all_families(family, e, k, n_shared, t):
         assert float((err / floor).mean()) <= 1e-3
         assert float((err / floor).max()) <= 4e-3, float((err / floor).max())
     eng.close()
+
+
+@pytest.mark.parametrize("family,e,k,n_shared", [("mixtral", 8, 2, 0), ("deepseek", 64, 6, 2)], ids=["mixtral", "deepseek_shared"])
+def test_profiling_times_the_batch1_kernels_themselves_and_changes_no_result(family, e, k, n_shared):
+    """Round 6: with profiling on, the batch-1 decode launchers carry the timing events on the launch (hipExtLaunchKernel start /
+    stop: the kernel's own begin and end, no event-record packets inside the interval — csrc/kernels.h arm_kernel_timer), and
+    moeinf_profile.kernel_timed_launches says so.  Every such interval must exist and be positive, the outputs must be the bits
+    of the unprofiled forward, and a three-token forward (another launcher) must still be timed the recorded-events way."""
+    h, f = 512, 384
+    gate, experts, shared = make_weights(family, h, f, e, 6100 + e, torch.bfloat16, n_shared=n_shared)
+    eng = engine_for(family, h, f, e, k, torch.bfloat16, n_shared=n_shared, max_tokens=4)
+    register_all(eng, experts, shared)
+    g = gate.to(DEV)
+    eng.prefetch(0, list(range(e)))
+    eng.sync_copies()
+    xs = [acts(1, h, torch.bfloat16, 6200 + i).to(DEV) for i in range(5)]
+    eng.forward(0, xs[0], g)  # (settles the copies: decision path)
+    plain = [eng.forward(0, x, g).clone() for x in xs]
+    eng.set_profiling(True)
+    timed = [eng.forward(0, x, g).clone() for x in xs]
+    p = eng.profile()
+    for a, b in zip(plain, timed):
+        assert torch.equal(a, b)
+    assert p["forwards"] == 5 and p["ffn1_launches"] == 5 and p["ffn2_launches"] == 5, p
+    assert p["kernel_timed_launches"] == 10, p
+    assert 0.0 < p["ffn1_ms"] < 5.0 and 0.0 < p["ffn2_ms"] < 5.0, p
+    x3 = acts(3, h, torch.bfloat16, 6300).to(DEV)
+    eng.forward(0, x3, g)
+    p = eng.profile()
+    assert p["forwards"] == 1 and p["kernel_timed_launches"] == 0 and p["ffn1_ms"] > 0.0, p
+    eng.set_profiling(False)
+    eng.close()
