@@ -1407,8 +1407,10 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       }
       if (!g->d_layer_part) { if (hipMalloc((void**)&g->d_layer_part, (size_t)4 * g->H * sizeof(float)) != hipSuccess) { g->d_layer_part = nullptr; (void)hipGetLastError(); } }
       sy.part = g->d_layer_part;
-      if (kt1 && fuse) arm_kernel_timer(pr->ev[2], pr->ev[3]);  // (a declined launch leaves it armed for the self-routing stage 1 below)
-      if (fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, g->layer1_switch_wgs_per_cu, st)) {
+      if (kt1 && fuse) arm_kernel_timer(pr->ev[2], pr->ev[3]);
+      const bool one_launch = fuse && launch_moe_layer1_switch(*sr->ra, *sr->ia, s1, s2, sy, ncu, g->layer1_switch_wgs_per_cu, st);
+      disarm_kernel_timer();  // (declined or failed before taking it: the self-routing stage 1 below arms its own)
+      if (one_launch) {
         g->layer1_launches += 1;
         if (prof) { HIPCHK(hipEventRecord(pr->ev[4], st)); g->prof.kernel_timed_launches += 1; }
         return MOEINF_OK;
@@ -1430,15 +1432,24 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       }
       // (a physical workgroup order that evens out the bytes per CU was measured in round 6: slower, profiles/r06_deepseek_front1_balanced_order_rejected.txt)
       if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]);
-      HIPCHK(launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st));
+      const hipError_t le = launch_moe_front1(*sr->ra, *sr->ia, sr->sh1, sr->sh2, s1, sy, st);
+      disarm_kernel_timer();
+      HIPCHK(le);
       g->layer1_launches += 1;  // only a launch that went out moves the grow-only counters' target (a failed one must not leave them out of step)
     } else if (sr && T > 1) HIPCHK(launch_ffn1_selfroute_multi(*sr->ra, *sr->ia, s1, sr->sh2, std::min(E, T * g->K), st));
-    else if (sr) { if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]); HIPCHK(launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st)); }
+    else if (sr) {
+      if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]);
+      const hipError_t le = launch_ffn1_selfroute(*sr->ra, *sr->ia, s1, sr->sh2, st);
+      disarm_kernel_timer();
+      HIPCHK(le);
+    }
     else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
     if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[3], st));
     if (sr && fuse && T == 1) {
       if (kt2 && (pr->k2 = get_event(g))) arm_kernel_timer(pr->k2, pr->ev[4]);
-      HIPCHK(launch_ffn2_decode1(s2, st));
+      const hipError_t le = launch_ffn2_decode1(s2, st);
+      disarm_kernel_timer();
+      HIPCHK(le);
     } else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
     if (prof && !(kt2 && pr->k2)) HIPCHK(hipEventRecord(pr->ev[4], st));
     if (prof) g->prof.kernel_timed_launches += (kt1 ? 1 : 0) + ((kt2 && pr->k2) ? 1 : 0);

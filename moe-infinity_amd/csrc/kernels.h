@@ -254,6 +254,7 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
 // the round-3..5 bench lines sat that far above rocprofv3's durations).  Thread-local; consumed by one launch.
 void arm_kernel_timer(hipEvent_t start, hipEvent_t stop);
 bool take_kernel_timer(hipEvent_t* start, hipEvent_t* stop);
+inline void disarm_kernel_timer() { hipEvent_t a, b; (void)take_kernel_timer(&a, &b); }  // after a launch that may have failed before taking it
 hipError_t launch_ffn1_selfroute(const RouteArgs& r, const IndexArgs& a, const FfnStage& s1, const FfnStage* sh2, hipStream_t st);
 // The same for decode batches of 2..8 tokens (bf16 / fp16 gated families, T*K <= 64): the meta block routes every token and
 // builds the index, every other workgroup routes the tokens for itself; stage 2 is the generic launch_ffn_stage (combine fused).
