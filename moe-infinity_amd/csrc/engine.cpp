@@ -1388,8 +1388,9 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
     fill_stage(g, layer, 2, s2);
     if (fuse) { s2.fuse_combine = fuse_mode(); s2.tile_done = g->d_arrive; s2.comb = *fuse; if (fused) *fused = true; }
     // decode launchers that carry the timer on their own dispatch packet: no event-record packets inside the interval
-    const bool kt1 = prof && sr && (sr->layer1_switch || sr->front1 || T == 1);
-    const bool kt2 = prof && sr && fuse && T == 1;
+    // (every FFN-stage launcher is ONE launch and carries the timer; the small-batch self-routing stage 1 is the exception)
+    const bool kt1 = prof && !(sr && !sr->layer1_switch && !sr->front1 && T > 1);
+    const bool kt2 = prof;
     if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[2], st));
     if (sr && sr->layer1_switch) {
       LayerSync sy;
@@ -1443,14 +1444,19 @@ int dispatch_experts(moeinf_engine* g, int layer, const void* x_in, int64_t ld_x
       disarm_kernel_timer();
       HIPCHK(le);
     }
-    else HIPCHK(launch_ffn_stage(s1, max_active, exp_rows, st));
-    if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[3], st));
-    if (sr && fuse && T == 1) {
-      if (kt2 && (pr->k2 = get_event(g))) arm_kernel_timer(pr->k2, pr->ev[4]);
-      const hipError_t le = launch_ffn2_decode1(s2, st);
+    else {
+      if (kt1) arm_kernel_timer(pr->ev[2], pr->ev[3]);
+      const hipError_t le = launch_ffn_stage(s1, max_active, exp_rows, st);
       disarm_kernel_timer();
       HIPCHK(le);
-    } else HIPCHK(launch_ffn_stage(s2, max_active, exp_rows, st));
+    }
+    if (prof && !kt1) HIPCHK(hipEventRecord(pr->ev[3], st));
+    {
+      if (kt2 && (pr->k2 = get_event(g))) arm_kernel_timer(pr->k2, pr->ev[4]);
+      const hipError_t le = (sr && fuse && T == 1) ? launch_ffn2_decode1(s2, st) : launch_ffn_stage(s2, max_active, exp_rows, st);
+      disarm_kernel_timer();
+      HIPCHK(le);
+    }
     if (prof && !(kt2 && pr->k2)) HIPCHK(hipEventRecord(pr->ev[4], st));
     if (prof) g->prof.kernel_timed_launches += (kt1 ? 1 : 0) + ((kt2 && pr->k2) ? 1 : 0);
   } else {
@@ -1821,10 +1827,12 @@ extern "C" int moeinf_get_profile(moeinf_engine* g, moeinf_profile* out) {
   drain_mirrors(g, true);
   for (auto& r : g->prof_pending) {
     float ms = 0.f;
+    // (an interval whose events were never recorded fails here and is skipped; its error must not stay in the sticky slot)
     if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) g->prof.route_ms += ms;
     if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) g->prof.ffn1_ms += ms;
     if (hipEventElapsedTime(&ms, r.k2 ? r.k2 : r.ev[3], r.ev[4]) == hipSuccess) g->prof.ffn2_ms += ms;
     if (hipEventElapsedTime(&ms, r.ev[4], r.ev[5]) == hipSuccess) g->prof.combine_ms += ms;
+    (void)hipGetLastError();
     for (int i = 0; i < 6; ++i) g->event_pool.push_back(r.ev[i]);
     if (r.k2) g->event_pool.push_back(r.k2);
   }

@@ -580,10 +580,10 @@ bool launch_ffn_gemm_big(const FfnStage& s, int nmat, dim3 grid, int max_rows, h
   static const int ring3 = env_int("MOEINF_GEMM_BIG_RING3", 1);
   static const int tail_max = env_int("MOEINF_GEMM_BIG_TAIL", 128);  // tokens up to which a last pass runs the short-pass variant (0: never)
   static const int mode = env_int("MOEINF_GEMM_BIG_MODE", 2);  // 2: ping-pong (the two waves of a SIMD alternate load / compute slots), 1: both in step
-#define BIGGO(NM, R3, MD) hipLaunchKernelGGL((ffn_gemm_big_kernel<uint16_t, NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus)
+#define BIGGO(NM, R3, MD) KL((ffn_gemm_big_kernel<uint16_t, NM, R3, MD>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus)
   if (s.dtype == DT_F16) {  // fp16 experts: the default schedule only (three-deep weight ring, ping-pong)
-    if (nmat == 2) hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 2, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
-    else hipLaunchKernelGGL((ffn_gemm_big_kernel<half_t, 1, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
+    if (nmat == 2) KL((ffn_gemm_big_kernel<half_t, 2, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
+    else KL((ffn_gemm_big_kernel<half_t, 1, true, 2>), g, dim3(512), 0, st, s, nx, ny, nz, xcd_map, tail_max, chunk, move_short, num_cus);
     return true;
   }
   if (ring3) {

@@ -555,7 +555,7 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
     static const int kk = env_int("MOEINF_GEMM_HYB_KK", 4);
     static const int hxl_env = env_int("MOEINF_GEMM_XL", 1);
     const bool hxl = hxl_env && (s.K % (2 * ept)) == 0 && (s.K_sh % (2 * ept)) == 0;
-#define HYB(NM, RWV, KKV, XLV) hipLaunchKernelGGL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV, XLV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
+#define HYB(NM, RWV, KKV, XLV) KL((ffn_gemm_hyb_kernel<T, NM, RWV, KKV, XLV>), dim3((grid.x + 4 * RWV - 1) / (4 * RWV), grid.y), dim3(256), 0, st, s)
     if constexpr (NMAT == 2) {
       if (kk == 2) { if (hxl) HYB(2, 1, 2, true); else HYB(2, 1, 2, false); }
       else { if (hxl) HYB(2, 1, 4, true); else HYB(2, 1, 4, false); }
@@ -571,7 +571,7 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
     static const int xl_env = env_int("MOEINF_GEMM_XL", 1);
     const bool xl = xl_env && (s.K % (2 * ept)) == 0 && (s.K_sh % (2 * ept)) == 0;  // full-line activation staging
     auto go = [&](auto kern, int rgb, int nwv) {
-      hipLaunchKernelGGL(kern, dim3((grid.x + rgb - 1) / rgb, grid.y), dim3(nwv * 64), 0, st, s);
+      KL(kern, dim3((grid.x + rgb - 1) / rgb, grid.y), dim3(nwv * 64), 0, st, s);
     };
 #define GO(NM, RG, NW) do { if (xl) go(ffn_gemm_lds_kernel<T, NM, RG, NW, true>, RG, NW); else go(ffn_gemm_lds_kernel<T, NM, RG, NW, false>, RG, NW); } while (0)
     if constexpr (NMAT == 2) {
@@ -588,11 +588,11 @@ bool launch_ffn_gemm(const FfnStage& s, dim3 grid, int max_rows, hipStream_t st)
   } else if (use_gemm) {
     const int nt = force_nt ? force_nt : 4;  // measured: (RG,NT)=(2,4)/(4,4) beats (1,8)/(2,8) at t_e ~128 (profiles/r01_ffn_sweep_prefill_gemm.txt)
     if constexpr (NMAT == 2) {  // gated: 2 matrices -> (RG, NT) = (2,4) or (1,8)
-      if (nt <= 4) hipLaunchKernelGGL((ffn_gemm_kernel<T, 2, 2, 4, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
-      else hipLaunchKernelGGL((ffn_gemm_kernel<T, 2, 1, 8, 4>), grid, dim3(256), 0, st, s);
+      if (nt <= 4) KL((ffn_gemm_kernel<T, 2, 2, 4, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
+      else KL((ffn_gemm_kernel<T, 2, 1, 8, 4>), grid, dim3(256), 0, st, s);
     } else {                    // plain: (4,4) or (2,8)
-      if (nt <= 4) hipLaunchKernelGGL((ffn_gemm_kernel<T, 1, 4, 4, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
-      else hipLaunchKernelGGL((ffn_gemm_kernel<T, 1, 2, 8, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
+      if (nt <= 4) KL((ffn_gemm_kernel<T, 1, 4, 4, 4>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, s);
+      else KL((ffn_gemm_kernel<T, 1, 2, 8, 4>), dim3((grid.x + 1) / 2, grid.y), dim3(256), 0, st, s);
     }
   } else {
     return false;

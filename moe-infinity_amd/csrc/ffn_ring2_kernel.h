@@ -284,18 +284,18 @@ static void launch_ring2(const FfnStage& s0, dim3 grid, const Ring2Form& f, hipS
     if (f.tail) {
       s.ring2_nblk = f.nblk; s.ring2_split = f.split;
       const dim3 g1((unsigned)f.blocks);
-      if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
-      else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
-      else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3, true>), g1, dim3(512), 0, st, s);
+      if (f.ntb == 8) KL((ffn_gemm_ring2_kernel<T, 2, 8, 4, true>), g1, dim3(512), 0, st, s);
+      else if (f.ntb == 12) KL((ffn_gemm_ring2_kernel<T, 2, 12, 3, true>), g1, dim3(512), 0, st, s);
+      else KL((ffn_gemm_ring2_kernel<T, 2, 16, 3, true>), g1, dim3(512), 0, st, s);
       return;
     }
-    if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
-    else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
-    else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);
+    if (f.ntb == 8) KL((ffn_gemm_ring2_kernel<T, 2, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (f.ntb == 12) KL((ffn_gemm_ring2_kernel<T, 2, 12, 3>), g2, dim3(512), 0, st, s);  // (D = 4: 386 vs 380 us and 16 B of scratch)
+    else KL((ffn_gemm_ring2_kernel<T, 2, 16, 3>), g2, dim3(512), 0, st, s);
   } else {
-    if (f.ntb == 8) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
-    else if (f.ntb == 12) hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
-    else hipLaunchKernelGGL((ffn_gemm_ring2_kernel<T, 1, 16, 4>), g2, dim3(512), 0, st, s);
+    if (f.ntb == 8) KL((ffn_gemm_ring2_kernel<T, 1, 8, 4>), g2, dim3(512), 0, st, s);
+    else if (f.ntb == 12) KL((ffn_gemm_ring2_kernel<T, 1, 12, 4>), g2, dim3(512), 0, st, s);  // (D = 6: 199 vs 201 us)
+    else KL((ffn_gemm_ring2_kernel<T, 1, 16, 4>), g2, dim3(512), 0, st, s);
   }
 }
 

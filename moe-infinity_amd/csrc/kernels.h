@@ -248,8 +248,8 @@ hipError_t launch_route_shared2(const RouteArgs& r, const IndexArgs& a, const Ff
 // Batch-1 decode of the gated families (bf16, T == 1, K <= 8, T*K <= 64, every owned expert resident): FFN stage 1 that
 // routes for itself from the gate logits (no top-k/index launch).  r/a as for launch_route_index (a.shared must be 0),
 // s1 = the routed stage-1 descriptor, sh2 = the hidden shared expert's stage-2 descriptor or nullptr.
-// Profiling: events armed here ride on the NEXT launch of a launcher that supports it (launch_ffn1_selfroute, launch_ffn2_decode1,
-// launch_moe_front1) as hipExtLaunchKernel's start / stop events — the kernel's own begin and end on its dispatch packet.  An event
+// Profiling: events armed here ride on the NEXT launch made through the KL macro (kdev.h: every FFN-stage launcher — launch_ffn_stage's
+// kernels, launch_ffn1_selfroute, launch_ffn2_decode1, launch_moe_front1, launch_moe_layer1_switch) as hipExtLaunchKernel's start / stop events — the kernel's own begin and end on its dispatch packet.  An event
 // RECORD in front of and behind a launch puts the command processor's barrier packets inside the interval (2.5-4 us per launch:
 // the round-3..5 bench lines sat that far above rocprofv3's durations).  Thread-local; consumed by one launch.
 void arm_kernel_timer(hipEvent_t start, hipEvent_t stop);

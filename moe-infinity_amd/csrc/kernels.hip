@@ -293,7 +293,7 @@ bool launch_ffn_gemm_ring2_f16(const FfnStage& s, int nmat, dim3 grid, int max_r
 
 template <typename T, int NMAT>
 static void launch_ffn_t(const FfnStage& s, dim3 grid, int nw, int u, bool many_tokens, int max_rows, hipStream_t st) {
-#define LAUNCH(NWV, UU, NTT) hipLaunchKernelGGL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
+#define LAUNCH(NWV, UU, NTT) KL((ffn_rows_kernel<T, NMAT, NWV, UU, NTT>), grid, dim3(NWV * 64), 0, st, s)
   if (many_tokens) {  // grouped GEMM kernels (ffn_gemm.hip); MOEINF_FFN_GEMM=0: the decode kernel looping 4 token tiles
     if constexpr (sizeof(T) == 2 && !std::is_same<T, uint16_t>::value) {
       // fp16 experts: the register ring first (long reductions, up to 340 rows per expert; its own translation unit), then
